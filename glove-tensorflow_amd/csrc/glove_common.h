@@ -1,0 +1,137 @@
+// Shared device helpers for the gfx950 GloVe kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/glove_hip.h"
+
+namespace glove {
+
+using f4 = float __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;        // 4 waves per workgroup
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
+constexpr int kPartials = 4;       // per-block loss partials: sum w diff^2, sum |r|^2+|c|^2, sum b^2, sum e
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- cross-lane sums ------------------------------------------------------------------
+// Butterfly all-reduce inside an aligned group of LPR lanes.  Strides 1,2 use quad_perm DPP;
+// 4 and 8 use row_half_mirror / row_mirror (valid as butterfly steps because the lanes of
+// each already-reduced sub-group hold the same value); 16 and 32 cross DPP rows.
+template <int CTRL>
+__device__ inline float dpp_add(float v)
+{
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(x);
+}
+
+template <int LPR>
+__device__ inline float group_sum(float v)
+{
+    static_assert(LPR == 16 || LPR == 32 || LPR == 64, "group width");
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ inline float wave_sum(float v) { return group_sum<64>(v); }
+
+__device__ inline float dot4(const f4 a, const f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// Per-workgroup reduction of kPartials running sums into out[blockIdx.x][kPartials].
+// Fixed order (lane butterfly, then waves 0..3) => bitwise repeatable for a fixed grid.
+__device__ inline void block_partials_store(float (&acc)[kPartials], float *out)
+{
+    __shared__ float red[kBlock / 64][kPartials];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kPartials; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < kPartials; ++i) red[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartials) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < kBlock / 64; ++wv) s += red[wv][threadIdx.x];
+        out[(size_t)blockIdx.x * kPartials + threadIdx.x] = s;
+    }
+}
+
+// ---- step workspace layout ----------------------------------------------------------------
+struct StepWs {
+    float *e;        // [B]            per-pair error coefficient, row-sorted order
+    float *gp_r;     // [cap_chunks*d] row-side chunk partial gradient rows
+    float *gp_c;     // [cap_chunks*d] col-side
+    float *gb_r;     // [cap_chunks]   row-side chunk partial bias gradients (sum e)
+    float *gb_c;     // [cap_chunks]
+    float *blockpart;  // [kMaxBlocks*kPartials]
+    size_t bytes;
+};
+
+inline StepWs carve_step_ws(void *ws, int64_t B, int32_t cap_chunks, int32_t d)
+{
+    StepWs s;
+    size_t off = 0;
+    char *base = (char *)ws;
+    auto take = [&](size_t nfloats) {
+        float *p = (float *)(base + off);
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    s.e = take((size_t)B);
+    s.gp_r = take((size_t)cap_chunks * d);
+    s.gp_c = take((size_t)cap_chunks * d);
+    s.gb_r = take((size_t)cap_chunks);
+    s.gb_c = take((size_t)cap_chunks);
+    s.blockpart = take((size_t)kMaxBlocks * kPartials);
+    s.bytes = off;
+    return s;
+}
+
+inline int blocks_for(int64_t items, int per_block)
+{
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+// (lanes per row, float4 per lane) covering d4 = d/4 float4 per embedding row with the least
+// idle lanes; a wave64 holds 64/LPR rows at a time.
+struct RowShape { int lpr, nv; };
+inline RowShape pick_row_shape(int d4)
+{
+    const RowShape cands[] = {{16, 1}, {32, 1}, {16, 2}, {64, 1}, {32, 2}, {32, 3}, {64, 2}, {64, 3}, {64, 4}};
+    RowShape best = {0, 0};
+    int best_slots = 1 << 30;
+    for (const RowShape &c : cands) {
+        const int slots = c.lpr * c.nv;
+        if (slots >= d4 && slots < best_slots) { best = c; best_slots = slots; }
+    }
+    return best;
+}
+
+#define GLOVE_DISPATCH_ROW_SHAPE(shape, CALL)                                   \
+    do {                                                                        \
+        const int key_ = (shape).lpr * 8 + (shape).nv;                          \
+        switch (key_) {                                                         \
+        case 16 * 8 + 1: { CALL(16, 1); } break;                                \
+        case 16 * 8 + 2: { CALL(16, 2); } break;                                \
+        case 32 * 8 + 1: { CALL(32, 1); } break;                                \
+        case 32 * 8 + 2: { CALL(32, 2); } break;                                \
+        case 32 * 8 + 3: { CALL(32, 3); } break;                                \
+        case 64 * 8 + 1: { CALL(64, 1); } break;                                \
+        case 64 * 8 + 2: { CALL(64, 2); } break;                                \
+        case 64 * 8 + 3: { CALL(64, 3); } break;                                \
+        case 64 * 8 + 4: { CALL(64, 4); } break;                                \
+        default: return GLOVE_E_BADARG;                                         \
+        }                                                                       \
+    } while (0)
+
+}  // namespace glove

@@ -1,0 +1,200 @@
+// Per-batch dedup index ("plan") built on the device.
+//
+// Replaces the bookkeeping half of OptimizerV2._resource_apply_sparse_duplicate_indices, i.e. the
+// tf.unique + unsorted_segment_sum pair Keras runs on each of the four IndexedSlices gradients
+// of every step (reached from reference src/models/train_utils.py:13-16).  The
+// sums themselves happen in glove_step.hip; this file only orders the pairs.
+//
+// Integer work: stable LSD radix sorts (rocPRIM device primitives) + two scans per side.  The
+// result is bit-exact against oracle/glove_ref.py:build_plan.
+#include "glove_common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+namespace glove {
+
+__global__ void iota_kernel(int32_t *out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)i;
+}
+
+// row side: pull col/w/y through the row-sort permutation
+__global__ void gather_row_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ col,
+                                const float *__restrict__ w, const float *__restrict__ y, int64_t n,
+                                int32_t *__restrict__ partner, float *__restrict__ ow, float *__restrict__ oy)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = perm[i];
+        partner[i] = col[p];
+        ow[i] = w[p];
+        oy[i] = y[p];
+    }
+}
+
+// col side: partner = row id of the row-sorted pair the permutation points at
+__global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ sorted_row, int64_t n,
+                                int32_t *__restrict__ partner)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        partner[i] = sorted_row[perm[i]];
+}
+
+// seg_start_in[k] = k where a new id starts, else 0 (max-scan turns it into "start of my run")
+__global__ void mark_runs(const int32_t *__restrict__ keys, int64_t n, int32_t *__restrict__ run_start)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        run_start[i] = (i == 0 || keys[i] != keys[i - 1]) ? (int32_t)i : 0;
+}
+
+// flags packed as (is_unique << 32) | is_chunk so that one 64-bit sum-scan numbers both
+__global__ void mark_chunks(const int32_t *__restrict__ keys, const int32_t *__restrict__ run_start, int64_t n,
+                            int32_t chunk_cap, uint64_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool uniq = (i == 0 || keys[i] != keys[i - 1]);
+        const bool chunk = uniq || ((i - run_start[i]) % chunk_cap == 0);
+        flags[i] = ((uint64_t)uniq << 32) | (uint64_t)chunk;
+    }
+}
+
+__global__ void emit_side(const int32_t *__restrict__ keys, const uint64_t *__restrict__ flags,
+                          const uint64_t *__restrict__ scanned, int64_t n, int32_t *__restrict__ chunk_id,
+                          int32_t *__restrict__ chunk_start, int32_t *__restrict__ uniq_slot,
+                          int32_t *__restrict__ counts /* [0]=chunks [1]=uniq */)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t f = flags[i], sc = scanned[i];
+        const int32_t ci = (int32_t)(sc & 0xffffffffu) - 1;
+        const int32_t ui = (int32_t)(sc >> 32) - 1;
+        if (f & 1u) { chunk_id[ci] = keys[i]; chunk_start[ci] = (int32_t)i; }
+        if (f >> 32) uniq_slot[ui] = ci;
+        if (i == n - 1) {
+            chunk_start[ci + 1] = (int32_t)n;
+            uniq_slot[ui + 1] = ci + 1;
+            counts[0] = ci + 1;
+            counts[1] = ui + 1;
+        }
+    }
+}
+
+struct PlanWs {
+    int32_t *iota, *perm, *keys_sorted, *row_sorted, *run_start;
+    uint64_t *flags, *scanned;
+    void *prim;          // rocPRIM temporary storage
+    size_t prim_bytes;
+    size_t bytes;
+};
+
+static size_t prim_budget(int64_t B) { return (size_t)(4u << 20) + (size_t)B * 24; }
+
+static PlanWs carve_plan_ws(void *ws, int64_t B)
+{
+    PlanWs p;
+    size_t off = 0;
+    char *base = (char *)ws;
+    auto take = [&](size_t bytes) { void *q = base + off; off += align_up(bytes, 256); return q; };
+    const size_t n = (size_t)(B > 0 ? B : 1);
+    p.iota = (int32_t *)take(n * 4);
+    p.perm = (int32_t *)take(n * 4);
+    p.keys_sorted = (int32_t *)take(n * 4);
+    p.row_sorted = (int32_t *)take(n * 4);
+    p.run_start = (int32_t *)take(n * 4);
+    p.flags = (uint64_t *)take(n * 8);
+    p.scanned = (uint64_t *)take(n * 8);
+    p.prim_bytes = prim_budget(B);
+    p.prim = take(p.prim_bytes);
+    p.bytes = off;
+    return p;
+}
+
+static int ceil_log2(int32_t v)
+{
+    int b = 1;
+    while (b < 31 && (1 << b) < v) ++b;
+    return b;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static int build_side(const int32_t *keys_sorted, int64_t B, int32_t chunk_cap, const PlanWs &w, int32_t *chunk_id,
+                      int32_t *chunk_start, int32_t *uniq_slot, int32_t *counts, hipStream_t st)
+{
+    const int nb = blocks_for(B, kBlock);
+    hipLaunchKernelGGL(mark_runs, dim3(nb), dim3(kBlock), 0, st, keys_sorted, B, w.run_start);
+    size_t need = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, need, w.run_start, w.run_start, (size_t)B, rocprim::maximum<int32_t>(), st));
+    if (need > w.prim_bytes) return GLOVE_E_WORKSPACE;
+    HIP_TRY(rocprim::inclusive_scan(w.prim, need, w.run_start, w.run_start, (size_t)B, rocprim::maximum<int32_t>(), st));
+    hipLaunchKernelGGL(mark_chunks, dim3(nb), dim3(kBlock), 0, st, keys_sorted, w.run_start, B, chunk_cap, w.flags);
+    HIP_TRY(rocprim::inclusive_scan(nullptr, need, w.flags, w.scanned, (size_t)B, rocprim::plus<uint64_t>(), st));
+    if (need > w.prim_bytes) return GLOVE_E_WORKSPACE;
+    HIP_TRY(rocprim::inclusive_scan(w.prim, need, w.flags, w.scanned, (size_t)B, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(emit_side, dim3(nb), dim3(kBlock), 0, st, keys_sorted, w.flags, w.scanned, B, chunk_id,
+                       chunk_start, uniq_slot, counts);
+    return (int)hipGetLastError();
+}
+
+}  // namespace glove
+
+using namespace glove;
+
+extern "C" {
+
+size_t glove_plan_workspace_bytes(int64_t B, int32_t V)
+{
+    (void)V;
+    if (B < 0) return 0;
+    return carve_plan_ws(nullptr, B).bytes;
+}
+
+int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
+                     const glove_plan *plan, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!plan || !ws || B < 0 || V <= 0 || plan->chunk_cap <= 0 || plan->B != B || !plan->counts) return GLOVE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        HIP_TRY(hipMemsetAsync(plan->counts, 0, 4 * sizeof(int32_t), st));
+        return 0;
+    }
+    if (!row || !col || !w || !y) return GLOVE_E_BADARG;
+    if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
+        !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
+        return GLOVE_E_BADARG;
+    // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
+    if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
+    const PlanWs pw = carve_plan_ws(ws, B);
+    if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+
+    const int nb = blocks_for(B, kBlock);
+    const int bits = ceil_log2(V);
+    size_t need = 0;
+
+    // ---- row side: stable sort (row id, position)
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(kBlock), 0, st, pw.iota, B);
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, row, pw.row_sorted, pw.iota, pw.perm, (size_t)B, 0, bits, st));
+    if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
+    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, row, pw.row_sorted, pw.iota, pw.perm, (size_t)B, 0, bits, st));
+    hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, col, w, y, B, plan->r_partner,
+                       plan->r_w, plan->r_y);
+    if (int rc = build_side(pw.row_sorted, B, plan->chunk_cap, pw, plan->r_chunk_id, plan->r_chunk_start,
+                            plan->r_uniq_slot, plan->counts + 0, st))
+        return rc;
+
+    // ---- col side: stable sort of the row-sorted pairs by col id
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
+                                      plan->c_perm, (size_t)B, 0, bits, st));
+    if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
+    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
+                                      plan->c_perm, (size_t)B, 0, bits, st));
+    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, B, plan->c_partner);
+    if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
+                            plan->c_uniq_slot, plan->counts + 2, st))
+        return rc;
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

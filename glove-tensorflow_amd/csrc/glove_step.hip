@@ -1,0 +1,737 @@
+// GloVe training step on gfx950: fused forward + gradient passes and the optimizer applies.
+//
+// What the kernels replace (reference = /root/reference, TF graph built by model_fn):
+//   rowpass   ResourceGather x4 + dot + Add (src/models/model_utils.py:41-54), weighted MSE head
+//             (src/models/estimator.py:48-56), activity-L2 losses (model_utils.py:18-21,52) and
+//             the row-side half of tf.gradients.
+//   colpass   the col-side half of tf.gradients.
+//   apply     OptimizerV2 dedup (Unique + UnsortedSegmentSum) + ResourceSparseApplyAdagradV2.
+//   dense_*   the same sums written to dense [V,d] buffers (DP all-reduce), ResourceApplyAdagradV2
+//             and Keras-legacy Adam (whole-table decay).
+//
+// Memory-bound gather/scatter: no MFMA.  A row of d floats is spread over LPR lanes as float4;
+// a wave64 therefore works on 64/LPR chunks at once.  All sums have a fixed order, so a step is
+// bitwise repeatable for a given plan.
+#include "glove_common.h"
+
+namespace glove {
+
+template <int LPR, int NV>
+__device__ inline void load_row(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
+{
+    const f4 *p = reinterpret_cast<const f4 *>(table) + (size_t)id * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        dst[k] = (i4 < d4) ? p[i4] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int LPR, int NV>
+__device__ inline void store_row(float *table, size_t row_index, int d4, int lg, const f4 (&src)[NV])
+{
+    f4 *p = reinterpret_cast<f4 *>(table) + row_index * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        if (i4 < d4) p[i4] = src[k];
+    }
+}
+
+// ---- optimizer arithmetic (Keras-legacy forms) -------------------------
+__device__ inline void adagrad_elem(float &Wv, float &A, float g, float lr, float eps)
+{
+    A += g * g;
+    Wv -= lr * g / (sqrtf(A) + eps);
+}
+
+__device__ inline f4 sqrt4(const f4 v) { return f4{sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w)}; }
+
+__device__ inline void adagrad_vec(f4 &Wv, f4 &A, const f4 g, float lr, float eps)
+{
+    A += g * g;
+    Wv -= (lr * g) / (sqrt4(A) + eps);
+}
+
+__device__ inline void adam_elem(float &Wv, float &M, float &Vv, float g, float lr_t, float b1, float b2, float eps)
+{
+    M = b1 * M + (1.0f - b1) * g;
+    Vv = b2 * Vv + (1.0f - b2) * g * g;
+    Wv -= lr_t * M / (sqrtf(Vv) + eps);
+}
+
+__device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, float b1, float b2, float eps)
+{
+    M = b1 * M + (1.0f - b1) * g;
+    Vv = b2 * Vv + (1.0f - b2) * g * g;
+    Wv -= (lr_t * M) / (sqrt4(Vv) + eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// rowpass: one group of LPR lanes per row-side chunk.
+// ------------------------------------------------------------------------------------------
+constexpr int kUnroll = 4;   // partner rows in flight per group
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void rowpass_kernel(
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
+    const float *__restrict__ w, const float *__restrict__ y,
+    const int32_t *__restrict__ chunk_id, const int32_t *__restrict__ chunk_start,
+    const float *__restrict__ R, const float *__restrict__ C,
+    const float *__restrict__ br, const float *__restrict__ bc,
+    const float *__restrict__ scalars, int64_t *__restrict__ step,
+    int d4, float inv_batch,
+    float *__restrict__ e_out, float *__restrict__ gp, float *__restrict__ gb,
+    float *__restrict__ blockpart)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int n_chunks = counts[0];
+    const float g = scalars[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
+
+    float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int j = blockIdx.x * GPB + grp; j < n_chunks; j += gridDim.x * GPB) {
+        const int32_t u = chunk_id[j];
+        const int s = chunk_start[j];
+        const int n = chunk_start[j + 1] - s;
+        f4 r[NV], acc[NV];
+        load_row<LPR, NV>(r, R, u, d4, lg);
+        const float bru = br[u];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+        float rr = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
+        float se = 0.f, cc_sum = 0.f;
+
+        for (int q0 = 0; q0 < n; q0 += kUnroll) {
+            int32_t col[kUnroll];
+            float wq[kUnroll], yq[kUnroll];
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) {
+                const bool ok = q0 + a < n;
+                const int k = ok ? s + q0 + a : s;       // tail slots replay pair 0 with weight 0
+                col[a] = partner[k];
+                wq[a] = ok ? w[k] : 0.f;
+                yq[a] = y[k];
+            }
+            f4 c[kUnroll][NV];
+            float bcv[kUnroll];
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) {
+                load_row<LPR, NV>(c[a], C, col[a], d4, lg);
+                bcv[a] = bc[col[a]];
+            }
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) {
+                const bool ok = q0 + a < n;
+                float dp = 0.f, cc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) { dp += dot4(r[k], c[a][k]); cc += dot4(c[a][k], c[a][k]); }
+                const float dot = group_sum<LPR>(dp);
+                const float diff = dot + bru + bcv[a] + g - yq[a];
+                const float e = 2.0f * wq[a] * diff * inv_batch;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
+                se += e;
+                if (ok) {
+                    cc_sum += cc;
+                    if (lg == 0) {
+                        e_out[s + q0 + a] = e;
+                        part[0] += wq[a] * diff * diff;
+                        part[2] += bcv[a] * bcv[a];
+                    }
+                }
+            }
+        }
+        store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
+        part[1] += cc_sum + (float)n * rr;
+        if (lg == 0) {
+            gb[j] = se;
+            part[2] += (float)n * bru * bru;
+            part[3] += se;
+        }
+    }
+    block_partials_store(part, blockpart);
+}
+
+// ------------------------------------------------------------------------------------------
+// colpass: per col-side chunk, sum_i e_i R[row_i] and sum_i e_i.
+// ------------------------------------------------------------------------------------------
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void colpass_kernel(
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
+    const int32_t *__restrict__ perm, const int32_t *__restrict__ chunk_start,
+    const float *__restrict__ R, const float *__restrict__ e_in, int d4,
+    float *__restrict__ gp, float *__restrict__ gb)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int n_chunks = counts[2];
+    for (int j = blockIdx.x * GPB + grp; j < n_chunks; j += gridDim.x * GPB) {
+        const int s = chunk_start[j];
+        const int n = chunk_start[j + 1] - s;
+        f4 acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+        float se = 0.f;
+        for (int q0 = 0; q0 < n; q0 += kUnroll) {
+            int32_t rid[kUnroll];
+            float eq[kUnroll];
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) {
+                const bool ok = q0 + a < n;
+                const int k = ok ? s + q0 + a : s;
+                rid[a] = partner[k];
+                const float ev = e_in[perm[k]];
+                eq[a] = ok ? ev : 0.f;
+            }
+            f4 r[kUnroll][NV];
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) load_row<LPR, NV>(r[a], R, rid[a], d4, lg);
+#pragma unroll
+            for (int a = 0; a < kUnroll; ++a) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) acc[k] += eq[a] * r[a][k];
+                se += eq[a];
+            }
+        }
+        store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
+        if (lg == 0) gb[j] = se;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Summed gradient of one distinct id: chunk partials in a fixed order + activity-L2 term.
+// Ids with at most kHeavyChunks chunks are summed by one group of LPR lanes; heavier ids
+// (Zipf head: "the", "<UNK>" own thousands of pairs of a large batch) are parked in an LDS
+// queue and then summed by the whole workgroup, GPB groups striding over the partial rows.
+// ------------------------------------------------------------------------------------------
+struct SideBufs {
+    const int32_t *chunk_id, *chunk_start, *uniq_slot;
+    const float *gp, *gb;
+    float *W, *S1, *bias, *S1b;
+};
+
+constexpr int kHeavyChunks = 8;
+constexpr int kHeavyCap = 128;
+
+struct StepConsts {
+    float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
+    float lr, eps;
+    float l2, m, inv_batch, inv_d;
+};
+
+template <int LPR, int NV>
+__device__ inline void sum_partials(const SideBufs &sb, int first, int last, int stride, int d4, int lg,
+                                    f4 (&G)[NV], float &Gb)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) G[k] = f4{0.f, 0.f, 0.f, 0.f};
+    Gb = 0.f;
+#pragma unroll 4
+    for (int sl = first; sl < last; sl += stride) {
+        f4 p[NV];
+        load_row<LPR, NV>(p, sb.gp, sl, d4, lg);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) G[k] += p[k];
+        Gb += sb.gb[sl];
+    }
+}
+
+// Calls f(is_row, id, G, Wv, Gb, bval) once per distinct id of both sides, on the LPR lanes of
+// one group (G/Wv hold that lane's float4 slices of the summed gradient and of the table row).
+template <int LPR, int NV, class F>
+__device__ inline void for_each_id(const int32_t *__restrict__ counts, const SideBufs &rs, const SideBufs &cs,
+                                   int d4, const StepConsts &k, F f)
+{
+    constexpr int GPB = kBlock / LPR;
+    __shared__ int heavy_q[kHeavyCap];
+    __shared__ int heavy_n;
+    __shared__ f4 red[GPB][LPR * NV];
+    __shared__ float redb[GPB];
+    const int lg = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int nu_r = counts[1], nu_c = counts[3];
+    const int total = nu_r + nu_c;
+    if (threadIdx.x == 0) heavy_n = 0;
+    __syncthreads();
+
+    auto finish = [&](const SideBufs &sb, bool is_row, int sl0, int sl1, f4 (&G)[NV], float Gb) {
+        const int32_t id = sb.chunk_id[sl0];
+        const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
+        f4 Wv[NV];
+        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
+        const float bval = sb.bias[id];
+        const float kc = k.kappa * cnt;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
+        Gb += k.kappa_b * cnt * bval;
+        f(is_row, id, G, Wv, Gb, bval);
+    };
+
+    for (int q = blockIdx.x * GPB + grp; q < total; q += gridDim.x * GPB) {
+        const bool is_row = q < nu_r;
+        const SideBufs &sb = is_row ? rs : cs;
+        const int qq = is_row ? q : q - nu_r;
+        const int sl0 = sb.uniq_slot[qq], sl1 = sb.uniq_slot[qq + 1];
+        if (sl1 - sl0 > kHeavyChunks) {
+            int slot = 0;
+            if (lg == 0) slot = atomicAdd(&heavy_n, 1);
+            slot = __shfl(slot, 0, LPR);
+            if (slot < kHeavyCap) {
+                if (lg == 0) heavy_q[slot] = q;
+                continue;
+            }
+        }
+        f4 G[NV]; float Gb;
+        sum_partials<LPR, NV>(sb, sl0, sl1, 1, d4, lg, G, Gb);
+        finish(sb, is_row, sl0, sl1, G, Gb);
+    }
+    __syncthreads();
+    const int nh = heavy_n < kHeavyCap ? heavy_n : kHeavyCap;
+    for (int hq = 0; hq < nh; ++hq) {
+        const int q = heavy_q[hq];
+        const bool is_row = q < nu_r;
+        const SideBufs &sb = is_row ? rs : cs;
+        const int qq = is_row ? q : q - nu_r;
+        const int sl0 = sb.uniq_slot[qq], sl1 = sb.uniq_slot[qq + 1];
+        f4 G[NV]; float Gb;
+        sum_partials<LPR, NV>(sb, sl0 + grp, sl1, GPB, d4, lg, G, Gb);
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) red[grp][lg + kk * LPR] = G[kk];
+        if (lg == 0) redb[grp] = Gb;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) G[kk] = red[0][lg + kk * LPR];
+            Gb = redb[0];
+            for (int g2 = 1; g2 < GPB; ++g2) {
+#pragma unroll
+                for (int kk = 0; kk < NV; ++kk) G[kk] += red[g2][lg + kk * LPR];
+                Gb += redb[g2];
+            }
+            finish(sb, is_row, sl0, sl1, G, Gb);
+        }
+        __syncthreads();
+    }
+}
+
+// Deterministic sum of the rowpass block partials (one wave, fixed order).
+__device__ inline void sum_blockpart(const float *blockpart, int nblocks, float (&tot)[kPartials])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < kPartials; ++i) tot[i] = 0.f;
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int i = 0; i < kPartials; ++i) tot[i] += blockpart[(size_t)b * kPartials + i];
+    }
+#pragma unroll
+    for (int i = 0; i < kPartials; ++i) tot[i] = wave_sum(tot[i]);
+}
+
+__device__ inline void loss_from_partials(const float (&tot)[kPartials], const StepConsts &k, float g,
+                                          float &loss, float &L, float &reg)
+{
+    // tot = {sum w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, sum e}
+    L = tot[0] * k.inv_batch;
+    reg = k.l2 * k.inv_d * k.inv_batch * tot[1] + k.l2 * k.inv_batch * tot[2] + k.l2 * g * g;
+    loss = L + k.m * reg;
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
+    const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    float *__restrict__ scalars, const float *__restrict__ blockpart, int nblocks_rowpass,
+    float *__restrict__ loss_out)
+{
+    const int lg = threadIdx.x % LPR;
+    for_each_id<LPR, NV>(counts, rs, cs, d4, k,
+        [&](bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval) {
+            const SideBufs &sb = is_row ? rs : cs;
+            f4 A[NV];
+            load_row<LPR, NV>(A, sb.S1, id, d4, lg);
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) {
+                adagrad_vec(Wv[kk], A[kk], G[kk], k.lr, k.eps);
+            }
+            store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
+            store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
+            if (lg == 0) {
+                const float Ab = sb.S1b[id] + Gb * Gb;
+                sb.S1b[id] = Ab;
+                sb.bias[id] = bval - k.lr * Gb / (sqrtf(Ab) + k.eps);
+            }
+        });
+    // global bias (dense Adagrad) + loss scalars: first wave of block 0
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float tot[kPartials];
+        sum_blockpart(blockpart, nblocks_rowpass, tot);
+        if (threadIdx.x == 0) {
+            const float g = scalars[0];
+            float loss, L, reg;
+            loss_from_partials(tot, k, g, loss, L, reg);
+            const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
+            const float Ag = scalars[1] + dg * dg;
+            scalars[1] = Ag;
+            scalars[0] = g - k.lr * dg / (sqrtf(Ag) + k.eps);
+            if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
+        }
+    }
+}
+
+// Adds this plan's summed gradients into the dense buffers (no two work items share an id
+// within one side, so plain read-modify-write is race free).
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void dense_grad_kernel(
+    const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    float *__restrict__ G_R, float *__restrict__ G_C, float *__restrict__ G_br, float *__restrict__ G_bc,
+    float *__restrict__ tail, const float *__restrict__ blockpart, int nblocks_rowpass)
+{
+    const int lg = threadIdx.x % LPR;
+    for_each_id<LPR, NV>(counts, rs, cs, d4, k,
+        [&](bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval) {
+            (void)Wv; (void)bval;
+            float *Gd = is_row ? G_R : G_C;
+            f4 old[NV];
+            load_row<LPR, NV>(old, Gd, id, d4, lg);
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) old[kk] += G[kk];
+            store_row<LPR, NV>(Gd, (size_t)id, d4, lg, old);
+            if (lg == 0) {
+                float *Gbd = is_row ? G_br : G_bc;
+                Gbd[id] += Gb;
+            }
+        });
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float tot[kPartials];
+        sum_blockpart(blockpart, nblocks_rowpass, tot);
+        if (threadIdx.x == 0) {
+            tail[0] += tot[3];   // sum e
+            tail[1] += tot[0];   // sum w diff^2
+            tail[2] += tot[1];   // sum |r|^2 + |c|^2
+            tail[3] += tot[2];   // sum br^2 + bc^2
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense sweeps over [R | C | br | bc] consuming (and zeroing) G_flat.
+// ------------------------------------------------------------------------------------------
+struct DenseSeg { float *W, *S1, *S2, *G; int64_t n; };
+struct DenseSegs { DenseSeg s[4]; };
+
+__global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
+    DenseSegs segs, StepConsts k, float *__restrict__ scalars, float *__restrict__ tail,
+    float *__restrict__ loss_out)
+{
+    const DenseSeg sg = segs.s[blockIdx.y];
+    const int64_t n4 = sg.n / 4;
+    f4 *W4 = reinterpret_cast<f4 *>(sg.W), *A4 = reinterpret_cast<f4 *>(sg.S1), *G4 = reinterpret_cast<f4 *>(sg.G);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const f4 gv = G4[i];
+        if (gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f) continue;  // untouched: exact no-op
+        f4 a = A4[i], wv = W4[i];
+        adagrad_vec(wv, a, gv, k.lr, k.eps);
+        A4[i] = a; W4[i] = wv; G4[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < sg.n; i += kBlock) {
+            const float gv = sg.G[i];
+            if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const float g = scalars[0];
+        const float tot[kPartials] = {tail[1], tail[2], tail[3], tail[0]};
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = tail[0] + 2.0f * k.m * k.l2 * g;
+        adagrad_elem(scalars[0], scalars[1], dg, k.lr, k.eps);
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tail[0]; }
+        tail[0] = tail[1] = tail[2] = tail[3] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void dense_adam_kernel(
+    DenseSegs segs, StepConsts k, double beta1, double beta2, const int64_t *__restrict__ step,
+    float *__restrict__ scalars, float *__restrict__ tail, float *__restrict__ loss_out)
+{
+    const DenseSeg sg = segs.s[blockIdx.y];
+    // t = global_step after rowpass advanced it; lr_t = lr sqrt(1-b2^t)/(1-b1^t)  (Keras legacy Adam)
+    const double t = (double)(*step);
+    const float lr_t = (float)((double)k.lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
+    const float b1 = (float)beta1, b2 = (float)beta2;
+    const int64_t n4 = sg.n / 4;
+    f4 *W4 = reinterpret_cast<f4 *>(sg.W), *M4 = reinterpret_cast<f4 *>(sg.S1), *V4 = reinterpret_cast<f4 *>(sg.S2),
+       *G4 = reinterpret_cast<f4 *>(sg.G);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        const f4 gv = G4[i];
+        f4 m = M4[i], v = V4[i], wv = W4[i];
+        adam_vec(wv, m, v, gv, lr_t, b1, b2, k.eps);
+        M4[i] = m; V4[i] = v; W4[i] = wv;
+        if (gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f) G4[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < sg.n; i += kBlock) {
+            adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
+            sg.G[i] = 0.f;
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const float g = scalars[0];
+        const float tot[kPartials] = {tail[1], tail[2], tail[3], tail[0]};
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = tail[0] + 2.0f * k.m * k.l2 * g;
+        adam_elem(scalars[0], scalars[1], scalars[2], dg, lr_t, b1, b2, k.eps);
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tail[0]; }
+        tail[0] = tail[1] = tail[2] = tail[3] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int check_common(const glove_plan *p, const glove_tables *t, const glove_hyper *h, const void *ws)
+{
+    if (!p || !t || !h || !ws) return GLOVE_E_BADARG;
+    if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
+    if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
+                     !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+        return GLOVE_E_BADARG;
+    if (pick_row_shape(t->d / 4).lpr == 0) return GLOVE_E_BADARG;
+    return 0;
+}
+
+static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
+{
+    StepConsts k;
+    k.kappa = 2.0f * h->reg_mult * h->l2_reg / (float)t->d * h->inv_batch;
+    k.kappa_b = 2.0f * h->reg_mult * h->l2_reg * h->inv_batch;
+    k.lr = h->learning_rate;
+    k.eps = h->epsilon;
+    k.l2 = h->l2_reg;
+    k.m = h->reg_mult;
+    k.inv_batch = h->inv_batch;
+    k.inv_d = 1.0f / (float)t->d;
+    return k;
+}
+
+static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_for(p->cap_chunks, kBlock / lpr); }
+
+static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tables *t, bool row)
+{
+    SideBufs s;
+    s.chunk_id = row ? p->r_chunk_id : p->c_chunk_id;
+    s.chunk_start = row ? p->r_chunk_start : p->c_chunk_start;
+    s.uniq_slot = row ? p->r_uniq_slot : p->c_uniq_slot;
+    s.gp = row ? w.gp_r : w.gp_c;
+    s.gb = row ? w.gb_r : w.gb_c;
+    s.W = row ? t->R : t->C;
+    s.S1 = row ? t->s1_R : t->s1_C;
+    s.bias = row ? t->br : t->bc;
+    s.S1b = row ? t->s1_br : t->s1_bc;
+    return s;
+}
+
+}  // namespace glove
+
+using namespace glove;
+
+extern "C" {
+
+int glove_abi_version(void) { return GLOVE_ABI_VERSION; }
+
+size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d)
+{
+    if (B < 0 || cap_chunks < 0 || d <= 0) return 0;
+    return carve_step_ws(nullptr, B, cap_chunks, d).bytes;
+}
+
+size_t glove_dense_grad_floats(int32_t V, int32_t d) { return (size_t)2 * V * d + (size_t)2 * V + 8; }
+
+int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                      void *stream)
+{
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = rowpass_blocks(p, shape.lpr);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                           \
+    hipLaunchKernelGGL((rowpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->r_partner,      \
+                       p->r_w, p->r_y, p->r_chunk_id, p->r_chunk_start, t->R, t->C, t->br, t->bc, t->scalars, \
+                       t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                      void *stream)
+{
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = blocks_for(p->cap_chunks, kBlock / shape.lpr);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                      \
+    hipLaunchKernelGGL((colpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->c_partner, \
+                       p->c_perm, p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
+                            size_t ws_bytes, float *loss_out, void *stream)
+{
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const int nb_row = rowpass_blocks(p, shape.lpr);
+    const StepConsts k = make_consts(t, h);
+    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                          \
+    hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, d4, \
+                       k, t->scalars, w.blockpart, nb_row, loss_out)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                         float *G_flat, void *stream)
+{
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    if (!G_flat) return GLOVE_E_BADARG;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const int nb_row = rowpass_blocks(p, shape.lpr);
+    const StepConsts k = make_consts(t, h);
+    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    const size_t Vd = (size_t)t->V * t->d;
+    float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V, *tail = G_bc + t->V;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                       \
+    hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, d4, \
+                       k, G_R, G_C, G_br, G_bc, tail, w.blockpart, nb_row)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_flat, bool adam, DenseSegs &segs,
+                        float *&tail, int &nbx)
+{
+    if (!t || !h || !G_flat || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
+    if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    if (adam && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;
+    const int64_t Vd = (int64_t)t->V * t->d;
+    float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V;
+    tail = G_bc + t->V;
+    segs.s[0] = {t->R, t->s1_R, t->s2_R, G_R, Vd};
+    segs.s[1] = {t->C, t->s1_C, t->s2_C, G_C, Vd};
+    // bias segments: the float4 body needs 16-B aligned G pointers; V may be odd, so sweep them scalar
+    segs.s[2] = {t->br, t->s1_br, t->s2_br, G_br, (int64_t)t->V};
+    segs.s[3] = {t->bc, t->s1_bc, t->s2_bc, G_bc, (int64_t)t->V};
+    nbx = blocks_for(Vd / 4, kBlock);
+    return 0;
+}
+
+}  // extern "C"
+
+namespace glove {
+// Bias segments of G_flat start at float offsets 2Vd and 2Vd+V, which are only 16-B aligned when
+// V % 4 == 0; they are tiny ([V]), so they get their own scalar kernels.
+__global__ __launch_bounds__(kBlock) void dense_adagrad_bias_kernel(DenseSeg a, DenseSeg b, StepConsts k)
+{
+    const DenseSeg sg = blockIdx.y == 0 ? a : b;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
+        const float gv = sg.G[i];
+        if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void dense_adam_bias_kernel(DenseSeg a, DenseSeg b, StepConsts k, double beta1,
+                                                                 double beta2, const int64_t *__restrict__ step)
+{
+    const DenseSeg sg = blockIdx.y == 0 ? a : b;
+    const double t = (double)(*step);
+    const float lr_t = (float)((double)k.lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
+    const float b1 = (float)beta1, b2 = (float)beta2;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
+        adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
+        sg.G[i] = 0.f;
+    }
+}
+}  // namespace glove
+
+extern "C" {
+
+int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
+{
+    DenseSegs segs; float *tail; int nbx;
+    if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx)) return rc;
+    const StepConsts k = make_consts(t, h);
+    hipStream_t st = (hipStream_t)stream;
+    // biases first: the embedding kernel's block (0,0) consumes and clears the tail last
+    hipLaunchKernelGGL(dense_adagrad_bias_kernel, dim3(blocks_for(t->V, kBlock), 2), dim3(kBlock), 0, st, segs.s[2],
+                       segs.s[3], k);
+    DenseSegs two = segs; two.s[2] = two.s[0]; two.s[3] = two.s[1];
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3(nbx, 2), dim3(kBlock), 0, st, two, k, t->scalars, tail, loss_out);
+    return (int)hipGetLastError();
+}
+
+int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
+{
+    DenseSegs segs; float *tail; int nbx;
+    if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx)) return rc;
+    const StepConsts k = make_consts(t, h);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dense_adam_bias_kernel, dim3(blocks_for(t->V, kBlock), 2), dim3(kBlock), 0, st, segs.s[2],
+                       segs.s[3], k, h->beta1, h->beta2, t->step);
+    DenseSegs two = segs; two.s[2] = two.s[0]; two.s[3] = two.s[1];
+    hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 2), dim3(kBlock), 0, st, two, k, h->beta1, h->beta2, t->step,
+                       t->scalars, tail, loss_out);
+    return (int)hipGetLastError();
+}
+
+int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                           float *loss_out, void *stream)
+{
+    if (int rc = glove_rowpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = glove_colpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
+}
+
+int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                        float *G_flat, float *loss_out, void *stream)
+{
+    if (int rc = glove_rowpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = glove_colpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = glove_dense_grad_f32(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
+    return glove_dense_adam_f32(t, h, G_flat, loss_out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+"""ctypes binding of libglove_hip.so (C ABI: include/glove_hip.h).
+
+This is the only way the host loop reaches the GPU kernels.  There is no CPU fallback: if the
+shared library is missing or a call fails, an exception is raised.  torch is used here only
+as the owner of device memory and streams (`tensor.data_ptr()`, `current_stream().cuda_stream`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+PKG_DIR = Path(__file__).resolve().parent.parent
+LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
+
+GLOVE_ABI_VERSION = 1
+DEFAULT_CHUNK_CAP = 32
+
+# every symbol include/glove_hip.h declares
+EXPORTED_SYMBOLS = (
+    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_step_workspace_bytes",
+    "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
+    "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
+    "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
+)
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class GloveTables(C.Structure):
+    _fields_ = [("V", C.c_int32), ("d", C.c_int32),
+                ("R", _fp), ("C", _fp), ("br", _fp), ("bc", _fp),
+                ("s1_R", _fp), ("s1_C", _fp), ("s1_br", _fp), ("s1_bc", _fp),
+                ("s2_R", _fp), ("s2_C", _fp), ("s2_br", _fp), ("s2_bc", _fp),
+                ("scalars", _fp), ("step", _fp)]
+
+
+class GloveHyper(C.Structure):
+    _fields_ = [("beta1", C.c_double), ("beta2", C.c_double),
+                ("l2_reg", C.c_float), ("reg_mult", C.c_float), ("learning_rate", C.c_float),
+                ("epsilon", C.c_float), ("inv_batch", C.c_float), ("reserved", C.c_float)]
+
+
+class GlovePlan(C.Structure):
+    _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
+                ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp),
+                ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp),
+                ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp),
+                ("c_partner", _fp), ("c_perm", _fp),
+                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp)]
+
+
+class GloveHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen libglove_hip.so and declare the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise GloveHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    lib = C.CDLL(str(p))
+    P = C.POINTER
+    sz, i32, i64, vp = C.c_size_t, C.c_int32, C.c_int64, C.c_void_p
+    protos = {
+        "glove_abi_version": (C.c_int, []),
+        "glove_plan_workspace_bytes": (sz, [i64, i32]),
+        "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
+        "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
+        "glove_rowpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
+        "glove_colpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
+        "glove_apply_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
+        "glove_dense_grad_floats": (sz, [i32, i32]),
+        "glove_dense_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
+        "glove_dense_adagrad_f32": (C.c_int, [P(GloveTables), P(GloveHyper), vp, vp, vp]),
+        "glove_dense_adam_f32": (C.c_int, [P(GloveTables), P(GloveHyper), vp, vp, vp]),
+        "glove_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
+        "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
+        "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
+        "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
+        "glove_topk_cosine_f32": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.glove_abi_version() != GLOVE_ABI_VERSION:
+        raise GloveHipError("ABI mismatch: library %d, binding %d" % (lib.glove_abi_version(), GLOVE_ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        names = {-1: "GLOVE_E_BADARG", -2: "GLOVE_E_WORKSPACE"}
+        raise GloveHipError("%s failed: %s" % (what, names.get(rc, "hipError %d" % rc)))
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GloveHipError("device tensor expected (the HIP path has no CPU fallback)")
+
+
+class DeviceTables:
+    """The five variables + optimizer slots as device buffers (reference model_utils.py:31-39)."""
+
+    NAMES = ("R", "C", "br", "bc")
+
+    def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None):
+        if d % 4 != 0:
+            raise ValueError("embedding size must be a multiple of 4 (16-byte rows), got %d" % d)
+        if optimizer not in ("Adagrad", "Adam"):
+            raise ValueError("optimizer must be 'Adagrad' or 'Adam' (Keras names), got %r" % (optimizer,))
+        self.V, self.d, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(seed)
+        else:
+            gen.seed()   # the reference is unseeded (train_utils.py:26-27)
+
+        def uni(*shape):  # Keras Embedding default: U(-0.05, 0.05)
+            return ((torch.rand(*shape, generator=gen, dtype=torch.float32) - 0.5) * 0.1).to(self.device)
+
+        self.R, self.C = uni(V, d), uni(V, d)
+        self.br, self.bc = uni(V), uni(V)
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.s1, self.s2 = {}, {}
+        for n in self.NAMES:
+            w = getattr(self, n)
+            if optimizer == "Adagrad":
+                self.s1[n] = torch.full_like(w, 0.1)   # initial_accumulator_value
+            else:
+                self.s1[n] = torch.zeros_like(w)
+                self.s2[n] = torch.zeros_like(w)
+        if optimizer == "Adagrad":
+            self.scalars[1] = 0.1
+        self._struct = None
+
+    def struct(self) -> GloveTables:
+        if self._struct is None:
+            s = GloveTables()
+            s.V, s.d = self.V, self.d
+            for n in self.NAMES:
+                setattr(s, n, _ptr(getattr(self, n)))
+                setattr(s, "s1_" + n, _ptr(self.s1[n]))
+                setattr(s, "s2_" + n, _ptr(self.s2.get(n)))
+            s.scalars, s.step = _ptr(self.scalars), _ptr(self.step)
+            self._struct = s
+        return self._struct
+
+    # ---- (de)serialisation used by the checkpoint code and the tests
+    def state_dict(self) -> dict:
+        out = {"V": self.V, "d": self.d, "optimizer": self.optimizer,
+               "scalars": self.scalars.cpu(), "global_step": self.step.cpu()}
+        for n in self.NAMES:
+            out[n] = getattr(self, n).cpu()
+            out["slot1_" + n] = self.s1[n].cpu()
+            if n in self.s2:
+                out["slot2_" + n] = self.s2[n].cpu()
+        return out
+
+    def load_state_dict(self, sd: dict):
+        if (sd["V"], sd["d"], sd["optimizer"]) != (self.V, self.d, self.optimizer):
+            raise ValueError("checkpoint is for V=%s d=%s %s, model is V=%d d=%d %s" % (
+                sd["V"], sd["d"], sd["optimizer"], self.V, self.d, self.optimizer))
+        self.scalars.copy_(sd["scalars"])
+        self.step.copy_(sd["global_step"])
+        for n in self.NAMES:
+            getattr(self, n).copy_(sd[n])
+            self.s1[n].copy_(sd["slot1_" + n])
+            if n in self.s2:
+                self.s2[n].copy_(sd["slot2_" + n])
+
+    @property
+    def global_bias(self) -> float:
+        return float(self.scalars[0].item())
+
+    @property
+    def global_step(self) -> int:
+        return int(self.step.item())
+
+
+class Plan:
+    """Device-resident dedup index of one batch (see glove_plan in include/glove_hip.h)."""
+
+    INT_FIELDS = ("r_partner", "r_chunk_id", "r_chunk_start", "r_uniq_slot",
+                  "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot")
+
+    def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
+                 cap_uniq: int | None = None):
+        self.B, self.V, self.chunk_cap = int(B), int(V), int(chunk_cap)
+        self.cap_chunks = int(B if cap_chunks is None else cap_chunks)
+        self.cap_uniq = int(min(B, V) if cap_uniq is None else cap_uniq)
+        dev = torch.device(device)
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        n = max(self.B, 1)
+        self.counts = torch.zeros(4, **i32)
+        self.r_partner, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(3))
+        self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
+        self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
+        self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
+        self.r_uniq_slot, self.c_uniq_slot = (torch.zeros(self.cap_uniq + 1, **i32) for _ in range(2))
+        self._struct = None
+
+    def struct(self) -> GlovePlan:
+        if self._struct is None:
+            s = GlovePlan()
+            s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
+            s.counts = _ptr(self.counts)
+            s.r_w, s.r_y = _ptr(self.r_w), _ptr(self.r_y)
+            for n in self.INT_FIELDS:
+                setattr(s, n, _ptr(getattr(self, n)))
+            self._struct = s
+        return self._struct
+
+    def compact(self) -> "Plan":
+        """Exact-size copy (one host sync): used when plans of a static stream stay resident."""
+        nc_r, nu_r, nc_c, nu_c = (int(x) for x in self.counts.tolist())
+        out = Plan.__new__(Plan)
+        out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
+        out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
+        out.counts = self.counts.clone()
+        out.r_partner, out.r_w, out.r_y = self.r_partner, self.r_w, self.r_y
+        out.c_partner, out.c_perm = self.c_partner, self.c_perm
+        out.r_chunk_id = self.r_chunk_id[:max(out.cap_chunks, 1)].clone()
+        out.c_chunk_id = self.c_chunk_id[:max(out.cap_chunks, 1)].clone()
+        out.r_chunk_start = self.r_chunk_start[:out.cap_chunks + 1].clone()
+        out.c_chunk_start = self.c_chunk_start[:out.cap_chunks + 1].clone()
+        out.r_uniq_slot = self.r_uniq_slot[:out.cap_uniq + 1].clone()
+        out.c_uniq_slot = self.c_uniq_slot[:out.cap_uniq + 1].clone()
+        out._struct = None
+        return out
+
+    def nbytes(self) -> int:
+        return sum(getattr(self, n).numel() * 4 for n in self.INT_FIELDS + ("r_w", "r_y", "counts"))
+
+
+def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
+               batch_size=None, inv_batch=None) -> GloveHyper:
+    h = GloveHyper()
+    h.beta1, h.beta2 = beta1, beta2
+    h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
+    h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
+    return h
+
+
+class GloveHip:
+    """Thin object wrapper over the C ABI; one instance per process/GPU."""
+
+    def __init__(self, device="cuda:0", lib_path=None):
+        self.lib = load_library(lib_path)
+        self.device = torch.device(device)
+        self._plan_ws = None
+        self._step_ws = None
+
+    # ---- workspaces (grown on demand, never inside a captured region)
+    def _ws(self, attr: str, nbytes: int) -> torch.Tensor:
+        cur = getattr(self, attr)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            setattr(self, attr, cur)
+        return cur
+
+    def step_workspace(self, plan: Plan, d: int) -> torch.Tensor:
+        return self._ws("_step_ws", self.lib.glove_step_workspace_bytes(plan.B, plan.cap_chunks, d))
+
+    # ---- index build
+    def build_plan(self, row, col, w, y, V: int, chunk_cap: int = DEFAULT_CHUNK_CAP, compact=False) -> Plan:
+        _require_cuda(row, col, w, y)
+        B = int(row.numel())
+        plan = Plan(B, V, chunk_cap, row.device)
+        ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
+        _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
+                                         _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
+        return plan.compact() if compact else plan
+
+    # ---- passes
+    def rowpass(self, plan, tables, hyper, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_rowpass_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                          _ptr(ws), ws.numel(), _stream()), "glove_rowpass_f32")
+
+    def colpass(self, plan, tables, hyper, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_colpass_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                          _ptr(ws), ws.numel(), _stream()), "glove_colpass_f32")
+
+    def apply_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_apply_adagrad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                                _ptr(ws), ws.numel(), _ptr(loss_out), _stream()),
+               "glove_apply_adagrad_f32")
+
+    def dense_grad(self, plan, tables, hyper, G_flat, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_dense_grad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                             _ptr(ws), ws.numel(), _ptr(G_flat), _stream()), "glove_dense_grad_f32")
+
+    def dense_adagrad(self, tables, hyper, G_flat, loss_out=None):
+        _check(self.lib.glove_dense_adagrad_f32(C.byref(tables.struct()), C.byref(hyper), _ptr(G_flat),
+                                                _ptr(loss_out), _stream()), "glove_dense_adagrad_f32")
+
+    def dense_adam(self, tables, hyper, G_flat, loss_out=None):
+        _check(self.lib.glove_dense_adam_f32(C.byref(tables.struct()), C.byref(hyper), _ptr(G_flat),
+                                             _ptr(loss_out), _stream()), "glove_dense_adam_f32")
+
+    def dense_grad_buffer(self, tables) -> torch.Tensor:
+        return torch.zeros(self.lib.glove_dense_grad_floats(tables.V, tables.d), dtype=torch.float32,
+                           device=tables.device)
+
+    # ---- whole steps
+    def step_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_step_adagrad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                               _ptr(ws), ws.numel(), _ptr(loss_out), _stream()),
+               "glove_step_adagrad_f32")
+
+    def step_adam(self, plan, tables, hyper, G_flat, loss_out=None, ws=None):
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_step_adam_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                            _ptr(ws), ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
+               "glove_step_adam_f32")
+
+    # ---- eval / predict
+    def eval_sums(self, row, col, w, y, tables, sums=None) -> torch.Tensor:
+        _require_cuda(row, col, w, y)
+        if sums is None:
+            sums = torch.zeros(4, dtype=torch.float64, device=tables.device)
+        _check(self.lib.glove_eval_f32(_ptr(row), _ptr(col), _ptr(w), _ptr(y), int(row.numel()),
+                                       C.byref(tables.struct()), _ptr(sums), _stream()), "glove_eval_f32")
+        return sums
+
+    def topk_cosine(self, R: torch.Tensor, query_ids: torch.Tensor, k: int):
+        _require_cuda(R, query_ids)
+        V, d = R.shape
+        n = int(query_ids.numel())
+        sims = torch.empty(n, k, dtype=torch.float32, device=R.device)
+        idx = torch.empty(n, k, dtype=torch.int32, device=R.device)
+        ws = torch.empty(self.lib.glove_topk_workspace_bytes(n, V, k), dtype=torch.uint8, device=R.device)
+        _check(self.lib.glove_topk_cosine_f32(_ptr(R), V, d, _ptr(query_ids), n, k, _ptr(sims), _ptr(idx),
+                                              _ptr(ws), ws.numel(), _stream()), "glove_topk_cosine_f32")
+        return sims, idx

@@ -1,0 +1,159 @@
+/*
+ * glove_hip.h — C ABI of the MI355X (gfx950) GloVe training hot path.
+ *
+ * The reference (yxtay/glove-tensorflow) has no native code and no FFI: its hot path is the
+ * TensorFlow graph that `model_fn` builds (reference src/models/estimator.py:13-56) and that
+ * `session.run(train_op)` executes once per step.  This library replaces exactly that graph.
+ * Each entry point cites the reference construct it stands in for; the binding a maintainer
+ * of the reference would add (a ctypes stub called from `model_fn`'s place) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, otherwise the hipError_t value (never throws, never aborts);
+ *     GLOVE_E_* codes (< 0) report argument errors detected on the host before any launch;
+ *   - every pointer inside the structs is a DEVICE pointer owned by the caller; the library
+ *     allocates nothing, keeps no global state and is re-entrant for distinct streams;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*) and returns;
+ *   - fp32 arithmetic, int32 ids (0 <= id < V), embedding size d % 4 == 0, rows 16-B aligned.
+ */
+#ifndef GLOVE_HIP_H
+#define GLOVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLOVE_ABI_VERSION 1
+
+#define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
+#define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
+
+/* Optimizer slots are generic: Adagrad uses slot1 = accumulator; Adam uses slot1 = m,
+ * slot2 = v (reference src/models/train_utils.py:13-16 picks the Keras optimizer by name). */
+typedef struct glove_tables {
+    int32_t V;                  /* vocab size = lines of vocab.txt (reference estimator.py:31) */
+    int32_t d;                  /* embedding size (--embedding-size) */
+    float *R, *C;               /* row_embedding / col_embedding [V,d] (model_utils.py:31-34) */
+    float *br, *bc;             /* row_bias / col_bias [V]         (model_utils.py:32-36) */
+    float *s1_R, *s1_C, *s1_br, *s1_bc;   /* slot 1, same shapes */
+    float *s2_R, *s2_C, *s2_br, *s2_bc;   /* slot 2 (Adam only; may be NULL for Adagrad) */
+    /* scalars live on the device so that a captured hipGraph replays without host patching:
+     *  [0] global_bias g (model_utils.py:39)  [1] slot1(g)  [2] slot2(g)  [3..7] reserved */
+    float *scalars;             /* float[8] */
+    /* global_step (estimator.py:45), int64[1].  glove_rowpass_f32 advances it by one (it is
+     * the first kernel of a step and does not read it); the apply kernels read t = *step. */
+    int64_t *step;
+} glove_tables;
+
+typedef struct glove_hyper {
+    double beta1, beta2;        /* Adam 0.9 / 0.999 (double: the bias correction 1-beta2^t
+                                 * loses 1e-5 relative accuracy if beta2 is rounded to fp32) */
+    float l2_reg;               /* --l2-reg  (activity L2, model_utils.py:8,38) */
+    float reg_mult;             /* m: times the regulariser list is counted (estimator.py:55) */
+    float learning_rate;        /* --learning-rate */
+    float epsilon;              /* Keras-legacy 1e-7 */
+    float inv_batch;            /* 1 / (global batch size): RegressionHead SUM_OVER_BATCH_SIZE */
+    float reserved;
+} glove_hyper;
+
+/*
+ * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,
+ * the `Unique` + `UnsortedSegmentSum` pair that Keras' OptimizerV2 runs on every sparse
+ * gradient: pairs are stably sorted by row id (row side) and the sorted
+ * pairs again by col id (col side); runs of equal ids are cut into chunks of at most
+ * `chunk_cap` pairs; `*_uniq_slot[q]` is the first chunk of the q-th distinct id.
+ * Built on the device by glove_plan_build; the arrays are plain device buffers so a caller
+ * may keep one plan per batch of a static nonzero stream resident in HBM.
+ */
+typedef struct glove_plan {
+    int64_t B;                  /* pairs in the batch */
+    int32_t chunk_cap;          /* max pairs per chunk */
+    int32_t cap_chunks;         /* capacity of the *_chunk_* arrays (>= chunks, <= B) */
+    int32_t cap_uniq;           /* capacity of the *_uniq_slot arrays minus one */
+    int32_t reserved;
+    int32_t *counts;            /* int32[4]: chunks_row, uniq_row, chunks_col, uniq_col */
+    /* row side: position k = k-th pair in (row id, original order) order */
+    int32_t *r_partner;         /* [B] col id of pair k */
+    float   *r_w;               /* [B] glove_weight */
+    float   *r_y;               /* [B] glove_value  */
+    int32_t *r_chunk_id;        /* [cap_chunks]   row id of the chunk */
+    int32_t *r_chunk_start;     /* [cap_chunks+1] first pair of the chunk; [chunks] = B */
+    int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
+    /* col side: position k = k-th row-sorted pair in (col id, row-sorted position) order */
+    int32_t *c_partner;         /* [B] row id */
+    int32_t *c_perm;            /* [B] row-sorted position of the pair (where its e lives) */
+    int32_t *c_chunk_id;
+    int32_t *c_chunk_start;
+    int32_t *c_uniq_slot;
+} glove_plan;
+
+int glove_abi_version(void);
+
+/* ---- index build: replaces tf.unique / UnsortedSegmentSum bookkeeping (a9) ------------- */
+size_t glove_plan_workspace_bytes(int64_t B, int32_t V);
+/* row/col/w/y: the batch as the input_fn delivers it (reference data_utils.py:4-26 after the
+ * vocab lookup of estimator.py:26-28), in arbitrary order. Fills every array of `plan`. */
+int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y,
+                     int64_t B, int32_t V, const glove_plan *plan,
+                     void *ws, size_t ws_bytes, void *stream);
+
+/* ---- step workspace ---------------------------------------------------------------------
+ * Holds e[B], per-chunk partial gradient rows and per-block loss partials. */
+size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d);
+
+/* ---- fused forward + gradient passes (model_utils.py:41-54, estimator.py:48-56, autodiff) --
+ * rowpass: per pair p = r.c + br + bc + g, e = 2 w (p - y) inv_batch, loss partials, and the
+ *          row-side per-chunk sums  sum_i e_i C[col_i]  /  sum_i e_i.
+ * colpass: col-side per-chunk sums  sum_i e_i R[row_i]  /  sum_i e_i.
+ * Neither modifies the tables. */
+int glove_rowpass_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                      void *ws, size_t ws_bytes, void *stream);
+int glove_colpass_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* ---- sparse optimizer apply: OptimizerV2 dedup + ResourceSparseApplyAdagradV2 (a9, a10) ----
+ * For every distinct id: G = sum of its chunk partials + activity-L2 term, then
+ * A += G^2 ; W -= lr G / (sqrt(A)+eps) on the touched rows of R, C, br, bc; dense update of the
+ * global bias; step += 1.  loss_out (device float[4]) = {loss, L, Reg, sum_e}. */
+int glove_apply_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                            void *ws, size_t ws_bytes, float *loss_out, void *stream);
+
+/* ---- dense-gradient path (data-parallel all-reduce, and Keras-legacy Adam a11) -------------
+ * G_flat layout: [G_R V*d | G_C V*d | G_br V | G_bc V | tail 8] floats, tail = {sum_e, sum
+ * w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, 0...}.  glove_dense_grad_f32 ADDS this batch's
+ * summed gradients (incl. the activity-L2 terms) into G_flat, which the caller keeps all-zero
+ * between steps (the dense apply kernels zero what they consume). */
+size_t glove_dense_grad_floats(int32_t V, int32_t d);
+int glove_dense_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                         void *ws, size_t ws_bytes, float *G_flat, void *stream);
+int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,
+                            float *loss_out, void *stream);
+int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,
+                         float *loss_out, void *stream);
+
+/* ---- whole step = session.run(train_op) (estimator.py:49-56) ------------------------------ */
+int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                           void *ws, size_t ws_bytes, float *loss_out, void *stream);
+int glove_step_adam_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                        void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
+
+/* ---- EVAL mode of model_fn: RegressionHead metrics over a batch (estimator.py:48-56) -------
+ * Accumulates into sums_out (device double[4]): sum w (p-y)^2, sum w, sum w p, sum w y. */
+int glove_eval_f32(const int32_t *row, const int32_t *col, const float *w, const float *y,
+                   int64_t B, const glove_tables *t, double *sums_out, void *stream);
+
+/* ---- PREDICT mode: cosine_similarity + tf.math.top_k (model_utils.py:81-110, utils.py:12-19) --
+ * For n query ids: sims/idx [n,k] sorted descending over all V ROW embeddings.
+ * ws: glove_topk_workspace_bytes. */
+size_t glove_topk_workspace_bytes(int32_t n, int32_t V, int32_t k);
+int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *query_ids, int32_t n,
+                          int32_t k, float *sims_out, int32_t *idx_out,
+                          void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOVE_HIP_H */

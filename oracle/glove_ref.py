@@ -1,0 +1,314 @@
+"""TEST INFRASTRUCTURE ONLY — CPU oracle for the GloVe training step.
+
+This module is the checker for the HIP path.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import it; nothing under `glove-tensorflow_amd/`
+or `trainer/` does, and the product path fails loudly when the HIP library is missing.
+
+PARITY UNPINNED (training step).  The reference's hot path runs inside TensorFlow 2.11 /
+Keras 2.11 / tensorflow-estimator 2.11 (reference `requirements.txt:15,38,40`), which is
+not present under /root/reference, is not installed here and cannot be fetched; the
+reference ships no tests or golden vectors for the step.  This file is
+therefore a restatement of the published algorithm written from the reference's call sites:
+
+  * parameters / init / activity regularisers .... src/models/model_utils.py:7-15,31-39
+  * forward  p = r.c + br + bc + g ................ src/models/model_utils.py:41-54
+  * mean activity loss (divide by batch) .......... src/models/model_utils.py:18-21,52
+  * weighted MSE head, regularisation list ........ src/models/estimator.py:48-56
+  * optimizer by Keras name, lr only .............. src/models/train_utils.py:13-16
+  * step counter == optimizer.iterations .......... src/models/estimator.py:45
+  * eval metrics of RegressionHead ................ src/models/estimator.py:48 (tf-estimator 2.11)
+  * predict: cosine over ROW embeddings + top_k ... src/models/model_utils.py:81-110, utils.py:12-19
+
+and of the pinned third-party semantics SURVEY.md §8a marks with a warning sign
+(SUM_OVER_BATCH_SIZE loss reduction, `get_losses_for` multiplicity m, OptimizerV2
+duplicate-index dedup = sum first then square, Keras-legacy Adagrad
+initial_accumulator_value=0.1 / epsilon=1e-7 with epsilon outside the sqrt, Keras-legacy
+Adam whose sparse path decays the WHOLE table every step).
+
+The parts of the reference that ARE importable here (`src/data/text8.py`) pin the data-side
+functions at the bottom of this file through committed fixtures: see
+`tests/golden/make_text8_golden.py` and `tests/test_oracle_golden.py`.
+
+Everything computes in the dtype of the arrays handed in: float64 tables give the
+high-precision oracle the fp32 HIP kernels are compared against; float32 tables give the
+"CPU port" that `bench.py` times.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+# Keras-legacy defaults
+ADAGRAD_INIT_ACC = 0.1
+KERAS_EPSILON = 1e-7
+ADAM_BETA1 = 0.9
+ADAM_BETA2 = 0.999
+INIT_RANGE = 0.05  # Keras Embedding default initializer "uniform" = U(-0.05, 0.05)
+
+
+@dataclasses.dataclass
+class Hyper:
+    """Hyper-parameters of one step (reference defaults: configs/app.ini:39-53)."""
+    l2_reg: float = 0.01
+    reg_mult: float = 2.0          # m: estimator.py:55 adds the loss list twice under keras>=2.4
+    learning_rate: float = 0.001
+    epsilon: float = KERAS_EPSILON
+    beta1: float = ADAM_BETA1
+    beta2: float = ADAM_BETA2
+
+
+class Tables:
+    """The five trainable variables + optimizer slots (model_utils.py:31-39)."""
+
+    def __init__(self, vocab_size, dim, optimizer="Adagrad", dtype=np.float64, seed=1):
+        rng = np.random.default_rng(seed)
+        u = lambda *s: rng.uniform(-INIT_RANGE, INIT_RANGE, size=s).astype(dtype)
+        self.V, self.d, self.dtype = int(vocab_size), int(dim), dtype
+        self.optimizer = optimizer
+        self.R, self.C = u(vocab_size, dim), u(vocab_size, dim)
+        self.br, self.bc = u(vocab_size), u(vocab_size)
+        self.g = dtype(0.0)
+        self.step = 0
+        names = ("R", "C", "br", "bc")
+        if optimizer == "Adagrad":
+            for n in names:
+                setattr(self, "A_" + n, np.full_like(getattr(self, n), ADAGRAD_INIT_ACC))
+            self.A_g = dtype(ADAGRAD_INIT_ACC)
+        elif optimizer == "Adam":
+            for n in names:
+                setattr(self, "M_" + n, np.zeros_like(getattr(self, n)))
+                setattr(self, "V_" + n, np.zeros_like(getattr(self, n)))
+            self.M_g = dtype(0.0)
+            self.V_g = dtype(0.0)
+        else:
+            raise ValueError("optimizer must be Adagrad or Adam, got %r" % (optimizer,))
+
+    def astype(self, dtype):
+        out = Tables.__new__(Tables)
+        out.V, out.d, out.dtype, out.optimizer, out.step = self.V, self.d, dtype, self.optimizer, self.step
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                setattr(out, k, v.astype(dtype))
+            elif isinstance(v, np.floating):
+                setattr(out, k, dtype(v))
+        return out
+
+    def copy(self):
+        return self.astype(self.dtype)
+
+
+def forward(t: Tables, row, col):
+    """logits p_i = r_i . c_i + br_i + bc_i + g  (model_utils.py:41-54)."""
+    r, c = t.R[row], t.C[col]
+    return (r * c).sum(-1) + t.br[row] + t.bc[col] + t.g
+
+
+def loss_terms(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
+    """(weighted_mse L, Reg) with the reference's reductions.
+
+    L   = sum_i w_i (p_i - y_i)^2 / B                     (estimator.py:48-51, SUM_OVER_BATCH_SIZE)
+    Reg = l2/(d B) sum_i(|r_i|^2+|c_i|^2) + l2/B sum_i(br_i^2+bc_i^2) + l2 g^2
+          (model_utils.py:8,18-21,32-38,52: activity regularisers on the gathered batch)
+    `inv_batch` overrides 1/B (data-parallel shards use 1/B_global).
+    """
+    dt = t.dtype
+    B = len(row)
+    ib = dt(1.0 / B) if inv_batch is None else dt(inv_batch)
+    r, c = t.R[row], t.C[col]
+    p = (r * c).sum(-1) + t.br[row] + t.bc[col] + t.g
+    diff = p - y.astype(dt)
+    L = (w.astype(dt) * diff * diff).sum() * ib
+    lam = dt(hp.l2_reg)
+    reg = lam / dt(t.d) * ib * ((r * r).sum() + (c * c).sum()) \
+        + lam * ib * ((t.br[row] ** 2).sum() + (t.bc[col] ** 2).sum())
+    return L, reg, diff
+
+
+def gradients(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
+    """Deduplicated gradients of TotalLoss = L + m*Reg  (SURVEY.md §8a a8-a9).
+
+    Returns dict with dense [V,d]/[V] summed gradients (zero on untouched rows), the scalar
+    global-bias gradient WITHOUT its own regulariser split out, per-pair e_i, and the loss.
+    In a data-parallel shard the l2*g^2 term (which does not depend on the batch) is added
+    once by the caller, so it is reported separately as `reg_g`/`dg_reg`.
+    """
+    dt = t.dtype
+    B = len(row)
+    ib = dt(1.0 / B) if inv_batch is None else dt(inv_batch)
+    lam, m, d = dt(hp.l2_reg), dt(hp.reg_mult), dt(t.d)
+    L, reg, diff = loss_terms(t, row, col, w, y, hp, inv_batch)
+    e = dt(2.0) * w.astype(dt) * diff * ib
+    kappa = dt(2.0) * m * lam / d * ib
+    kappa_b = dt(2.0) * m * lam * ib
+    r, c = t.R[row], t.C[col]
+    G_R = np.zeros_like(t.R)
+    G_C = np.zeros_like(t.C)
+    G_br = np.zeros_like(t.br)
+    G_bc = np.zeros_like(t.bc)
+    # OptimizerV2 dedup: Unique + UnsortedSegmentSum == np.add.at
+    np.add.at(G_R, row, e[:, None] * c + kappa * r)
+    np.add.at(G_C, col, e[:, None] * r + kappa * c)
+    np.add.at(G_br, row, e + kappa_b * t.br[row])
+    np.add.at(G_bc, col, e + kappa_b * t.bc[col])
+    touched_r = np.zeros(t.V, bool)
+    touched_c = np.zeros(t.V, bool)
+    touched_r[row] = True
+    touched_c[col] = True
+    return dict(G_R=G_R, G_C=G_C, G_br=G_br, G_bc=G_bc, sum_e=e.sum(), e=e,
+                L=L, reg=reg, reg_g=lam * t.g * t.g, dg_reg=dt(2.0) * m * lam * t.g,
+                touched_r=touched_r, touched_c=touched_c)
+
+
+def _adagrad(W, A, G, touched, lr, eps):
+    """Keras-legacy Adagrad, sparse: only touched rows move."""
+    A[touched] += G[touched] ** 2
+    W[touched] -= lr * G[touched] / (np.sqrt(A[touched]) + eps)
+
+
+def _adam_dense_decay(W, M, Vv, G, lr_t, b1, b2, eps):
+    """Keras-legacy Adam `_resource_apply_sparse`: m,v decay over the WHOLE variable, the
+    scaled gradient is scatter-added on touched rows, and every row moves (a11)."""
+    M *= b1
+    M += (1 - b1) * G
+    Vv *= b2
+    Vv += (1 - b2) * G * G
+    W -= lr_t * M / (np.sqrt(Vv) + eps)
+
+
+def apply_update(t: Tables, gr, hp: Hyper):
+    """Optimizer update of the five variables from summed gradients `gr`; step += 1."""
+    dt = t.dtype
+    lr, eps = dt(hp.learning_rate), dt(hp.epsilon)
+    dg = gr["sum_e"] + gr["dg_reg"]
+    if t.optimizer == "Adagrad":
+        _adagrad(t.R, t.A_R, gr["G_R"], gr["touched_r"], lr, eps)
+        _adagrad(t.C, t.A_C, gr["G_C"], gr["touched_c"], lr, eps)
+        _adagrad(t.br, t.A_br, gr["G_br"], gr["touched_r"], lr, eps)
+        _adagrad(t.bc, t.A_bc, gr["G_bc"], gr["touched_c"], lr, eps)
+        t.A_g = t.A_g + dg * dg
+        t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
+    else:
+        b1, b2 = dt(hp.beta1), dt(hp.beta2)
+        tt = t.step + 1
+        lr_t = dt(hp.learning_rate * math.sqrt(1.0 - hp.beta2 ** tt) / (1.0 - hp.beta1 ** tt))
+        _adam_dense_decay(t.R, t.M_R, t.V_R, gr["G_R"], lr_t, b1, b2, eps)
+        _adam_dense_decay(t.C, t.M_C, t.V_C, gr["G_C"], lr_t, b1, b2, eps)
+        _adam_dense_decay(t.br, t.M_br, t.V_br, gr["G_br"], lr_t, b1, b2, eps)
+        _adam_dense_decay(t.bc, t.M_bc, t.V_bc, gr["G_bc"], lr_t, b1, b2, eps)
+        t.M_g = b1 * t.M_g + (1 - b1) * dg
+        t.V_g = b2 * t.V_g + (1 - b2) * dg * dg
+        t.g = t.g - lr_t * t.M_g / (np.sqrt(t.V_g) + eps)
+    t.step += 1
+
+
+def train_step(t: Tables, row, col, w, y, hp: Hyper):
+    """One `session.run(train_op)`.  Returns (loss, L, Reg)."""
+    gr = gradients(t, row, col, w, y, hp)
+    m = t.dtype(hp.reg_mult)
+    reg = gr["reg"] + gr["reg_g"]
+    loss = gr["L"] + m * reg
+    apply_update(t, gr, hp)
+    return loss, gr["L"], reg
+
+
+def eval_metrics(t: Tables, row, col, w, y):
+    """RegressionHead eval metrics over one pass (tf-estimator 2.11 `_eval_metric_ops`):
+    average_loss = sum w l / sum w, prediction/mean, label/mean (both weighted means)."""
+    p = forward(t, row, col)
+    wd = w.astype(t.dtype)
+    yd = y.astype(t.dtype)
+    sw = wd.sum()
+    return dict(average_loss=(wd * (p - yd) ** 2).sum() / sw,
+                prediction_mean=(wd * p).sum() / sw, label_mean=(wd * yd).sum() / sw,
+                weight_sum=sw)
+
+
+def cosine_topk(R, query_ids, k):
+    """get_predictions (model_utils.py:81-110) with utils.cosine_similarity (utils.py:12-19):
+    l2-normalise rows (tf.math.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))), matmul,
+    top_k sorted descending (ties -> lower index first, as tf.math.top_k)."""
+    n = R / np.sqrt(np.maximum((R * R).sum(-1, keepdims=True), 1e-12))
+    sim = n[query_ids] @ n.T
+    idx = np.argsort(-sim, axis=-1, kind="stable")[:, :k]
+    return np.take_along_axis(sim, idx, -1), idx
+
+
+# --------------------------------------------------------------------------------------
+# Dedup index ("plan") — integer work, bit-exact target for glove_plan_build.
+# --------------------------------------------------------------------------------------
+def build_plan(row, col, chunk_cap):
+    """Reference construction of the per-batch dedup index the HIP library builds on device.
+
+    Row side: pairs stably sorted by row id; each run of equal ids is cut into chunks of at
+    most `chunk_cap` pairs.  Col side: the ROW-SORTED pairs stably sorted by col id, `c_perm`
+    pointing back into row-sorted positions.  See DESIGN.md "Data layout".
+    """
+    row = np.asarray(row, np.int64)
+    col = np.asarray(col, np.int64)
+    B = len(row)
+
+    def side(keys):
+        starts = np.flatnonzero(np.r_[True, keys[1:] != keys[:-1]]) if B else np.zeros(0, np.int64)
+        ends = np.r_[starts[1:], B] if B else starts
+        chunk_id, chunk_start, uniq_slot = [], [], []
+        for s, e_ in zip(starts, ends):
+            uniq_slot.append(len(chunk_id))
+            for cs in range(s, e_, chunk_cap):
+                chunk_id.append(int(keys[s]))
+                chunk_start.append(cs)
+        chunk_start.append(B)
+        uniq_slot.append(len(chunk_id))
+        return (np.asarray(chunk_id, np.int32), np.asarray(chunk_start, np.int32),
+                np.asarray(uniq_slot, np.int32))
+
+    perm_r = np.argsort(row, kind="stable")
+    s_row, s_col = row[perm_r], col[perm_r]
+    r_chunk_id, r_chunk_start, r_uniq_slot = side(s_row)
+    perm_c = np.argsort(s_col, kind="stable")
+    c_chunk_id, c_chunk_start, c_uniq_slot = side(s_col[perm_c])
+    return dict(perm_r=perm_r.astype(np.int32), r_partner=s_col.astype(np.int32),
+                r_chunk_id=r_chunk_id, r_chunk_start=r_chunk_start, r_uniq_slot=r_uniq_slot,
+                c_perm=perm_c.astype(np.int32), c_partner=s_row[perm_c].astype(np.int32),
+                c_chunk_id=c_chunk_id, c_chunk_start=c_chunk_start, c_uniq_slot=c_uniq_slot,
+                counts=np.asarray([len(r_chunk_id), len(r_uniq_slot) - 1,
+                                   len(c_chunk_id), len(c_uniq_slot) - 1], np.int32))
+
+
+# --------------------------------------------------------------------------------------
+# Data-side functions (pinned by the importable reference module src/data/text8.py).
+# --------------------------------------------------------------------------------------
+def glove_weight(count, alpha=0.75, x_max=100):
+    """src/data/text8.py:138-139."""
+    return np.clip(np.power(np.asarray(count, np.float64) / x_max, alpha), 0, 1)
+
+
+def cooccurrence(token_ids, context_size):
+    """Right-context co-occurrence, symmetrised (src/data/text8.py:84-108).
+
+    For every position p and offset k in 1..context_size with ids a=tok[p], b=tok[p+k], a!=b:
+    count(a,b)+=1, value(a,b)+=1/k; then the union with the swapped table is summed.
+    Returns (row, col, count, value) sorted by (row, col).
+    """
+    tok = np.asarray(token_ids, np.int64)
+    n = len(tok)
+    V = int(tok.max()) + 1 if n else 0
+    keys, vals = [], []
+    for k in range(1, context_size + 1):
+        a, b = tok[:n - k], tok[k:]
+        keep = a != b
+        keys.append(a[keep] * V + b[keep])
+        vals.append(np.full(int(keep.sum()), 1.0 / k))
+    keys = np.concatenate(keys) if keys else np.zeros(0, np.int64)
+    vals = np.concatenate(vals) if vals else np.zeros(0)
+    uk, inv = np.unique(keys, return_inverse=True)
+    cnt = np.bincount(inv, minlength=len(uk))
+    val = np.bincount(inv, weights=vals, minlength=len(uk))
+    r, c = uk // V, uk % V
+    # union swap + sum (text8.py:103-108)
+    k2 = np.concatenate([r * V + c, c * V + r])
+    uk2, inv2 = np.unique(k2, return_inverse=True)
+    cnt2 = np.bincount(inv2, weights=np.concatenate([cnt, cnt]), minlength=len(uk2)).astype(np.int64)
+    val2 = np.bincount(inv2, weights=np.concatenate([val, val]), minlength=len(uk2))
+    return uk2 // V, uk2 % V, cnt2, val2

@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C ABI) against the float64 oracle on identical inputs.
+
+Tolerances (fp32 kernels vs float64 restatement): loss rtol 1e-5; updated
+parameters / optimizer slots rtol 1e-5, atol 1e-6; integer index work bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import glove_ref as ref
+from helpers import assert_tables_close, make_batch, oracle_tables, tables_from_oracle, to_dev
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+PARAM_RTOL, PARAM_ATOL = 1e-5, 1e-6
+
+
+def _hyper(hp: ref.Hyper, B):
+    from trainer.hip_api import make_hyper
+    return make_hyper(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=hp.learning_rate, epsilon=hp.epsilon,
+                      beta1=hp.beta1, beta2=hp.beta2, batch_size=B)
+
+
+@pytest.mark.parametrize("B,V,cap", [(1, 5, 32), (7, 50, 32), (64, 50, 4), (1024, 300, 32), (5000, 97, 3),
+                                     (20000, 2000, 32), (100000, 12000, 16)])
+def test_plan_build_bit_exact(hip, B, V, cap):
+    row, col, w, y = make_batch(B + V, B, V)
+    drow, dcol, dw, dy = to_dev(row, col, w, y)
+    plan = hip.build_plan(drow, dcol, dw, dy, V, chunk_cap=cap)
+    want = ref.build_plan(row, col, cap)
+    counts = plan.counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, want["counts"])
+    nc_r, nu_r, nc_c, nu_c = counts
+    np.testing.assert_array_equal(plan.r_partner.cpu().numpy()[:B], want["r_partner"])
+    np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
+    np.testing.assert_array_equal(plan.r_y.cpu().numpy()[:B], y[want["perm_r"]])
+    np.testing.assert_array_equal(plan.r_chunk_id.cpu().numpy()[:nc_r], want["r_chunk_id"])
+    np.testing.assert_array_equal(plan.r_chunk_start.cpu().numpy()[:nc_r + 1], want["r_chunk_start"])
+    np.testing.assert_array_equal(plan.r_uniq_slot.cpu().numpy()[:nu_r + 1], want["r_uniq_slot"])
+    np.testing.assert_array_equal(plan.c_perm.cpu().numpy()[:B], want["c_perm"])
+    np.testing.assert_array_equal(plan.c_partner.cpu().numpy()[:B], want["c_partner"])
+    np.testing.assert_array_equal(plan.c_chunk_id.cpu().numpy()[:nc_c], want["c_chunk_id"])
+    np.testing.assert_array_equal(plan.c_chunk_start.cpu().numpy()[:nc_c + 1], want["c_chunk_start"])
+    np.testing.assert_array_equal(plan.c_uniq_slot.cpu().numpy()[:nu_c + 1], want["c_uniq_slot"])
+    # compacted copy describes the same index
+    cp = plan.compact()
+    assert cp.cap_chunks == max(nc_r, nc_c) and cp.cap_uniq == max(nu_r, nu_c)
+    np.testing.assert_array_equal(cp.r_chunk_start.cpu().numpy()[:nc_r + 1], want["r_chunk_start"])
+
+
+def test_plan_empty_batch(hip):
+    e = torch.empty(0, dtype=torch.int32, device="cuda:0")
+    f = torch.empty(0, dtype=torch.float32, device="cuda:0")
+    plan = hip.build_plan(e, e, f, f, 10)
+    assert plan.counts.tolist() == [0, 0, 0, 0]
+
+
+# (B, V, d, chunk_cap): d covers every (lanes-per-row, float4-per-lane) kernel shape
+STEP_CASES = [
+    (7, 50, 8, 32), (64, 50, 64, 4), (1024, 300, 64, 32), (1024, 50, 128, 32), (1024, 120, 300, 32),
+    (3000, 40, 16, 2), (4096, 500, 256, 8), (2048, 64, 512, 32), (2048, 64, 1024, 32), (512, 64, 768, 16),
+    (20000, 2000, 64, 32), (1024, 12000, 64, 32), (777, 33, 96, 5), (900, 70, 384, 7),
+]
+
+
+@pytest.mark.parametrize("B,V,d,cap", STEP_CASES)
+def test_adagrad_single_step(hip, B, V, d, cap):
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B * 3 + d, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    loss_out = torch.zeros(4, device="cuda:0")
+    hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+    loss, L, reg = ref.train_step(t, row, col, w, y, hp)
+    got = loss_out.cpu().numpy()
+    np.testing.assert_allclose(got[:3], [loss, L, reg], rtol=LOSS_RTOL)
+    assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
+
+
+def test_per_pair_error_coefficients(hip):
+    """e_i = 2 w_i (p_i - y_i)/B straight out of the rowpass workspace (e_i rtol 1e-5, atol 1e-7)."""
+    from trainer.hip_api import DeviceTables
+    B, V, d = 4096, 200, 64
+    row, col, w, y = make_batch(5, B, V)
+    hp = ref.Hyper()
+    t = oracle_tables(V, d, "Adagrad")
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V)
+    ws = hip.step_workspace(plan, d)
+    hip.rowpass(plan, dt, _hyper(hp, B), ws)
+    torch.cuda.synchronize()
+    e_dev = ws[:4 * B].view(torch.float32).cpu().numpy()     # first array of the workspace, row-sorted order
+    gr = ref.gradients(t, row, col, w, y, hp)
+    perm_r = np.argsort(row, kind="stable")
+    np.testing.assert_allclose(e_dev, gr["e"][perm_r], rtol=1e-5, atol=1e-7)
+    assert dt.global_step == 1          # rowpass advances global_step
+
+
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+@pytest.mark.parametrize("B,V,d", [(1024, 400, 64), (512, 100, 300)])
+def test_trajectory(hip, optimizer, B, V, d):
+    """30 consecutive steps on fresh batches: the state stays within tolerance of the oracle."""
+    from trainer.hip_api import DeviceTables
+    hp = ref.Hyper(learning_rate=0.01 if optimizer == "Adam" else 0.05)
+    t = oracle_tables(V, d, optimizer)
+    dt = tables_from_oracle(t, DeviceTables)
+    G = hip.dense_grad_buffer(dt) if optimizer == "Adam" else None
+    loss_out = torch.zeros(4, device="cuda:0")
+    for s in range(30):
+        row, col, w, y = make_batch(1000 + s, B, V)
+        plan = hip.build_plan(*to_dev(row, col, w, y), V)
+        if optimizer == "Adam":
+            hip.step_adam(plan, dt, _hyper(hp, B), G, loss_out)
+        else:
+            hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+        loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss_out[0].item(), loss, rtol=5e-5, err_msg="step %d" % s)
+    assert_tables_close(dt, t, rtol=2e-4, atol=1e-5)   # 30 steps of fp32 rounding
+    if G is not None:
+        assert float(G.abs().max()) == 0.0     # the dense apply leaves the gradient buffer zeroed
+
+
+@pytest.mark.parametrize("B,V,d,cap", [(7, 50, 8, 32), (1024, 300, 64, 32), (1024, 120, 300, 32), (5000, 60, 64, 4)])
+def test_adam_single_step_dense_decay(hip, B, V, d, cap):
+    """Keras-legacy Adam: every row moves, also untouched ones."""
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B + 11, B, V)
+    hp = ref.Hyper(learning_rate=0.001)
+    t = oracle_tables(V, d, "Adam")
+    # start from a mid-run state so that m, v of untouched rows are non-zero
+    rng = np.random.default_rng(3)
+    for n in ("R", "C", "br", "bc"):
+        setattr(t, "M_" + n, rng.normal(0, 1e-3, getattr(t, n).shape).astype(np.float32).astype(np.float64))
+        setattr(t, "V_" + n, (rng.uniform(0, 1e-5, getattr(t, n).shape)).astype(np.float32).astype(np.float64))
+    t.step = 41
+    dt = tables_from_oracle(t, DeviceTables)
+    before = dt.R.clone()
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    G = hip.dense_grad_buffer(dt)
+    loss_out = torch.zeros(4, device="cuda:0")
+    hip.step_adam(plan, dt, _hyper(hp, B), G, loss_out)
+    loss, L, reg = ref.train_step(t, row, col, w, y, hp)
+    np.testing.assert_allclose(loss_out.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
+    assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
+    untouched = np.setdiff1d(np.arange(V), row)
+    if len(untouched):
+        assert (dt.R[untouched] != before[untouched]).any()
+
+
+@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2)])
+def test_dense_path_equals_sparse_path_bitwise(hip, B, V, d, cap):
+    """dense_grad + dense_adagrad (the data-parallel form) == sparse apply, bit for bit: both sum
+    the same partials in the same order and G = 0 is an exact no-op for Adagrad."""
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(99, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    h = _hyper(hp, B)
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    hip.step_adagrad(plan, a, h, la)
+    G = hip.dense_grad_buffer(b)
+    hip.rowpass(plan, b, h)
+    hip.colpass(plan, b, h)
+    hip.dense_grad(plan, b, h, G)
+    hip.dense_adagrad(b, h, G, lb)
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+        assert torch.equal(a.s1[n], b.s1[n]), "slot " + n
+    assert torch.equal(a.scalars, b.scalars)
+    assert torch.equal(la, lb)
+    assert float(G.abs().max()) == 0.0
+
+
+def test_step_is_bitwise_repeatable(hip):
+    from trainer.hip_api import DeviceTables
+    B, V, d = 20000, 500, 64
+    row, col, w, y = make_batch(17, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    plan = hip.build_plan(*to_dev(row, col, w, y), V)
+    outs = []
+    for _ in range(2):
+        dt = tables_from_oracle(t, DeviceTables)
+        for _ in range(3):
+            hip.step_adagrad(plan, dt, _hyper(hp, B))
+        outs.append(dt)
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(outs[0], n), getattr(outs[1], n))
+    assert torch.equal(outs[0].scalars, outs[1].scalars)
+
+
+def test_heavy_ids_take_the_workgroup_path(hip):
+    """One id owning most of the batch (Zipf head) -> hundreds of chunks -> LDS-queue path."""
+    from trainer.hip_api import DeviceTables
+    B, V, d = 30000, 40, 64
+    rng = np.random.default_rng(2)
+    row = np.where(rng.random(B) < 0.7, 3, rng.integers(0, V, B)).astype(np.int32)
+    col = np.where(rng.random(B) < 0.5, 7, rng.integers(0, V, B)).astype(np.int32)
+    col[row == col] = (col[row == col] + 1) % V
+    _, _, w, y = make_batch(4, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=8)
+    loss_out = torch.zeros(4, device="cuda:0")
+    hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+    loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+    np.testing.assert_allclose(loss_out[0].item(), loss, rtol=LOSS_RTOL)
+    assert_tables_close(dt, t, 2e-5, PARAM_ATOL)
+
+
+def test_untouched_rows_do_not_move_under_adagrad(hip):
+    from trainer.hip_api import DeviceTables
+    B, V, d = 256, 5000, 64
+    row, col, w, y = make_batch(8, B, V, zipf=False)
+    dt = DeviceTables(V, d, "Adagrad", seed=3)
+    R0, A0 = dt.R.clone(), dt.s1["R"].clone()
+    plan = hip.build_plan(*to_dev(row, col, w, y), V)
+    hip.step_adagrad(plan, dt, _hyper(ref.Hyper(learning_rate=0.05), B))
+    untouched = torch.from_numpy(np.setdiff1d(np.arange(V), row)).cuda()
+    assert torch.equal(dt.R[untouched], R0[untouched]) and torch.equal(dt.s1["R"][untouched], A0[untouched])
+    touched = torch.from_numpy(np.unique(row)).cuda()
+    assert (dt.R[touched] != R0[touched]).any(dim=1).all()
+
+
+def test_eval_metrics(hip):
+    from trainer.hip_api import DeviceTables
+    B, V, d = 10000, 300, 64
+    row, col, w, y = make_batch(21, B, V)
+    t = oracle_tables(V, d, "Adagrad")
+    t.g = np.float64(np.float32(0.3))
+    dt = tables_from_oracle(t, DeviceTables)
+    sums = hip.eval_sums(*to_dev(row, col, w, y), dt).cpu().numpy()
+    want = ref.eval_metrics(t, row, col, w, y)
+    np.testing.assert_allclose(sums[0] / sums[1], want["average_loss"], rtol=1e-5)
+    np.testing.assert_allclose(sums[1], want["weight_sum"], rtol=1e-6)
+    np.testing.assert_allclose(sums[2] / sums[1], want["prediction_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sums[3] / sums[1], want["label_mean"], rtol=1e-6)
+    assert dt.global_step == 0      # EVAL mode leaves the step alone
+
+
+@pytest.mark.parametrize("V,d,k", [(500, 64, 20), (1000, 300, 5), (64, 8, 64)])
+def test_topk_cosine(hip, V, d, k):
+    rng = np.random.default_rng(5)
+    R = rng.normal(size=(V, d)).astype(np.float32)
+    R[7] = R[3]                          # exact tie -> lower index first, like tf.math.top_k
+    q = np.array([0, 3, 7, V - 1, 5], np.int32)
+    sims, idx = hip.topk_cosine(*to_dev(R, q), k)
+    want_s, want_i = ref.cosine_topk(R.astype(np.float64), q, k)
+    np.testing.assert_allclose(sims.cpu().numpy(), want_s, rtol=1e-5, atol=1e-6)
+    got_i = idx.cpu().numpy()
+    # identical neighbour sets; order may only differ where similarities agree to rounding
+    for a in range(len(q)):
+        mism = got_i[a] != want_i[a]
+        if mism.any():
+            np.testing.assert_allclose(want_s[a][mism], np.sort(want_s[a][mism])[::-1])
+            assert set(got_i[a]) == set(want_i[a]) or abs(want_s[a, -1] - ref.cosine_topk(
+                R.astype(np.float64), q[a:a + 1], k + 1)[0][0, -1]) < 1e-6
+    assert got_i[0, 0] == 0 and got_i[1, 0] == 3 and got_i[2, 0] == 3   # self first; tie -> index 3 before 7
+
+
+def test_argument_errors_are_reported_not_swallowed(hip):
+    from trainer.hip_api import DeviceTables, GloveHipError
+    with pytest.raises(ValueError):
+        DeviceTables(10, 6, "Adagrad")
+    with pytest.raises(ValueError):
+        DeviceTables(10, 8, "SGD")
+    row, col, w, y = make_batch(1, 64, 10)
+    dt = DeviceTables(10, 8, "Adagrad", seed=0)
+    plan = hip.build_plan(*to_dev(row, col, w, y), 10)
+    tiny = torch.empty(16, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(GloveHipError, match="WORKSPACE"):
+        hip.step_adagrad(plan, dt, _hyper(ref.Hyper(), 64), ws=tiny)
+    with pytest.raises(GloveHipError):
+        hip.build_plan(*[a.cpu() for a in to_dev(row, col, w, y)], 10)

@@ -1,0 +1,125 @@
+"""CPU tests of the oracle itself: the float64 restatement against finite differences and
+against its scalar-C twin, and the dedup-index construction against brute force."""
+import numpy as np
+import pytest
+
+import glove_ref as ref
+from helpers import make_batch
+
+
+def _total_loss(t, row, col, w, y, hp):
+    L, reg, _ = ref.loss_terms(t, row, col, w, y, hp)
+    return L + hp.reg_mult * (reg + hp.l2_reg * t.g * t.g)
+
+
+@pytest.mark.parametrize("m", [1.0, 2.0])
+def test_gradients_match_finite_differences(m):
+    B, V, d = 40, 9, 8
+    row, col, w, y = make_batch(0, B, V)
+    hp = ref.Hyper(reg_mult=m, l2_reg=0.3)
+    t = ref.Tables(V, d, "Adagrad", dtype=np.float64, seed=2)
+    t.g = np.float64(0.2)
+    gr = ref.gradients(t, row, col, w, y, hp)
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    for name, G in (("R", gr["G_R"]), ("C", gr["G_C"]), ("br", gr["G_br"]), ("bc", gr["G_bc"])):
+        W = getattr(t, name)
+        for _ in range(12):
+            idx = tuple(rng.integers(0, s) for s in W.shape)
+            old = W[idx]
+            W[idx] = old + eps
+            lp = _total_loss(t, row, col, w, y, hp)
+            W[idx] = old - eps
+            lm = _total_loss(t, row, col, w, y, hp)
+            W[idx] = old
+            np.testing.assert_allclose(G[idx], (lp - lm) / (2 * eps), rtol=1e-5, atol=1e-9, err_msg=name)
+    g0 = t.g
+    t.g = g0 + eps
+    lp = _total_loss(t, row, col, w, y, hp)
+    t.g = g0 - eps
+    lm = _total_loss(t, row, col, w, y, hp)
+    t.g = g0
+    np.testing.assert_allclose(gr["sum_e"] + gr["dg_reg"], (lp - lm) / (2 * eps), rtol=1e-5)
+
+
+def test_adagrad_sums_duplicates_before_squaring():
+    """Two pairs hitting the same row: A += (g1+g2)^2, not g1^2+g2^2."""
+    t = ref.Tables(3, 4, "Adagrad", dtype=np.float64, seed=0)
+    row, col = np.array([1, 1], np.int32), np.array([0, 2], np.int32)
+    w, y = np.ones(2, np.float32), np.array([1.0, -2.0], np.float32)
+    hp = ref.Hyper(l2_reg=0.0, learning_rate=0.1)
+    gr = ref.gradients(t, row, col, w, y, hp)
+    A0 = t.A_R.copy()
+    ref.apply_update(t, gr, hp)
+    np.testing.assert_allclose(t.A_R[1] - A0[1], gr["G_R"][1] ** 2)
+    assert (t.A_R[[0, 2]] == A0[[0, 2]]).all() and t.step == 1
+
+
+def test_adam_moves_untouched_rows():
+    t = ref.Tables(6, 4, "Adam", dtype=np.float64, seed=0)
+    t.M_R[:] = 0.01
+    t.V_R[:] = 1e-4
+    R0 = t.R.copy()
+    row, col, w, y = make_batch(1, 3, 6)
+    ref.train_step(t, row, col, w, y, ref.Hyper())
+    untouched = np.setdiff1d(np.arange(6), row)
+    assert len(untouched) and (t.R[untouched] != R0[untouched]).all()
+
+
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+def test_c_port_tracks_numpy_restatement(optimizer):
+    import glove_ref_c
+    B, V, d = 512, 200, 32
+    hp = ref.Hyper(learning_rate=0.05 if optimizer == "Adagrad" else 0.002)
+    t64 = ref.Tables(V, d, optimizer, dtype=np.float32, seed=4).astype(np.float64)
+    port = glove_ref_c.CPort(t64, B)
+    for s in range(10):
+        row, col, w, y = make_batch(50 + s, B, V)
+        loss64, L64, reg64 = ref.train_step(t64, row, col, w, y, hp)
+        loss, L, reg = port.step(row, col, w, y, hp)
+        np.testing.assert_allclose([loss, L, reg], [loss64, L64, reg64], rtol=2e-5)
+    np.testing.assert_allclose(port.arr["R"], t64.R, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(port.arr["bc"], t64.bc, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(port.g, t64.g, rtol=2e-4, atol=2e-6)
+    assert port.st.step == 10
+    assert not port.arr["G_R"].any() and not port.arr["mark_r"].any()
+
+
+@pytest.mark.parametrize("B,V,cap", [(1, 3, 4), (50, 7, 3), (1000, 31, 8), (300, 1000, 32)])
+def test_plan_partitions_the_batch(B, V, cap):
+    row, col, _, _ = make_batch(B, B, V)
+    p = ref.build_plan(row, col, cap)
+    nc_r, nu_r, nc_c, nu_c = p["counts"]
+    assert nu_r == len(np.unique(row)) and nu_c == len(np.unique(col))
+    # every pair is in exactly one chunk of each side; chunks respect the cap and hold one id
+    for side, keys in (("r", row[p["perm_r"]]), ("c", col[p["perm_r"]][p["c_perm"]])):
+        cs, cid = p[side + "_chunk_start"], p[side + "_chunk_id"]
+        assert cs[0] == 0 and cs[-1] == B and (np.diff(cs) > 0).all() and (np.diff(cs) <= cap).all()
+        for j in range(len(cid)):
+            assert (keys[cs[j]:cs[j + 1]] == cid[j]).all()
+        us = p[side + "_uniq_slot"]
+        assert us[0] == 0 and us[-1] == len(cid)
+        assert len(np.unique(cid[us[:-1]])) == len(us) - 1
+    # col side points back to the same pairs
+    np.testing.assert_array_equal(p["c_partner"], row[p["perm_r"]][p["c_perm"]])
+    # segment sums through the plan == np.add.at
+    e = np.random.default_rng(0).normal(size=B)
+    want = np.zeros(V)
+    np.add.at(want, col, e)
+    got = np.zeros(V)
+    e_rs = e[p["perm_r"]]
+    cs = p["c_chunk_start"]
+    for j, cid in enumerate(p["c_chunk_id"]):
+        got[cid] += e_rs[p["c_perm"][cs[j]:cs[j + 1]]].sum()
+    np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_eval_and_topk_reference_behaviour():
+    t = ref.Tables(20, 8, "Adagrad", dtype=np.float64, seed=1)
+    row, col, w, y = make_batch(3, 100, 20)
+    m = ref.eval_metrics(t, row, col, w, y)
+    p = ref.forward(t, row, col)
+    np.testing.assert_allclose(m["average_loss"], np.average((p - y) ** 2, weights=w))
+    sims, idx = ref.cosine_topk(t.R, np.array([4, 9]), 5)
+    assert idx[0, 0] == 4 and idx[1, 0] == 9 and np.allclose(sims[:, 0], 1.0)
+    assert (np.diff(sims, axis=1) <= 1e-15).all()
