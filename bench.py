@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — co-occurrence nonzeros/sec of the GloVe training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload text8_d64] [--batch-size B]
+
+A "step" is one optimizer step (fused forward+gradient passes + sparse Adagrad update) over one
+batch of B synthetic co-occurrence nonzeros that are already resident in HBM together with
+their dedup index (DESIGN.md "Data layout"; the index of a static stream is built once at load
+time, `--dynamic` puts the index build of every batch inside the timed region instead).
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own shard of
+nonzeros, computes the summed gradients of its batch into a dense buffer, the buffers are
+all-reduced over RCCL and every rank applies the identical dense Adagrad update
+(global batch = N * B, weak scaling).
+
+Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is measured live
+with HIP events on the launch stream in a second, instrumented pass over the same batches;
+`cpu_baseline` times the scalar C port of the oracle (oracle/glove_ref.c) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="text8_d64", choices=["text8_d64", "text8_v50k_d300", "zipf_v400k_d300"])
+    ap.add_argument("--batch-size", type=int, default=131072)
+    ap.add_argument("--chunk-cap", type=int, default=32)
+    ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad"])
+    ap.add_argument("--learning-rate", type=float, default=0.05)
+    ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(B, d, u_row, u_col):
+    """16 B of (row, col, weight, value) per nonzero + read W, read A, write W,
+    write A for every distinct touched row and its bias."""
+    return 16 * B + 16 * (d + 1) * (u_row + u_col)
+
+
+def cpu_baseline(workload, B, hp_kwargs, seconds):
+    sys.path.insert(0, str(REPO / "oracle"))
+    import numpy as np
+    import glove_ref as ref
+    import glove_ref_c
+    t = ref.Tables(workload["V"], workload["d"], "Adagrad", dtype=np.float32, seed=1)
+    port = glove_ref_c.CPort(t, B)
+    hp = ref.Hyper(**hp_kwargs)
+    row, col = workload["row"].cpu().numpy(), workload["col"].cpu().numpy()
+    w, y = workload["w"].cpu().numpy(), workload["y"].cpu().numpy()
+    nb = max(1, len(row) // B)
+    port.step(row[:B], col[:B], w[:B], y[:B], hp)            # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        b = n % nb
+        s = slice(b * B, (b + 1) * B)
+        port.step(row[s], col[s], w[s], y[s], hp)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 2000:
+            break
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n * B / el, "unit": "nonzeros/s", "cores": 1, "kind": "port",
+            "sample": "%d Adagrad steps of %d nonzeros (same batches, oracle/glove_ref.c, -O2 scalar fp32)" % (n, B),
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, GloveHip, make_hyper
+
+    hip = GloveHip(dev)
+    B, cap = args.batch_size, args.chunk_cap
+    wl = synthetic.make_workload(args.workload, seed=rank, device=dev, work_device=dev)
+    V, d = wl["V"], wl["d"]
+    nnz = wl["row"].numel()
+    nb = min(max(1, nnz // B), args.max_batches)
+    if nnz < B:
+        raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))
+
+    # ---- load time (untimed): resident batches + their dedup index
+    batches, plans = [], []
+    for b in range(nb):
+        s = slice(b * B, (b + 1) * B)
+        batches.append(tuple(wl[k][s].contiguous() for k in ("row", "col", "w", "y")))
+    t0 = time.perf_counter()
+    for bt in batches:
+        plans.append(hip.build_plan(*bt, V, chunk_cap=cap, compact=True))
+    torch.cuda.synchronize()
+    plan_build_ms = (time.perf_counter() - t0) * 1e3 / nb
+    counts = [p.counts.tolist() for p in plans]
+    u_row = sum(c[1] for c in counts) / nb
+    u_col = sum(c[3] for c in counts) / nb
+    chunks = sum(c[0] + c[2] for c in counts) / nb
+
+    tables = DeviceTables(V, d, args.optimizer, device=dev, seed=1)      # identical init on every rank
+    hyper = make_hyper(learning_rate=args.learning_rate, batch_size=B * world)
+    ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
+                     else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
+    loss_out = torch.zeros(4, device=dev)
+    G = hip.dense_grad_buffer(tables) if world > 1 else None
+
+    def step(i):
+        bt = batches[i % nb]
+        plan = hip.build_plan(*bt, V, chunk_cap=cap) if args.dynamic else plans[i % nb]
+        if world == 1:
+            hip.step_adagrad(plan, tables, hyper, loss_out, ws)
+        else:
+            hip.rowpass(plan, tables, hyper, ws)
+            hip.colpass(plan, tables, hyper, ws)
+            hip.dense_grad(plan, tables, hyper, G, ws)
+            dist.all_reduce(G)
+            hip.dense_adagrad(tables, hyper, G, loss_out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss_out[0].item())
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+
+    # ---- instrumented pass: HIP events around each kernel of the step, on the launch stream
+    kern = {"rowpass": 0.0, "colpass": 0.0, "apply": 0.0}
+    n_inst = min(args.steps, 50)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_inst)]
+    torch.cuda.synchronize()
+    for i in range(n_inst):
+        plan = plans[i % nb]
+        e = evs[i]
+        e[0].record(); hip.rowpass(plan, tables, hyper, ws)
+        e[1].record(); hip.colpass(plan, tables, hyper, ws)
+        if world == 1:
+            e[2].record(); hip.apply_adagrad(plan, tables, hyper, loss_out, ws)
+        else:
+            e[2].record(); hip.dense_grad(plan, tables, hyper, G, ws); G.zero_()
+        e[3].record()
+    torch.cuda.synchronize()
+    for e in evs:
+        kern["rowpass"] += e[0].elapsed_time(e[1]) * 1e3 / n_inst
+        kern["colpass"] += e[1].elapsed_time(e[2]) * 1e3 / n_inst
+        kern["apply"] += e[2].elapsed_time(e[3]) * 1e3 / n_inst
+    step_us = sum(kern.values())
+    alg = algorithmic_bytes(B, d, u_row, u_col)
+    achieved = alg / (step_us * 1e-6) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "co-occurrence nonzeros/sec", "value": args.steps * B * world / elapsed, "unit": "nonzeros/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "V": V, "d": d, "optimizer": args.optimizer,
+                       "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz,
+                       "resident_batches": nb, "chunk_cap": cap,
+                       "index": "rebuilt every step" if args.dynamic else "static, built at load",
+                       "parallelism": "dp%d dense-grad all-reduce" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "one step = rowpass + colpass + apply_adagrad",
+                         "algorithmic_bytes_per_step": alg, "kernel_us": kern,
+                         "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
+            "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,12 +35,15 @@ __global__ void gather_row_side(const int32_t *__restrict__ perm, const int32_t 
     }
 }
 
-// col side: partner = row id of the row-sorted pair the permutation points at
+// col side: partner = row id of the row-sorted pair the permutation points at; r_to_c = inverse
 __global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ sorted_row, int64_t n,
-                                int32_t *__restrict__ partner)
+                                int32_t *__restrict__ partner, int32_t *__restrict__ r_to_c)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        partner[i] = sorted_row[perm[i]];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = perm[i];
+        partner[i] = sorted_row[p];
+        r_to_c[p] = (int32_t)i;
+    }
 }
 
 // seg_start_in[k] = k where a new id starts, else 0 (max-scan turns it into "start of my run")
@@ -162,7 +165,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
-        !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
+        !plan->r_to_c || !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
         return GLOVE_E_BADARG;
     // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
@@ -190,7 +193,8 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
     HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
                                       plan->c_perm, (size_t)B, 0, bits, st));
-    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, B, plan->c_partner);
+    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, B, plan->c_partner,
+                       plan->r_to_c);
     if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
                             plan->c_uniq_slot, plan->counts + 2, st))
         return rc;

@@ -19,11 +19,14 @@ namespace glove {
 template <int LPR, int NV>
 __device__ inline void load_row(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
 {
+    // branch-free: lanes past the row end re-read its last float4 and are zeroed by a select
+    // (a predicated load makes hipcc branch around every row load and serialise its waits)
     const f4 *p = reinterpret_cast<const f4 *>(table) + (size_t)id * d4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i4 = lg + k * LPR;
-        dst[k] = (i4 < d4) ? p[i4] : f4{0.f, 0.f, 0.f, 0.f};
+        const f4 v = p[i4 < d4 ? i4 : d4 - 1];
+        dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -68,35 +71,67 @@ __device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, f
 }
 
 // ------------------------------------------------------------------------------------------
-// rowpass: one group of LPR lanes per row-side chunk.
+// rowpass / colpass: one GROUP of LPR lanes per chunk; a wave64 works on 64/LPR chunks at once.
+//
+// The step is latency-bound at realistic batch sizes (a few pairs per lane over the whole chip),
+// so each chunk is a short dependent chain  descriptor -> pair fields -> partner rows:
+//   * the pair fields of the WHOLE chunk are fetched up front, kSlots pairs per lane (coalesced),
+//     and handed round the group with ds_bpermute;
+//   * after that every loop trip costs one memory round trip with U partner rows in flight per
+//     group (4U rows per wave at d = 64);
+//   * chunks are dealt to groups round-robin over the grid so that the full-length chunks of the
+//     Zipf head do not pile up in a few workgroups.
+// chunk_cap <= kSlots * LPR.  (A wave-per-chunk form with the groups splitting one chunk's pairs
+// measured 40 % slower in-process at B = 131072, d = 64: it quadruples the instruction count.)
 // ------------------------------------------------------------------------------------------
-constexpr int kUnroll = 4;   // partner rows in flight per group
+template <int NV> struct Unroll { static constexpr int value = NV == 1 ? 8 : 4; };
+
+constexpr int kSlots = 2;
+
+template <int LPR, typename T>
+__device__ inline T group_bcast(const T (&mine)[kSlots], int q)
+{
+    const T v = (q >= LPR) ? mine[1] : mine[0];
+    return __shfl(v, q & (LPR - 1), LPR);
+}
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void rowpass_kernel(
     const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
-    const float *__restrict__ w, const float *__restrict__ y,
+    const float *__restrict__ w, const float *__restrict__ y, const int32_t *__restrict__ r_to_c,
     const int32_t *__restrict__ chunk_id, const int32_t *__restrict__ chunk_start,
     const float *__restrict__ R, const float *__restrict__ C,
     const float *__restrict__ br, const float *__restrict__ bc,
     const float *__restrict__ scalars, int64_t *__restrict__ step,
     int d4, float inv_batch,
-    float *__restrict__ e_out, float *__restrict__ gp, float *__restrict__ gb,
+    float *__restrict__ e_col, float *__restrict__ gp, float *__restrict__ gb,
     float *__restrict__ blockpart)
 {
     constexpr int GPB = kBlock / LPR;
+    constexpr int U = Unroll<NV>::value;
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const int n_chunks = counts[0];
     const float g = scalars[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
-
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
-
-    for (int j = blockIdx.x * GPB + grp; j < n_chunks; j += gridDim.x * GPB) {
+    for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
         const int32_t u = chunk_id[j];
         const int s = chunk_start[j];
         const int n = chunk_start[j + 1] - s;
+        int32_t my_partner[kSlots], my_epos[kSlots];
+        float my_w[kSlots], my_y[kSlots], my_e[kSlots];
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl) {
+            const int t = lg + sl * LPR;
+            const int k = s + (t < n ? t : 0);
+            my_partner[sl] = partner[k];
+            my_epos[sl] = r_to_c[k];
+            const float wv = w[k];
+            my_w[sl] = t < n ? wv : 0.f;
+            my_y[sl] = y[k];
+            my_e[sl] = 0.f;
+        }
         f4 r[NV], acc[NV];
         load_row<LPR, NV>(r, R, u, d4, lg);
         const float bru = br[u];
@@ -106,27 +141,26 @@ __global__ __launch_bounds__(kBlock) void rowpass_kernel(
 #pragma unroll
         for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
         float se = 0.f, cc_sum = 0.f;
-
-        for (int q0 = 0; q0 < n; q0 += kUnroll) {
-            int32_t col[kUnroll];
-            float wq[kUnroll], yq[kUnroll];
+        for (int q0 = 0; q0 < n; q0 += U) {
+            int32_t col[U];
+            float wq[U], yq[U];
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) {
-                const bool ok = q0 + a < n;
-                const int k = ok ? s + q0 + a : s;       // tail slots replay pair 0 with weight 0
-                col[a] = partner[k];
-                wq[a] = ok ? w[k] : 0.f;
-                yq[a] = y[k];
+            for (int a = 0; a < U; ++a) {
+                const int q = q0 + a < n ? q0 + a : 0;
+                col[a] = group_bcast<LPR>(my_partner, q);
+                const float wv = group_bcast<LPR>(my_w, q);
+                wq[a] = q0 + a < n ? wv : 0.f;
+                yq[a] = group_bcast<LPR>(my_y, q);
             }
-            f4 c[kUnroll][NV];
-            float bcv[kUnroll];
+            f4 c[U][NV];
+            float bcv[U];
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) {
+            for (int a = 0; a < U; ++a) {
                 load_row<LPR, NV>(c[a], C, col[a], d4, lg);
                 bcv[a] = bc[col[a]];
             }
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) {
+            for (int a = 0; a < U; ++a) {
                 const bool ok = q0 + a < n;
                 float dp = 0.f, cc = 0.f;
 #pragma unroll
@@ -137,16 +171,18 @@ __global__ __launch_bounds__(kBlock) void rowpass_kernel(
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
                 se += e;
-                if (ok) {
-                    cc_sum += cc;
-                    if (lg == 0) {
-                        e_out[s + q0 + a] = e;
-                        part[0] += wq[a] * diff * diff;
-                        part[2] += bcv[a] * bcv[a];
-                    }
+                cc_sum += ok ? cc : 0.f;
+                const int q = q0 + a;
+                if (ok && lg == (q & (LPR - 1))) { if (q >= LPR) my_e[1] = e; else my_e[0] = e; }
+                if (lg == 0) {
+                    part[0] += wq[a] * diff * diff;
+                    part[2] += ok ? bcv[a] * bcv[a] : 0.f;
                 }
             }
         }
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl)
+            if (lg + sl * LPR < n) e_col[my_epos[sl]] = my_e[sl];
         store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
         part[1] += cc_sum + (float)n * rr;
         if (lg == 0) {
@@ -158,43 +194,50 @@ __global__ __launch_bounds__(kBlock) void rowpass_kernel(
     block_partials_store(part, blockpart);
 }
 
-// ------------------------------------------------------------------------------------------
-// colpass: per col-side chunk, sum_i e_i R[row_i] and sum_i e_i.
-// ------------------------------------------------------------------------------------------
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void colpass_kernel(
     const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
-    const int32_t *__restrict__ perm, const int32_t *__restrict__ chunk_start,
-    const float *__restrict__ R, const float *__restrict__ e_in, int d4,
+    const int32_t *__restrict__ chunk_start,
+    const float *__restrict__ R, const float *__restrict__ e_col, int d4,
     float *__restrict__ gp, float *__restrict__ gb)
 {
     constexpr int GPB = kBlock / LPR;
+    constexpr int U = Unroll<NV>::value;
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const int n_chunks = counts[2];
-    for (int j = blockIdx.x * GPB + grp; j < n_chunks; j += gridDim.x * GPB) {
+    for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
         const int s = chunk_start[j];
         const int n = chunk_start[j + 1] - s;
+        int32_t my_partner[kSlots];
+        float my_e[kSlots];
+#pragma unroll
+        for (int sl = 0; sl < kSlots; ++sl) {
+            const int t = lg + sl * LPR;
+            const int k = s + (t < n ? t : 0);
+            my_partner[sl] = partner[k];
+            const float ev = e_col[k];
+            my_e[sl] = t < n ? ev : 0.f;
+        }
         f4 acc[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
         float se = 0.f;
-        for (int q0 = 0; q0 < n; q0 += kUnroll) {
-            int32_t rid[kUnroll];
-            float eq[kUnroll];
+        for (int q0 = 0; q0 < n; q0 += U) {
+            int32_t rid[U];
+            float eq[U];
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) {
-                const bool ok = q0 + a < n;
-                const int k = ok ? s + q0 + a : s;
-                rid[a] = partner[k];
-                const float ev = e_in[perm[k]];
-                eq[a] = ok ? ev : 0.f;
+            for (int a = 0; a < U; ++a) {
+                const int q = q0 + a < n ? q0 + a : 0;
+                rid[a] = group_bcast<LPR>(my_partner, q);
+                const float ev = group_bcast<LPR>(my_e, q);
+                eq[a] = q0 + a < n ? ev : 0.f;
             }
-            f4 r[kUnroll][NV];
+            f4 r[U][NV];
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) load_row<LPR, NV>(r[a], R, rid[a], d4, lg);
+            for (int a = 0; a < U; ++a) load_row<LPR, NV>(r[a], R, rid[a], d4, lg);
 #pragma unroll
-            for (int a = 0; a < kUnroll; ++a) {
+            for (int a = 0; a < U; ++a) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += eq[a] * r[a][k];
                 se += eq[a];
@@ -230,9 +273,6 @@ template <int LPR, int NV>
 __device__ inline void sum_partials(const SideBufs &sb, int first, int last, int stride, int d4, int lg,
                                     f4 (&G)[NV], float &Gb)
 {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) G[k] = f4{0.f, 0.f, 0.f, 0.f};
-    Gb = 0.f;
 #pragma unroll 4
     for (int sl = first; sl < last; sl += stride) {
         f4 p[NV];
@@ -243,11 +283,14 @@ __device__ inline void sum_partials(const SideBufs &sb, int first, int last, int
     }
 }
 
-// Calls f(is_row, id, G, Wv, Gb, bval) once per distinct id of both sides, on the LPR lanes of
-// one group (G/Wv hold that lane's float4 slices of the summed gradient and of the table row).
+// Visits every distinct id of both sides once, on the LPR lanes of one group.  `fn` supplies
+//   fn.prefetch(is_row, id, P, pb)                  its own row + bias slot (Adagrad accumulator,
+//                                                   or the dense gradient row), requested together
+//                                                   with the table row so the latencies overlap
+//   fn.finish(is_row, id, G, Wv, Gb, bval, P, pb)   G = summed gradient incl. the activity-L2 term
 template <int LPR, int NV, class F>
 __device__ inline void for_each_id(const int32_t *__restrict__ counts, const SideBufs &rs, const SideBufs &cs,
-                                   int d4, const StepConsts &k, F f)
+                                   int d4, const StepConsts &k, F fn)
 {
     constexpr int GPB = kBlock / LPR;
     __shared__ int heavy_q[kHeavyCap];
@@ -261,20 +304,9 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
 
-    auto finish = [&](const SideBufs &sb, bool is_row, int sl0, int sl1, f4 (&G)[NV], float Gb) {
-        const int32_t id = sb.chunk_id[sl0];
-        const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
-        f4 Wv[NV];
-        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
-        const float bval = sb.bias[id];
-        const float kc = k.kappa * cnt;
-#pragma unroll
-        for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
-        Gb += k.kappa_b * cnt * bval;
-        f(is_row, id, G, Wv, Gb, bval);
-    };
-
-    for (int q = blockIdx.x * GPB + grp; q < total; q += gridDim.x * GPB) {
+    // ids are dealt round-robin over the grid: the heavy ones are the low (frequent) ids and
+    // would otherwise all land in the first few workgroups
+    for (int q = blockIdx.x + grp * gridDim.x; q < total; q += gridDim.x * GPB) {
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
@@ -288,9 +320,21 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
                 continue;
             }
         }
-        f4 G[NV]; float Gb;
-        sum_partials<LPR, NV>(sb, sl0, sl1, 1, d4, lg, G, Gb);
-        finish(sb, is_row, sl0, sl1, G, Gb);
+        const int32_t id = sb.chunk_id[sl0];
+        const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
+        f4 G[NV], Wv[NV], P[NV];
+        load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);        // first partial: independent of id
+        float Gb = sb.gb[sl0];
+        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
+        const float bval = sb.bias[id];
+        float pb;
+        fn.prefetch(is_row, id, P, pb);
+        sum_partials<LPR, NV>(sb, sl0 + 1, sl1, 1, d4, lg, G, Gb);
+        const float kc = k.kappa * cnt;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
+        Gb += k.kappa_b * cnt * bval;
+        fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
     }
     __syncthreads();
     const int nh = heavy_n < kHeavyCap ? heavy_n : kHeavyCap;
@@ -300,39 +344,66 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
         const int sl0 = sb.uniq_slot[qq], sl1 = sb.uniq_slot[qq + 1];
-        f4 G[NV]; float Gb;
+        const int32_t id = sb.chunk_id[sl0];
+        f4 G[NV], Wv[NV], P[NV];
+        float Gb = 0.f, bval = 0.f, pb = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) G[kk] = f4{0.f, 0.f, 0.f, 0.f};
+        if (grp == 0) {
+            load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
+            bval = sb.bias[id];
+            fn.prefetch(is_row, id, P, pb);
+        }
         sum_partials<LPR, NV>(sb, sl0 + grp, sl1, GPB, d4, lg, G, Gb);
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) red[grp][lg + kk * LPR] = G[kk];
         if (lg == 0) redb[grp] = Gb;
         __syncthreads();
         if (grp == 0) {
-#pragma unroll
-            for (int kk = 0; kk < NV; ++kk) G[kk] = red[0][lg + kk * LPR];
-            Gb = redb[0];
             for (int g2 = 1; g2 < GPB; ++g2) {
 #pragma unroll
                 for (int kk = 0; kk < NV; ++kk) G[kk] += red[g2][lg + kk * LPR];
                 Gb += redb[g2];
             }
-            finish(sb, is_row, sl0, sl1, G, Gb);
+            const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
+            const float kc = k.kappa * cnt;
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
+            Gb += k.kappa_b * cnt * bval;
+            fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
         }
         __syncthreads();
     }
 }
 
-// Deterministic sum of the rowpass block partials (one wave, fixed order).
+// Deterministic sum of the rowpass block partials by the whole workgroup (thread t takes blocks
+// t, t+256, ...; then lanes, then waves, in a fixed order).  Result valid in thread 0.
 __device__ inline void sum_blockpart(const float *blockpart, int nblocks, float (&tot)[kPartials])
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ float red2[kBlock / 64][kPartials];
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    const f4 *bp = reinterpret_cast<const f4 *>(blockpart);
 #pragma unroll
-    for (int i = 0; i < kPartials; ++i) tot[i] = 0.f;
-    for (int b = lane; b < nblocks; b += 64) {
-#pragma unroll
-        for (int i = 0; i < kPartials; ++i) tot[i] += blockpart[(size_t)b * kPartials + i];
+    for (int it = 0; it < kMaxBlocks / kBlock; ++it) {
+        const int b = threadIdx.x + it * kBlock;
+        const f4 v = bp[b < nblocks ? b : 0];
+        acc += (b < nblocks) ? v : f4{0.f, 0.f, 0.f, 0.f};
     }
+    tot[0] = wave_sum(acc.x); tot[1] = wave_sum(acc.y); tot[2] = wave_sum(acc.z); tot[3] = wave_sum(acc.w);
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int i = 0; i < kPartials; ++i) tot[i] = wave_sum(tot[i]);
+        for (int i = 0; i < kPartials; ++i) red2[threadIdx.x >> 6][i] = tot[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kPartials; ++i) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kBlock / 64; ++wv) sacc += red2[wv][i];
+            tot[i] = sacc;
+        }
+    }
 }
 
 __device__ inline void loss_from_partials(const float (&tot)[kPartials], const StepConsts &k, float g,
@@ -345,31 +416,42 @@ __device__ inline void loss_from_partials(const float (&tot)[kPartials], const S
 }
 
 template <int LPR, int NV>
+struct AdagradApply {
+    SideBufs rs, cs;
+    int d4, lg;
+    float lr, eps;
+    __device__ void prefetch(bool is_row, int32_t id, f4 (&A)[NV], float &Ab) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+        load_row<LPR, NV>(A, sb.S1, id, d4, lg);
+        Ab = sb.S1b[id];
+    }
+    __device__ void finish(bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, f4 (&A)[NV],
+                           float Ab) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[kk], A[kk], G[kk], lr, eps);
+        store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
+        store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
+        if (lg == 0) {
+            adagrad_elem(bval, Ab, Gb, lr, eps);
+            sb.S1b[id] = Ab;
+            sb.bias[id] = bval;
+        }
+    }
+};
+
+template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
     const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ scalars, const float *__restrict__ blockpart, int nblocks_rowpass,
     float *__restrict__ loss_out)
 {
-    const int lg = threadIdx.x % LPR;
     for_each_id<LPR, NV>(counts, rs, cs, d4, k,
-        [&](bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval) {
-            const SideBufs &sb = is_row ? rs : cs;
-            f4 A[NV];
-            load_row<LPR, NV>(A, sb.S1, id, d4, lg);
-#pragma unroll
-            for (int kk = 0; kk < NV; ++kk) {
-                adagrad_vec(Wv[kk], A[kk], G[kk], k.lr, k.eps);
-            }
-            store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
-            store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
-            if (lg == 0) {
-                const float Ab = sb.S1b[id] + Gb * Gb;
-                sb.S1b[id] = Ab;
-                sb.bias[id] = bval - k.lr * Gb / (sqrtf(Ab) + k.eps);
-            }
-        });
+                         AdagradApply<LPR, NV>{rs, cs, d4, (int)(threadIdx.x % LPR), k.lr, k.eps});
     // global bias (dense Adagrad) + loss scalars: first wave of block 0
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (blockIdx.x == 0) {
         float tot[kPartials];
         sum_blockpart(blockpart, nblocks_rowpass, tot);
         if (threadIdx.x == 0) {
@@ -388,27 +470,34 @@ __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
 // Adds this plan's summed gradients into the dense buffers (no two work items share an id
 // within one side, so plain read-modify-write is race free).
 template <int LPR, int NV>
+struct DenseGradAdd {
+    float *G_R, *G_C, *G_br, *G_bc;
+    int d4, lg;
+    __device__ void prefetch(bool is_row, int32_t id, f4 (&old)[NV], float &oldb) const
+    {
+        load_row<LPR, NV>(old, is_row ? G_R : G_C, id, d4, lg);
+        oldb = (is_row ? G_br : G_bc)[id];
+    }
+    __device__ void finish(bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, f4 (&old)[NV],
+                           float oldb) const
+    {
+        (void)Wv; (void)bval;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) old[kk] += G[kk];
+        store_row<LPR, NV>(is_row ? G_R : G_C, (size_t)id, d4, lg, old);
+        if (lg == 0) (is_row ? G_br : G_bc)[id] = oldb + Gb;
+    }
+};
+
+template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void dense_grad_kernel(
     const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ G_R, float *__restrict__ G_C, float *__restrict__ G_br, float *__restrict__ G_bc,
     float *__restrict__ tail, const float *__restrict__ blockpart, int nblocks_rowpass)
 {
-    const int lg = threadIdx.x % LPR;
     for_each_id<LPR, NV>(counts, rs, cs, d4, k,
-        [&](bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval) {
-            (void)Wv; (void)bval;
-            float *Gd = is_row ? G_R : G_C;
-            f4 old[NV];
-            load_row<LPR, NV>(old, Gd, id, d4, lg);
-#pragma unroll
-            for (int kk = 0; kk < NV; ++kk) old[kk] += G[kk];
-            store_row<LPR, NV>(Gd, (size_t)id, d4, lg, old);
-            if (lg == 0) {
-                float *Gbd = is_row ? G_br : G_bc;
-                Gbd[id] += Gb;
-            }
-        });
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+                         DenseGradAdd<LPR, NV>{G_R, G_C, G_br, G_bc, d4, (int)(threadIdx.x % LPR)});
+    if (blockIdx.x == 0) {
         float tot[kPartials];
         sum_blockpart(blockpart, nblocks_rowpass, tot);
         if (threadIdx.x == 0) {
@@ -504,9 +593,10 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
-                     !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+                     !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
-    if (pick_row_shape(t->d / 4).lpr == 0) return GLOVE_E_BADARG;
+    const RowShape shape = pick_row_shape(t->d / 4);
+    if (shape.lpr == 0 || p->chunk_cap <= 0 || p->chunk_cap > kSlots * shape.lpr) return GLOVE_E_BADARG;
     return 0;
 }
 
@@ -569,8 +659,8 @@ int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                           \
     hipLaunchKernelGGL((rowpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->r_partner,      \
-                       p->r_w, p->r_y, p->r_chunk_id, p->r_chunk_start, t->R, t->C, t->br, t->bc, t->scalars, \
-                       t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart)
+                       p->r_w, p->r_y, p->r_to_c, p->r_chunk_id, p->r_chunk_start, t->R, t->C, t->br, t->bc,  \
+                       t->scalars, t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();
@@ -584,11 +674,11 @@ int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
-    const int nb = blocks_for(p->cap_chunks, kBlock / shape.lpr);
+    const int nb = rowpass_blocks(p, shape.lpr);
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                      \
     hipLaunchKernelGGL((colpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->c_partner, \
-                       p->c_perm, p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c)
+                       p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();

@@ -46,7 +46,7 @@ class GloveHyper(C.Structure):
 class GlovePlan(C.Structure):
     _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
                 ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp),
-                ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp),
+                ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp),
                 ("c_partner", _fp), ("c_perm", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp)]
@@ -203,7 +203,7 @@ class DeviceTables:
 class Plan:
     """Device-resident dedup index of one batch (see glove_plan in include/glove_hip.h)."""
 
-    INT_FIELDS = ("r_partner", "r_chunk_id", "r_chunk_start", "r_uniq_slot",
+    INT_FIELDS = ("r_partner", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot",
                   "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
@@ -216,7 +216,7 @@ class Plan:
         f32 = dict(dtype=torch.float32, device=dev)
         n = max(self.B, 1)
         self.counts = torch.zeros(4, **i32)
-        self.r_partner, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(3))
+        self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
         self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
@@ -241,7 +241,7 @@ class Plan:
         out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
         out.counts = self.counts.clone()
-        out.r_partner, out.r_w, out.r_y = self.r_partner, self.r_w, self.r_y
+        out.r_partner, out.r_w, out.r_y, out.r_to_c = self.r_partner, self.r_w, self.r_y, self.r_to_c
         out.c_partner, out.c_perm = self.c_partner, self.c_perm
         out.r_chunk_id = self.r_chunk_id[:max(out.cap_chunks, 1)].clone()
         out.c_chunk_id = self.c_chunk_id[:max(out.cap_chunks, 1)].clone()

@@ -79,12 +79,14 @@ typedef struct glove_plan {
     int32_t *r_partner;         /* [B] col id of pair k */
     float   *r_w;               /* [B] glove_weight */
     float   *r_y;               /* [B] glove_value  */
+    int32_t *r_to_c;            /* [B] col-side position of pair k (inverse of c_perm): where
+                                 * rowpass drops e_k so that colpass reads it in order */
     int32_t *r_chunk_id;        /* [cap_chunks]   row id of the chunk */
     int32_t *r_chunk_start;     /* [cap_chunks+1] first pair of the chunk; [chunks] = B */
     int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
     /* col side: position k = k-th row-sorted pair in (col id, row-sorted position) order */
     int32_t *c_partner;         /* [B] row id */
-    int32_t *c_perm;            /* [B] row-sorted position of the pair (where its e lives) */
+    int32_t *c_perm;            /* [B] row-sorted position of the pair */
     int32_t *c_chunk_id;
     int32_t *c_chunk_start;
     int32_t *c_uniq_slot;
@@ -117,7 +119,7 @@ int glove_colpass_f32(const glove_plan *plan, const glove_tables *t, const glove
 /* ---- sparse optimizer apply: OptimizerV2 dedup + ResourceSparseApplyAdagradV2 (a9, a10) ----
  * For every distinct id: G = sum of its chunk partials + activity-L2 term, then
  * A += G^2 ; W -= lr G / (sqrt(A)+eps) on the touched rows of R, C, br, bc; dense update of the
- * global bias; step += 1.  loss_out (device float[4]) = {loss, L, Reg, sum_e}. */
+ * global bias.  loss_out (device float[4]) = {loss, L, Reg, sum_e}. */
 int glove_apply_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                             void *ws, size_t ws_bytes, float *loss_out, void *stream);
 

@@ -243,7 +243,7 @@ def build_plan(row, col, chunk_cap):
 
     Row side: pairs stably sorted by row id; each run of equal ids is cut into chunks of at
     most `chunk_cap` pairs.  Col side: the ROW-SORTED pairs stably sorted by col id, `c_perm`
-    pointing back into row-sorted positions.  See DESIGN.md "Data layout".
+    pointing back into row-sorted positions and `r_to_c` its inverse.  See DESIGN.md "Data layout".
     """
     row = np.asarray(row, np.int64)
     col = np.asarray(col, np.int64)
@@ -268,7 +268,9 @@ def build_plan(row, col, chunk_cap):
     r_chunk_id, r_chunk_start, r_uniq_slot = side(s_row)
     perm_c = np.argsort(s_col, kind="stable")
     c_chunk_id, c_chunk_start, c_uniq_slot = side(s_col[perm_c])
-    return dict(perm_r=perm_r.astype(np.int32), r_partner=s_col.astype(np.int32),
+    r_to_c = np.empty(B, np.int64)
+    r_to_c[perm_c] = np.arange(B)
+    return dict(perm_r=perm_r.astype(np.int32), r_partner=s_col.astype(np.int32), r_to_c=r_to_c.astype(np.int32),
                 r_chunk_id=r_chunk_id, r_chunk_start=r_chunk_start, r_uniq_slot=r_uniq_slot,
                 c_perm=perm_c.astype(np.int32), c_partner=s_row[perm_c].astype(np.int32),
                 c_chunk_id=c_chunk_id, c_chunk_start=c_chunk_start, c_uniq_slot=c_uniq_slot,

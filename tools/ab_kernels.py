@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""In-process A/B timing of kernel variants (cdna guide rule 24: interleaved rounds, one process).
+Usage: python tools/ab_kernels.py [--workload text8_d64] [--batch-size 131072] [--caps 32,16]"""
+import argparse
+import ctypes as C
+import statistics
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from trainer import synthetic  # noqa: E402
+from trainer.hip_api import DeviceTables, GloveHip, make_hyper  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="text8_d64")
+    ap.add_argument("--batch-size", type=int, default=131072)
+    ap.add_argument("--caps", default="32,16")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=40)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    hip = GloveHip(dev)
+    set_variant = getattr(hip.lib, "glove_debug_set_variant", None)   # only in diagnostic builds
+    wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
+    V, d, B = wl["V"], wl["d"], args.batch_size
+    nb = min(8, wl["row"].numel() // B)
+    tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
+    hyper = make_hyper(learning_rate=0.05, batch_size=B)
+    loss = torch.zeros(4, device=dev)
+    configs = []
+    for cap in [int(c) for c in args.caps.split(",")]:
+        plans = [hip.build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
+                                chunk_cap=cap, compact=True) for b in range(nb)]
+        for v in [int(x) for x in args.variants.split(",")]:
+            configs.append((cap, v, plans))
+    ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
+    res = {(c, v): {"rowpass": [], "colpass": [], "apply": [], "step": []} for c, v, _ in configs}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for rnd in range(args.rounds + 1):
+        for cap, v, plans in configs:
+            if set_variant is not None:
+                set_variant(v)
+            for name in ("rowpass", "colpass", "apply", "step"):
+                fn = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws),
+                      "colpass": lambda p: hip.colpass(p, tables, hyper, ws),
+                      "apply": lambda p: hip.apply_adagrad(p, tables, hyper, loss, ws),
+                      "step": lambda p: hip.step_adagrad(p, tables, hyper, loss, ws)}[name]
+                for i in range(4):
+                    fn(plans[i % nb])
+                a, b = ev(), ev()
+                a.record()
+                for i in range(args.reps):
+                    fn(plans[i % nb])
+                b.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    res[(cap, v)][name].append(a.elapsed_time(b) * 1e3 / args.reps)
+    print("%s B=%d d=%d  (us per launch incl. launch gaps; median / min over %d rounds)" % (args.workload, B, d, args.rounds))
+    for (cap, v), r in res.items():
+        print("cap=%-3d variant=%d  " % (cap, v) + "  ".join(
+            "%s %.2f/%.2f" % (k, statistics.median(x), min(x)) for k, x in r.items()))
+
+
+if __name__ == "__main__":
+    main()
