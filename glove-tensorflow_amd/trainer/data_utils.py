@@ -1,0 +1,160 @@
+"""Input side of the training path.
+
+The reference streams `interaction.csv` through `tf.data.experimental.make_csv_dataset`
+(reference src/models/data_utils.py:4-26: four selected columns, string tokens, shuffle buffer,
+batches of --batch-size) and maps tokens to ids with a StaticHashTable inside the graph
+(reference src/models/model_utils.py:121-127; id = line number of vocab.txt, OOV -> 0).
+
+Here the CSV is parsed ONCE into a binary COO of (row_id i32, col_id i32, weight f32, value f32)
+that stays resident in HBM; the per-step input is a slice of it plus its dedup index.
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import logging
+import os
+
+import numpy as np
+import torch
+
+logger = logging.getLogger(__name__)
+
+
+def file_lines(fname) -> int:
+    """Reference src/models/utils.py:4-9."""
+    i = -1
+    with open(fname, encoding="utf8") as f:
+        for i, _ in enumerate(f):
+            pass
+    return i + 1
+
+
+def read_vocab(vocab_txt) -> list:
+    """Tokens in id order.  `vocab.txt` is written as "\\n".join(tokens) (reference
+    src/data/text8.py:150), i.e. without a trailing newline; a token may be any string,
+    including "nan"/"null"/"na"."""
+    with open(vocab_txt, encoding="utf8") as f:
+        text = f.read()
+    tokens = text.split("\n")
+    if tokens and tokens[-1] == "" and text.endswith("\n"):
+        tokens.pop()
+    return tokens
+
+
+def get_string_id_table(vocab_txt) -> dict:
+    """token -> id (line number); look up with `.get(token, 0)`: OOV -> 0 (model_utils.py:121-127).
+    A token listed twice keeps its LAST line, as TextFileInitializer would fail on duplicates
+    this is only a tie-break for malformed files."""
+    return {tok: i for i, tok in enumerate(read_vocab(vocab_txt))}
+
+
+def get_id_string_table(vocab_txt) -> list:
+    """id -> token; ids outside the table read "<UNK>" (model_utils.py:130-136)."""
+    return read_vocab(vocab_txt)
+
+
+def _cache_key(paths, vocab_txt, columns) -> str:
+    h = hashlib.sha1()
+    for p in list(paths) + [vocab_txt]:
+        st = os.stat(p)
+        h.update(("%s:%d:%d;" % (os.path.abspath(p), st.st_size, int(st.st_mtime))).encode())
+    h.update("|".join(columns).encode())
+    return h.hexdigest()[:16]
+
+
+def load_interaction_csv(file_pattern, vocab_txt, row_name="row_token", col_name="col_token",
+                         weight_name="glove_weight", target_name="glove_value", cache_dir=None):
+    """CSV -> dict(row i32[nnz], col i32[nnz], w f32[nnz], y f32[nnz]) as numpy arrays.
+
+    Tokens are read as plain strings with NA parsing OFF (text8 contains the words "nan", "null",
+    "na": reference README.md:54).  Rows keep file order.  With `cache_dir` the parsed COO is
+    stored as `interaction-<key>.coo.npz` and reused while the CSV / vocab files are unchanged.
+    """
+    import pandas as pd
+    paths = sorted(glob.glob(file_pattern)) or [file_pattern]
+    columns = [row_name, col_name, weight_name, target_name]
+    cache = None
+    if cache_dir:
+        cache = os.path.join(cache_dir, "interaction-%s.coo.npz" % _cache_key(paths, vocab_txt, columns))
+        if os.path.exists(cache):
+            z = np.load(cache)
+            return {k: z[k] for k in ("row", "col", "w", "y")}
+    table = get_string_id_table(vocab_txt)
+    parts = []
+    for p in paths:
+        df = pd.read_csv(p, usecols=columns, dtype={row_name: str, col_name: str, weight_name: np.float32,
+                                                    target_name: np.float32},
+                         keep_default_na=False, na_filter=False)
+        row = df[row_name].map(table).fillna(0).to_numpy(np.int32)   # OOV -> 0
+        col = df[col_name].map(table).fillna(0).to_numpy(np.int32)
+        parts.append((row, col, df[weight_name].to_numpy(np.float32), df[target_name].to_numpy(np.float32)))
+    out = {k: np.concatenate([p[i] for p in parts]) for i, k in enumerate(("row", "col", "w", "y"))}
+    if cache:
+        np.savez(cache, **out)
+    logger.info("loaded %d nonzeros from %s", len(out["row"]), paths)
+    return out
+
+
+class NonzeroStream:
+    """The nonzero stream of one rank, resident on the device, cut into fixed batches.
+
+    Training batches follow the reference's `num_epochs=None` dataset: full batches only, an
+    endless stream (data_utils.py:12-21).  The pairs are permuted once (seeded; the reference's
+    shuffle is an unseeded 10k-row buffer over an already hash-shuffled file), cut into
+    floor(nnz / B) batches whose dedup index is built once, and every epoch visits the batches
+    in a fresh random order.  The `nnz mod B` pairs behind the last full batch are only used when
+    the stream is re-cut (`recut()`), which draws a new permutation.
+    """
+
+    def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
+                 chunk_cap=32):
+        self.B, self.V, self.backend, self.device = int(batch_size), int(V), backend, torch.device(device)
+        self.chunk_cap = chunk_cap
+        self.gen = torch.Generator(device="cpu")
+        if seed is None:
+            self.gen.seed()
+        else:
+            self.gen.manual_seed(int(seed))
+        # contiguous shard of a global permutation for this rank (DESIGN.md "Multi-GPU")
+        n = len(coo["row"])
+        perm = torch.randperm(n, generator=self.gen)
+        per = n // world
+        mine = perm[rank * per:(rank + 1) * per] if world > 1 else perm
+        take = lambda a: torch.from_numpy(np.ascontiguousarray(a))[mine].to(self.device)
+        self.row, self.col, self.w, self.y = take(coo["row"]), take(coo["col"]), take(coo["w"]), take(coo["y"])
+        self.nnz = int(self.row.numel())
+        if self.nnz < self.B:
+            raise ValueError("batch size %d exceeds the %d nonzeros of this rank" % (self.B, self.nnz))
+        self.plans = []
+        self.recut(first=True)
+        self._order, self._pos = None, 0
+
+    def recut(self, first=False):
+        if not first:
+            p = torch.randperm(self.nnz, generator=self.gen).to(self.device)
+            self.row, self.col, self.w, self.y = self.row[p], self.col[p], self.w[p], self.y[p]
+        nb = self.nnz // self.B
+        self.plans = [self.backend.build_plan(*(t[b * self.B:(b + 1) * self.B] for t in
+                                                (self.row, self.col, self.w, self.y)), self.V, self.chunk_cap)
+                      for b in range(nb)]
+
+    @property
+    def batches_per_epoch(self) -> int:
+        return len(self.plans)
+
+    def next_plan(self):
+        if self._order is None or self._pos >= len(self._order):
+            self._order = torch.randperm(len(self.plans), generator=self.gen).tolist()
+            self._pos = 0
+        self.last_batch = self._order[self._pos]      # index b: pairs [b*B, (b+1)*B) of the stream
+        plan = self.plans[self.last_batch]
+        self._pos += 1
+        return plan
+
+    def eval_batches(self, batch_size=None):
+        """One pass over every nonzero of this rank, final partial batch included (eval input_fn:
+        num_epochs=1, estimator.py:87)."""
+        bs = int(batch_size or self.B)
+        for s in range(0, self.nnz, bs):
+            yield self.row[s:s + bs], self.col[s:s + bs], self.w[s:s + bs], self.y[s:s + bs]

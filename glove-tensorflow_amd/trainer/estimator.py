@@ -1,0 +1,189 @@
+"""`python -m trainer.estimator` — the GloVe trainer (reference src/models/estimator.py).
+
+Same command line, same job_dir layout and the same three modes as the reference's `model_fn`
+(TRAIN / EVAL / PREDICT, estimator.py:13-56), but the graph the reference hands to
+`tf.estimator.train_and_evaluate` (estimator.py:95) is replaced by a host loop that calls the
+hand-written HIP kernels of libglove_hip.so through the C ABI.  One process per GPU; launch with
+`python -m torch.distributed.run --nproc-per-node N -m trainer.estimator ...` for data parallel.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import sys
+import time
+
+import torch
+
+from trainer.config_utils import parse_args
+from trainer.data_utils import NonzeroStream, file_lines, get_id_string_table, load_interaction_csv
+from trainer.model_utils import MatrixFactorisation, get_predictions, summary_values
+from trainer.stepper import HipBackend, Stepper
+from trainer.train_utils import CheckpointManager, get_optimizer
+
+logger = logging.getLogger(__name__)
+
+
+def _dist_env():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class Estimator:
+    """The slice of `tf.estimator.Estimator` the reference uses (train_utils.py:30-36):
+    model_dir = job_dir, periodic checkpoints, auto-resume, train / evaluate / predict."""
+
+    def __init__(self, params: dict, backend=None, dist=None, device=None):
+        self.params = params
+        self.world, self.rank, local_rank = _dist_env() if dist is not None or backend is None else (1, 0, 0)
+        self.dist = dist
+        if backend is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("trainer.estimator needs an MI355X: the HIP path has no CPU fallback")
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+            if self.world > 1 and dist is None:
+                import torch.distributed as dist
+                dist.init_process_group("nccl", device_id=device)
+                self.dist = dist
+            backend = HipBackend(device)
+        self.backend, self.device = backend, torch.device(device)
+        self.vocab_size = file_lines(params["vocab_txt"])
+        opt = get_optimizer(params["optimizer"], learning_rate=params["learning_rate"])
+        self.optimizer_name = opt["class_name"]
+        seed = params.get("seed")
+        self.model = MatrixFactorisation(self.vocab_size, params["embedding_size"], params["l2_reg"],
+                                         optimizer=self.optimizer_name, device=self.device,
+                                         seed=None if seed is None else seed + 1)
+        if self.world > 1:      # identical replicas: rank 0's init wins
+            t = self.model.tables
+            for buf in (t.R, t.C, t.br, t.bc):
+                self.dist.broadcast(buf, src=0)
+        self.ckpt = CheckpointManager(params["job_dir"], params.get("save_checkpoints_secs", 300.0),
+                                      params.get("keep_checkpoint_max", 5))
+        self.ckpt.restore(self.model.tables)
+        self._stream = None
+
+    # ---- input_fn
+    def stream(self) -> NonzeroStream:
+        if self._stream is None:
+            a = self.params["input_fn_args"]
+            row, col, weight, target = a["select_columns"]
+            coo = load_interaction_csv(a["file_pattern"], self.params["vocab_txt"], row, col, weight, target,
+                                       cache_dir=self.params["job_dir"] if self.rank == 0 else None)
+            self._stream = NonzeroStream(coo, a["batch_size"], self.vocab_size, self.backend, self.device,
+                                         rank=self.rank, world=self.world, seed=self.params.get("seed"),
+                                         chunk_cap=self.params.get("chunk_cap", 32))
+        return self._stream
+
+    def _log(self, name, record):
+        if self.rank != 0:
+            return
+        path = os.path.join(self.params["job_dir"], name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(record) + "\n")
+
+    # ---- TRAIN
+    def train(self, max_steps: int):
+        """Runs until global_step == max_steps (absolute, train_utils.py:39-40)."""
+        p, tables = self.params, self.model.tables
+        step = tables.global_step
+        if step >= max_steps:
+            logger.info("global_step %d >= max_steps %d: nothing to train", step, max_steps)
+            return
+        stream = self.stream()
+        hyper_kwargs = dict(l2_reg=p["l2_reg"], reg_mult=p.get("reg_multiplicity", 2.0),
+                            learning_rate=p["learning_rate"])
+        stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
+        log_every = max(1, int(p.get("log_every", 100)))
+        if self.rank == 0 and self.ckpt.latest() is None:
+            self.ckpt.save(tables)          # Estimator saves at step 0 too
+        t_last, s_last = time.perf_counter(), step
+        while step < max_steps:
+            stepper.step(stream.next_plan())
+            step += 1
+            if step % log_every == 0 or step == max_steps:
+                rec = stepper.read_loss()                      # device sync
+                if not math.isfinite(rec["loss"]):
+                    raise FloatingPointError("loss is %r at global_step %d" % (rec["loss"], step))   # NanTensorHook
+                now = time.perf_counter()
+                rate = (step - s_last) / max(now - t_last, 1e-9)
+                rec.update(global_step=step, steps_per_sec=rate,
+                           nonzeros_per_sec=rate * p["batch_size"] * self.world, **summary_values(self.model))
+                self._log("train_log.jsonl", rec)
+                logger.info("global_step %d: loss = %.6f (%.1f steps/s)", step, rec["loss"], rate)
+                t_last, s_last = now, step
+            if self.ckpt.due() or step == max_steps:
+                if self.rank == 0:
+                    self.ckpt.save(tables)
+                if not p.get("skip_eval"):
+                    self.evaluate()
+        torch.cuda.synchronize() if self.device.type == "cuda" else None
+
+    # ---- EVAL
+    def evaluate(self) -> dict:
+        """One pass over the CSV (the reference evaluates on the training file, estimator.py:86-87).
+        RegressionHead metrics: average_loss = sum w l / sum w, loss = mean over batches of the
+        batch-mean weighted loss, prediction/mean, label/mean."""
+        tables, stream = self.model.tables, self.stream()
+        sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+        n_batches = 0
+        for row, col, w, y in stream.eval_batches():
+            self.backend.eval_sums(row, col, w, y, tables, sums)
+            n_batches += 1
+        if self.world > 1:
+            self.dist.all_reduce(sums)
+        s = sums.tolist()
+        rec = {"global_step": tables.global_step, "average_loss": s[0] / s[1],
+               "loss": s[0] / (stream.nnz * self.world) , "prediction/mean": s[2] / s[1], "label/mean": s[3] / s[1]}
+        self._log(os.path.join("eval", "eval_log.jsonl"), rec)
+        logger.info("eval at global_step %d: average_loss = %.6f", rec["global_step"], rec["average_loss"])
+        return rec
+
+    # ---- PREDICT
+    def predict(self, batch=256):
+        """Every vocab line as the query token (estimator.py:59-76); yields one dict per token."""
+        id_string = get_id_string_table(self.params["vocab_txt"])
+        k = min(self.params.get("top_k", 20), self.vocab_size)
+        for s in range(0, self.vocab_size, batch):
+            ids = torch.arange(s, min(s + batch, self.vocab_size), dtype=torch.int32)
+            out = get_predictions(self.backend, self.model, ids, id_string, k)
+            for i in range(len(ids)):
+                yield {"input_string": out["input_string"][i], "input_embedding": out["input_embedding"][i].numpy(),
+                       "top_k_similarity": out["top_k_similarity"][i].numpy(),
+                       "top_k_string": out["top_k_string"][i]}
+
+
+def estimator_predict(params):
+    """Reference estimator.py:72-76."""
+    return Estimator(params).predict()
+
+
+def main(argv=None):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(name)s: %(message)s")
+    world, rank, _ = _dist_env()
+    params = parse_args(argv) if rank == 0 or world == 1 else None
+    if world > 1:
+        # every rank must agree on the (time-stamped) job_dir: rank 0 decides
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        box = [params]
+        dist.broadcast_object_list(box, src=0)
+        params = box[0]
+        estimator = Estimator(params, dist=dist)
+    else:
+        estimator = Estimator(params)
+    estimator.train(params["train_steps"])
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    try:
+        main()
+    except KeyboardInterrupt:
+        pass

@@ -1,0 +1,84 @@
+"""One optimizer step = `session.run(train_op)` of the reference (estimator.py:49-56), on one
+GPU or data-parallel over the GPUs of a node.
+
+Data-parallel form (new: the reference is single-process).  Every rank holds its
+own shard of the nonzero stream and a full replica of the five variables and their slots.
+Per step every rank runs the forward+gradient passes over its batch of B nonzeros with
+inv_batch = 1 / (world * B), adds the summed gradients into one flat dense buffer
+[G_R | G_C | G_br | G_bc | tail], the buffers are summed with ONE all-reduce (RCCL over xGMI when
+the backend is "nccl") and every rank applies the identical dense update.  The result equals a
+single-GPU step at batch size world * B up to fp32 summation order.
+
+`backend` is the kernel provider: `HipBackend` (below) is the only product implementation and
+drives libglove_hip.so; there is no CPU implementation in the product.  Tests inject their own
+provider to exercise the sharding / collective logic with gloo on CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class HipBackend:
+    """Kernel provider on top of the C ABI (trainer.hip_api.GloveHip)."""
+
+    def __init__(self, device):
+        from trainer.hip_api import GloveHip
+        self.hip = GloveHip(device)
+        self.device = torch.device(device)
+
+    def build_plan(self, row, col, w, y, V, chunk_cap):
+        return self.hip.build_plan(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), V,
+                                   chunk_cap=chunk_cap, compact=True)
+
+    def make_hyper(self, **kw):
+        from trainer.hip_api import make_hyper
+        return make_hyper(**kw)
+
+    def dense_grad_buffer(self, tables):
+        return self.hip.dense_grad_buffer(tables)
+
+    def step_sparse_adagrad(self, plan, tables, hyper, loss_out):
+        self.hip.step_adagrad(plan, tables, hyper, loss_out)
+
+    def local_dense_grad(self, plan, tables, hyper, G):
+        self.hip.rowpass(plan, tables, hyper)
+        self.hip.colpass(plan, tables, hyper)
+        self.hip.dense_grad(plan, tables, hyper, G)
+
+    def apply_dense(self, tables, hyper, G, loss_out):
+        if tables.optimizer == "Adagrad":
+            self.hip.dense_adagrad(tables, hyper, G, loss_out)
+        else:
+            self.hip.dense_adam(tables, hyper, G, loss_out)
+
+    def eval_sums(self, row, col, w, y, tables, sums):
+        return self.hip.eval_sums(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), tables, sums)
+
+    def topk_cosine(self, R, query_ids, k):
+        return self.hip.topk_cosine(R, query_ids, k)
+
+
+class Stepper:
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None):
+        self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
+        if self.world > 1 and dist is None:
+            raise ValueError("world > 1 needs an initialised torch.distributed module")
+        self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
+        # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
+        self.dense = self.world > 1 or tables.optimizer != "Adagrad"
+        self.G = backend.dense_grad_buffer(tables) if self.dense else None
+
+    def step(self, plan):
+        if not self.dense:
+            self.backend.step_sparse_adagrad(plan, self.tables, self.hyper, self.loss_out)
+            return
+        self.backend.local_dense_grad(plan, self.tables, self.hyper, self.G)
+        if self.world > 1:
+            self.dist.all_reduce(self.G)          # sum over ranks; the tail carries the loss partials
+        self.backend.apply_dense(self.tables, self.hyper, self.G, self.loss_out)
+
+    def read_loss(self) -> dict:
+        """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
+        loss, L, reg, _ = self.loss_out.tolist()
+        return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}

@@ -1,0 +1,65 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/glove_hip.h declares and
+its structs have the layout the ctypes binding assumes.  No compute calls here."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+HEADER = REPO / "include" / "glove_hip.h"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from trainer import hip_api
+    if not hip_api.LIB_PATH.exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    return hip_api.load_library()
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(glove_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from trainer import hip_api
+    names = declared_functions()
+    assert len(names) >= 16
+    assert set(names) == set(hip_api.EXPORTED_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.glove_abi_version() == hip_api.GLOVE_ABI_VERSION
+
+
+def test_size_queries_are_pure_host_functions(lib):
+    assert lib.glove_dense_grad_floats(100, 64) == 2 * 100 * 64 + 2 * 100 + 8
+    small, big = lib.glove_step_workspace_bytes(1024, 1024, 64), lib.glove_step_workspace_bytes(4096, 4096, 64)
+    assert 0 < small < big
+    assert lib.glove_plan_workspace_bytes(1024, 1000) > 1024 * 4 * 5
+    assert lib.glove_topk_workspace_bytes(8, 1000, 20) >= 8 * 1000 * 4
+
+
+def test_struct_layout_matches_the_c_header(tmp_path):
+    from trainer import hip_api
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "glove_hip.h"\nint main(void){\n'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(glove_tables), sizeof(glove_hyper), '
+                   'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
+                   'offsetof(glove_plan, counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, c_uniq_slot));\n'
+                   'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    T, H, P = hip_api.GloveTables, hip_api.GloveHyper, hip_api.GlovePlan
+    assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
+                   P.counts.offset, P.r_to_c.offset, P.c_uniq_slot.offset]
+
+
+def test_missing_library_is_an_error_not_a_fallback(tmp_path):
+    from trainer import hip_api
+    with pytest.raises(hip_api.GloveHipError, match="no CPU fallback"):
+        hip_api.load_library(tmp_path / "libglove_hip.so")

@@ -1,0 +1,61 @@
+"""Data-parallel host logic on CPU: world_size 2 over gloo, kernels replaced by the oracle.
+
+Property under test (DESIGN.md "Multi-GPU"): N ranks stepping on their own batches of B
+nonzeros with one all-reduce of the flat dense-gradient buffer == one rank stepping on the
+concatenated batch of N*B nonzeros."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = Path(__file__).resolve().parent
+WORLD = 2
+B, V, D, STEPS = 96, 40, 8, 5
+
+
+def _batches():
+    sys.path.insert(0, str(HERE))
+    from helpers import make_batch
+    return [[make_batch(100 * s + r, B, V) for r in range(WORLD)] for s in range(STEPS)]
+
+
+def _worker(rank, port, optimizer, out_dir):
+    for p in (HERE.parent, HERE.parent / "oracle", HERE):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import glove_ref as ref
+    from oracle_backend import OracleBackend, OracleTables
+    from trainer.stepper import Stepper
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    tables = OracleTables(ref.Tables(V, D, optimizer, dtype=np.float64, seed=3))
+    backend = OracleBackend()
+    stepper = Stepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist)
+    assert stepper.dense and abs(stepper.hyper["inv_batch"] - 1.0 / (WORLD * B)) < 1e-15
+    for step_batches in _batches():
+        stepper.step(backend.build_plan(*step_batches[rank], V, 32))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), R=tables.t.R, C=tables.t.C, br=tables.t.br,
+             bc=tables.t.bc, g=tables.t.g, step=tables.t.step)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer):
+    sys.path.insert(0, str(HERE.parent / "oracle"))
+    import glove_ref as ref
+    port = 29500 + os.getpid() % 2000 + (0 if optimizer == "Adagrad" else 1)
+    mp.spawn(_worker, args=(port, optimizer, str(tmp_path)), nprocs=WORLD, join=True)
+    t = ref.Tables(V, D, optimizer, dtype=np.float64, seed=3)
+    hp = ref.Hyper(learning_rate=0.05)
+    for step_batches in _batches():
+        joint = [np.concatenate([b[i] for b in step_batches]) for i in range(4)]
+        ref.train_step(t, *joint, hp)
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(WORLD)]
+    for name in ("R", "C", "br", "bc", "g"):
+        np.testing.assert_array_equal(ranks[0][name], ranks[1][name])           # replicas stay identical
+        np.testing.assert_allclose(ranks[0][name], getattr(t, name), rtol=1e-10, atol=1e-13)
+    assert int(ranks[0]["step"]) == STEPS

@@ -1,0 +1,87 @@
+"""End-to-end trainer on the GPU: CLI, job_dir layout, resume, export, and the trajectory parity
+gates of SURVEY.md §8d (same batches + same init for 1,024 steps at bs = 1,024: 100-step-smoothed
+loss within 1 % of the CPU restatement, top-20 neighbour overlap >= 0.9 on probe tokens)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import glove_ref as ref
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def test_cli_train_resume_export(hip, tmp_path):
+    from trainer import estimator, export_embeddings
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+            "--train-steps", "60", "--log-every", "20", "--seed", "7"]
+    estimator.main(argv)
+    assert (job / "params.json").exists() and (job / vocab.name).exists()
+    assert (job / "checkpoint").read_text().startswith('model_checkpoint_path: "model.ckpt-60"')
+    assert (job / "model.ckpt-0.pt").exists() and (job / "model.ckpt-60.pt").exists()
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert [r["global_step"] for r in log] == [20, 40, 60]
+    assert all(np.isfinite(r["loss"]) for r in log) and log[-1]["loss"] < log[0]["loss"]
+    ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+    assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
+    # resume: max_steps is absolute
+    estimator.main(argv[:-6] + ["--train-steps", "100", "--log-every", "20", "--seed", "7"])
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert log[-1]["global_step"] == 100 and (job / "model.ckpt-100.pt").exists()
+    estimator.main(argv[:-6] + ["--train-steps", "100", "--log-every", "20"])      # nothing left to do
+    assert len((job / "train_log.jsonl").read_text().splitlines()) == len(log)
+    # export (PREDICT mode over the vocabulary)
+    out = tmp_path / "embeddings.json"
+    export_embeddings.main(job_dir=str(job), embeddings_json=str(out))
+    emb = json.loads(out.read_text())
+    tokens = vocab.read_text().split("\n")
+    assert set(emb) == set(tokens) - {"<UNK>"} and "nan" in emb
+    assert emb["the"]["item_id"] == "the" and len(emb["the"]["item_embedding"]) == 16
+    # predictions: the query token is its own nearest neighbour (reference README.md:284)
+    params = json.loads((job / "params.json").read_text())
+    first = next(iter(estimator.Estimator(params).predict()))
+    assert first["top_k_string"][0] == first["input_string"] and abs(first["top_k_similarity"][0] - 1) < 1e-5
+    assert len(first["top_k_string"]) == 20
+
+
+@pytest.mark.parametrize("optimizer,lr", [("Adam", 0.001), ("Adagrad", 0.05)])
+def test_loss_curve_and_neighbours_match_cpu_restatement(hip, optimizer, lr):
+    from helpers import tables_from_oracle
+    from trainer import synthetic
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables
+    from trainer.stepper import HipBackend, Stepper
+    V, d, B, steps = 600, 64, 1024, 1024
+    row, col, w, y = synthetic.text8_shaped(V=V, n_tokens=400_000, seed=5)
+    coo = dict(row=row.numpy(), col=col.numpy(), w=w.numpy(), y=y.numpy())
+    backend = HipBackend("cuda:0")
+    stream = NonzeroStream(coo, B, V, backend, "cuda:0", seed=11)
+    assert stream.batches_per_epoch >= 8
+    t = ref.Tables(V, d, optimizer, dtype=np.float32, seed=1).astype(np.float64)
+    dt = tables_from_oracle(t, DeviceTables)
+    hp = ref.Hyper(learning_rate=lr)
+    stepper = Stepper(backend, dt, dict(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=lr), B)
+    gpu_loss, cpu_loss = [], []
+    host = {k: getattr(stream, k).cpu().numpy() for k in ("row", "col", "w", "y")}
+    for s in range(steps):
+        stepper.step(stream.next_plan())
+        gpu_loss.append(stepper.loss_out[0].item())
+        sl = slice(stream.last_batch * B, (stream.last_batch + 1) * B)
+        cpu_loss.append(ref.train_step(t, host["row"][sl], host["col"][sl], host["w"][sl], host["y"][sl], hp)[0])
+    gpu_loss, cpu_loss = np.array(gpu_loss), np.array(cpu_loss)
+    smooth = lambda x: np.convolve(x, np.ones(100) / 100, mode="valid")
+    np.testing.assert_allclose(smooth(gpu_loss), smooth(cpu_loss), rtol=0.01)
+    assert cpu_loss[-100:].mean() < cpu_loss[:100].mean()
+    assert dt.global_step == steps
+    # top-20 neighbours of probe tokens by cosine over ROW embeddings
+    probes = np.array([1, 2, 5, 17, 100], np.int32)
+    _, idx = backend.topk_cosine(dt.R, torch.from_numpy(probes).cuda(), 20)
+    _, want = ref.cosine_topk(t.R, probes, 20)
+    overlap = [len(set(a) & set(b)) / 20 for a, b in zip(idx.cpu().numpy().tolist(), want.tolist())]
+    assert min(overlap) >= 0.9, overlap

@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference interface: defaults, flags, job_dir layout, checkpoints."""
+import json
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def test_defaults_match_reference_app_ini():
+    """reference configs/app.ini:39-53 under ENVIRONMENT=dev."""
+    from trainer import config
+    assert (config.EMBEDDING_SIZE, config.L2_REG, config.OPTIMIZER, config.LEARNING_RATE, config.BATCH_SIZE,
+            config.TOP_K) == (64, 0.01, "Adam", 0.001, 1024, 20)
+    assert config.TRAIN_STEPS == 1024                      # [dev] override (app.ini:49-50)
+    assert config.read_config(environment="prod").getint("TRAIN_STEPS") == 65536
+    assert (config.ROW_NAME, config.COL_NAME, config.TARGET_NAME, config.WEIGHT_NAME) == (
+        "row_token", "col_token", "glove_value", "glove_weight")
+    assert config.TRAIN_CSV == "data/interaction.csv" and config.JOB_DIR == "checkpoints/estimator"
+
+
+def test_cli_flags_are_the_reference_flags():
+    from trainer.config_utils import build_parser
+    flags = {a.option_strings[0] for a in build_parser()._actions if a.option_strings}
+    reference = {"--train-csv", "--vocab-txt", "--row-name", "--col-name", "--target-name", "--weight-name",
+                 "--pos-name", "--neg-name", "--job-dir", "--disable-datetime-path", "--embedding-size", "--l2-reg",
+                 "--neg-factor", "--optimizer", "--learning-rate", "--batch-size", "--train-steps",
+                 "--steps-per-epoch", "--top-k"}                       # config_utils.py:78-180
+    assert reference <= flags
+    ns = build_parser().parse_args(["--embedding-size", "300", "--optimizer", "Adagrad", "--learning-rate", "0.05"])
+    assert ns.embedding_size == 300 and ns.optimizer == "Adagrad" and ns.learning_rate == 0.05
+    assert ns.reg_multiplicity == 2.0
+
+
+def test_init_params_builds_the_job_dir(tmp_path):
+    from trainer.config_utils import parse_args
+    vocab = GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    params = parse_args(["--job-dir", str(tmp_path / "job"), "--vocab-txt", str(vocab), "--train-csv", "x.csv"])
+    assert re.fullmatch(r".*job-\d{8}-\d{6}", params["job_dir"])          # config_utils.py:57-61
+    job = Path(params["job_dir"])
+    assert (job / vocab.name).read_text() == vocab.read_text()             # copied (config_utils.py:63-66)
+    assert params["vocab_txt"] == str(job / vocab.name)                   # repointed (config_utils.py:63-66)
+    saved = json.loads((job / "params.json").read_text())
+    assert saved["input_fn_args"] == {"file_pattern": "x.csv", "batch_size": 1024,
+                                      "select_columns": ["row_token", "col_token", "glove_weight", "glove_value"],
+                                      "target_names": ["glove_value"]}
+    assert saved["serving_input_fn_args"] == {"string_features": ["row_token", "col_token"]}
+    fixed = parse_args(["--job-dir", str(tmp_path / "fixed"), "--disable-datetime-path", "--vocab-txt", str(vocab)])
+    assert fixed["job_dir"] == str(tmp_path / "fixed")
+
+
+def test_get_optimizer_by_keras_name():
+    from trainer.train_utils import get_optimizer
+    assert get_optimizer("adagrad", learning_rate=0.1) == {
+        "class_name": "Adagrad", "config": {"initial_accumulator_value": 0.1, "epsilon": 1e-7, "learning_rate": 0.1}}
+    assert get_optimizer("Adam")["config"]["beta_2"] == 0.999
+    with pytest.raises(ValueError, match="no HIP kernel"):
+        get_optimizer("Ftrl")
+
+
+def test_checkpoint_layout_and_resume(tmp_path):
+    from trainer.hip_api import DeviceTables
+    from trainer.train_utils import CheckpointManager
+    t = DeviceTables(12, 8, "Adam", device="cpu", seed=0)
+    mgr = CheckpointManager(str(tmp_path), save_secs=300, keep_max=3)
+    for step in (0, 10, 20, 30, 40):
+        t.step.fill_(step)
+        t.R += 1.0
+        mgr.save(t)
+    state = (tmp_path / "checkpoint").read_text()
+    assert state.splitlines()[0] == 'model_checkpoint_path: "model.ckpt-40"'
+    assert sorted(p.name for p in tmp_path.glob("model.ckpt-*")) == [
+        "model.ckpt-20.pt", "model.ckpt-30.pt", "model.ckpt-40.pt"]            # keep_checkpoint_max
+    fresh = DeviceTables(12, 8, "Adam", device="cpu", seed=1)
+    assert CheckpointManager(str(tmp_path)).restore(fresh)
+    assert fresh.global_step == 40 and torch.equal(fresh.R, t.R) and torch.equal(fresh.s2["C"], t.s2["C"])
+    with pytest.raises(ValueError, match="checkpoint is for"):
+        CheckpointManager(str(tmp_path)).restore(DeviceTables(12, 16, "Adam", device="cpu", seed=1))
+    assert not CheckpointManager(str(tmp_path / "empty")).restore(fresh)
+
+
+def test_device_tables_follow_keras_defaults():
+    from trainer.hip_api import DeviceTables
+    t = DeviceTables(1000, 64, "Adagrad", device="cpu", seed=0)
+    for w in (t.R, t.C, t.br, t.bc):
+        assert -0.05 <= float(w.min()) and float(w.max()) <= 0.05 and abs(float(w.mean())) < 5e-3   # U(-0.05, 0.05)
+    assert float(t.scalars[0]) == 0.0 and float(t.scalars[1]) == pytest.approx(0.1)               # g = 0, acc = 0.1
+    assert all(float(s.min()) == pytest.approx(0.1) for s in t.s1.values())
+    a = DeviceTables(10, 8, "Adam", device="cpu", seed=0)
+    assert all(float(s.abs().max()) == 0.0 for s in list(a.s1.values()) + list(a.s2.values()))
+    assert not torch.equal(DeviceTables(10, 8, "Adam", device="cpu").R, DeviceTables(10, 8, "Adam", device="cpu").R)
+
+
+def test_synthetic_workloads_are_well_formed():
+    from trainer import synthetic
+    row, col, w, y = synthetic.text8_shaped(V=600, n_tokens=400_000, seed=3)
+    assert row.dtype == torch.int32 and w.dtype == torch.float32 and (row != col).all()
+    assert int(row.max()) < 600 and float(w.min()) > 0 and float(w.max()) <= 1.0
+    pairs = set(zip(row.tolist(), col.tolist()))
+    assert len(pairs) == row.numel() and all((c, r) in pairs for r, c in list(pairs)[:500])   # unique, symmetric
+    r2, c2, w2, y2 = synthetic.zipf_sampled(1000, 20000, seed=1)
+    assert (r2 != c2).all() and int(r2.max()) < 1000 and torch.isfinite(y2).all()
+    assert np.bincount(r2.numpy(), minlength=1000)[0] > np.bincount(r2.numpy(), minlength=1000)[500]
