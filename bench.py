@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad"])
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
@@ -55,6 +56,22 @@ def algorithmic_bytes(B, d, u_row, u_col):
     """16 B of (row, col, weight, value) per nonzero + read W, read A, write W,
     write A for every distinct touched row and its bias."""
     return 16 * B + 16 * (d + 1) * (u_row + u_col)
+
+
+def measured_traffic(workload, B, cap):
+    """HBM-side bytes per step from the committed PMC summary of this exact configuration
+    (profiles/*_traffic.json, produced by tools/pmc_traffic.py from separate `rocprofv3 --pmc`
+    passes of this bench); None when no summary matches."""
+    import glob
+    for f in sorted(glob.glob(str(REPO / "profiles" / "*_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            m = j.get("meta", {})
+            if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap:
+                return float(j["traffic_bytes_per_step"]), os.path.basename(f)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def cpu_baseline(workload, B, hp_kwargs, seconds):
@@ -161,12 +178,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    # One hipGraph holds a full sweep over the resident batches (nb steps); it is replayed
+    # steps // nb times and the remainder runs eagerly, so exactly `steps` steps are timed.
+    use_graph = world == 1 and not args.dynamic and not args.no_graph
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(nb):
+                step(i)                       # warm the launch path on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(nb):
+                step(i)
+
+    def run(n_steps, first):
+        done = 0
+        if graph is not None:
+            for _ in range(n_steps // nb):
+                graph.replay()
+            done = (n_steps // nb) * nb
+        for i in range(done, n_steps):
+            step(first + i)
+
+    run(args.warmup, 0)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run(args.steps, args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -177,29 +218,33 @@ def main():
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
 
-    # ---- instrumented pass: HIP events around each kernel of the step, on the launch stream
-    kern = {"rowpass": 0.0, "colpass": 0.0, "apply": 0.0}
-    n_inst = min(args.steps, 50)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_inst)]
-    torch.cuda.synchronize()
-    for i in range(n_inst):
-        plan = plans[i % nb]
-        e = evs[i]
-        e[0].record(); hip.rowpass(plan, tables, hyper, ws)
-        e[1].record(); hip.colpass(plan, tables, hyper, ws)
-        if world == 1:
-            e[2].record(); hip.apply_adagrad(plan, tables, hyper, loss_out, ws)
-        else:
-            e[2].record(); hip.dense_grad(plan, tables, hyper, G, ws); G.zero_()
-        e[3].record()
-    torch.cuda.synchronize()
-    for e in evs:
-        kern["rowpass"] += e[0].elapsed_time(e[1]) * 1e3 / n_inst
-        kern["colpass"] += e[1].elapsed_time(e[2]) * 1e3 / n_inst
-        kern["apply"] += e[2].elapsed_time(e[3]) * 1e3 / n_inst
+    # ---- instrumented pass: HIP events (on the launch stream) around `reps` back-to-back launches of
+    # each kernel of the step over the same resident batches; per-launch time = span / reps (it includes
+    # the ~1-2 us launch-to-launch gap that rocprofv3's per-kernel durations exclude)
+    kern = {}
+    reps = max(nb, min(200, args.steps))
+    calls = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws), "colpass": lambda p: hip.colpass(p, tables, hyper, ws)}
+    if world == 1:
+        calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
+    else:
+        calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
+    for name, fn in calls.items():
+        for i in range(4):
+            fn(plans[i % nb])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(reps):
+            fn(plans[i % nb])
+        b.record()
+        torch.cuda.synchronize()
+        kern[name] = a.elapsed_time(b) * 1e3 / reps
+    if G is not None:
+        G.zero_()
     step_us = sum(kern.values())
     alg = algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
+
+    traffic, traffic_src = measured_traffic(args.workload, B, cap) if world == 1 else (None, None)
 
     if rank == 0:
         out = {
@@ -210,10 +255,11 @@ def main():
                        "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz,
                        "resident_batches": nb, "chunk_cap": cap,
                        "index": "rebuilt every step" if args.dynamic else "static, built at load",
+                       "launch": "hipGraph replay" if graph is not None else "eager",
                        "parallelism": "dp%d dense-grad all-reduce" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "one step = rowpass + colpass + apply_adagrad",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "one step = " + " + ".join(kern),
                          "algorithmic_bytes_per_step": alg, "kernel_us": kern,
                          "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
