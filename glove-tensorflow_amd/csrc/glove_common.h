@@ -12,6 +12,21 @@ constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
 constexpr int kPartials = 4;       // per-block loss partials: sum w diff^2, sum |r|^2+|c|^2, sum b^2, sum e
 
+// ---- diagnostic build only (-DGLOVE_STAMPS): per-wave wall-clock stamps (s_memrealtime, 100 MHz)
+#ifdef GLOVE_STAMPS
+extern __device__ unsigned long long *g_stamps;     // [waves][8], set by glove_debug_set_stamps
+__device__ inline void stamp(int slot)
+{
+    if ((threadIdx.x & 63) == 0 && g_stamps)
+        g_stamps[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+#define GLOVE_STAMP(slot) stamp(slot)
+#define GLOVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define GLOVE_STAMP(slot) ((void)0)
+#define GLOVE_DRAIN() ((void)0)
+#endif
+
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- cross-lane sums ------------------------------------------------------------------
@@ -28,11 +43,11 @@ __device__ inline float dpp_add(float v)
 template <int LPR>
 __device__ inline float group_sum(float v)
 {
-    static_assert(LPR == 16 || LPR == 32 || LPR == 64, "group width");
+    static_assert(LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "group width");
     v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror
+    if (LPR >= 16) v = dpp_add<0x140>(v);   // row_mirror
     if (LPR >= 32) v += __shfl_xor(v, 16, 64);
     if (LPR >= 64) v += __shfl_xor(v, 32, 64);
     return v;
@@ -116,6 +131,33 @@ inline RowShape pick_row_shape(int d4)
     }
     return best;
 }
+
+// Shapes of the gather passes (rowpass / colpass): narrow groups (8 lanes = one 128-B line per
+// load at d = 64) put 8 chunks on a wave, which divides the per-pair bookkeeping instructions.
+inline RowShape pick_pass_shape(int d4)
+{
+    if (d4 <= 8) return RowShape{8, 1};
+    if (d4 <= 16) return RowShape{8, 2};      // d = 64: measured faster than 16 x 1 (A/B, same process)
+    return pick_row_shape(d4);                // wider rows: 16-lane x 5 measured slower than 32 x 3 at d = 300
+}
+
+#define GLOVE_DISPATCH_PASS_SHAPE(shape, CALL)                                  \
+    do {                                                                        \
+        const int key_ = (shape).lpr * 8 + (shape).nv;                          \
+        switch (key_) {                                                         \
+        case 8 * 8 + 1: { CALL(8, 1); } break;                                  \
+        case 8 * 8 + 2: { CALL(8, 2); } break;                                  \
+        case 16 * 8 + 2: { CALL(16, 2); } break;                                \
+        case 32 * 8 + 1: { CALL(32, 1); } break;                                \
+        case 32 * 8 + 2: { CALL(32, 2); } break;                                \
+        case 32 * 8 + 3: { CALL(32, 3); } break;                                \
+        case 64 * 8 + 1: { CALL(64, 1); } break;                                \
+        case 64 * 8 + 2: { CALL(64, 2); } break;                                \
+        case 64 * 8 + 3: { CALL(64, 3); } break;                                \
+        case 64 * 8 + 4: { CALL(64, 4); } break;                                \
+        default: return GLOVE_E_BADARG;                                         \
+        }                                                                       \
+    } while (0)
 
 #define GLOVE_DISPATCH_ROW_SHAPE(shape, CALL)                                   \
     do {                                                                        \

@@ -16,6 +16,10 @@
 
 namespace glove {
 
+#ifdef GLOVE_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#endif
+
 template <int LPR, int NV>
 __device__ inline void load_row(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
 {
@@ -27,6 +31,29 @@ __device__ inline void load_row(f4 (&dst)[NV], const float *table, int32_t id, i
         const int i4 = lg + k * LPR;
         const f4 v = p[i4 < d4 ? i4 : d4 - 1];
         dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// Gather-pass row load: 32-bit byte offsets off a uniform base (tables < 4 GiB, checked on the
+// host) so the compiler can use the SGPR-base + VGPR-offset load form instead of 64-bit pointer
+// arithmetic per row; FULL (d4 == LPR*NV) drops the row-end predicate altogether, otherwise only the
+// last float4 slot of a lane can lie past the row end.
+template <int LPR, int NV, bool FULL>
+__device__ inline void load_row_fast(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
+{
+    const char *base = reinterpret_cast<const char *>(table);
+    const uint32_t row_bytes = FULL ? (uint32_t)(LPR * NV * 16) : (uint32_t)d4 * 16u;
+    const uint32_t off = (uint32_t)id * row_bytes + (uint32_t)lg * 16u;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (FULL || k < NV - 1) {
+            dst[k] = *reinterpret_cast<const f4 *>(base + (off + (uint32_t)(k * LPR * 16)));
+        } else {
+            const int i4 = lg + k * LPR;
+            const uint32_t o = (uint32_t)id * row_bytes + (uint32_t)(i4 < d4 ? i4 : d4 - 1) * 16u;
+            const f4 v = *reinterpret_cast<const f4 *>(base + o);
+            dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -71,33 +98,31 @@ __device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, f
 }
 
 // ------------------------------------------------------------------------------------------
-// rowpass / colpass: one GROUP of LPR lanes per chunk; a wave64 works on 64/LPR chunks at once.
+// Gather passes (rowpass / colpass): one GROUP of LPR lanes per chunk, 64/LPR chunks per wave.
 //
-// The step is latency-bound at realistic batch sizes (a few pairs per lane over the whole chip),
-// so each chunk is a short dependent chain  descriptor -> pair fields -> partner rows:
-//   * the pair fields of the WHOLE chunk are fetched up front, kSlots pairs per lane (coalesced),
-//     and handed round the group with ds_bpermute;
-//   * after that every loop trip costs one memory round trip with U partner rows in flight per
-//     group (4U rows per wave at d = 64);
-//   * chunks are dealt to groups round-robin over the grid so that the full-length chunks of the
-//     Zipf head do not pile up in a few workgroups.
-// chunk_cap <= kSlots * LPR.  (A wave-per-chunk form with the groups splitting one chunk's pairs
-// measured 40 % slower in-process at B = 131072, d = 64: it quadruples the instruction count.)
+// The step is latency-bound at realistic batch sizes (a few pairs per lane over the whole chip), so
+// a chunk is a short dependent chain  descriptor -> pair fields -> partner rows:
+//   * the pair fields of the WHOLE chunk are fetched up front (lane t takes pairs t, t+LPR, ...,
+//     coalesced) and staged in LDS; every trip reads the fields of its U pairs back with
+//     ds_read_b128 (a broadcast inside the group);
+//   * after that every trip costs one memory round trip with U partner rows in flight per group;
+//   * groups are 8 lanes wide at d <= 64 (8 lanes x 2 float4 = one 128-B line per load), so a wave
+//     carries 8 chunks and the per-pair bookkeeping (addresses, DPP butterfly, diff, e) is issued
+//     once for 8 pairs;
+//   * chunks are dealt to groups round-robin over the grid so the full-length chunks of the Zipf head
+//     do not pile up in a few workgroups.
+// Measured in-process (tools/ab_kernels.py) against two earlier forms: a wave per chunk (-40 %) and
+// per-pair ds_bpermute broadcasts on 16-lane groups (-7 % at B = 131072, -20 % at B = 1048576, d = 64).
+// kChunkMax bounds chunk_cap.
 // ------------------------------------------------------------------------------------------
-template <int NV> struct Unroll { static constexpr int value = NV == 1 ? 8 : 4; };
+constexpr int kChunkMax = 32;
+constexpr int kFieldStride = kChunkMax + 4;      // dwords; +16 B staggers the groups over the LDS banks
 
-constexpr int kSlots = 2;
+template <int NV> struct PassUnroll { static constexpr int value = NV <= 2 ? 8 : 4; };
 
-template <int LPR, typename T>
-__device__ inline T group_bcast(const T (&mine)[kSlots], int q)
-{
-    const T v = (q >= LPR) ? mine[1] : mine[0];
-    return __shfl(v, q & (LPR - 1), LPR);
-}
-
-template <int LPR, int NV>
-__global__ __launch_bounds__(kBlock) void rowpass_kernel(
-    const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
+template <int LPR, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
+    const int32_t *__restrict__ counts, int n_host, const int32_t *__restrict__ partner,
     const float *__restrict__ w, const float *__restrict__ y, const int32_t *__restrict__ r_to_c,
     const int32_t *__restrict__ chunk_id, const int32_t *__restrict__ chunk_start,
     const float *__restrict__ R, const float *__restrict__ C,
@@ -108,116 +133,154 @@ __global__ __launch_bounds__(kBlock) void rowpass_kernel(
     float *__restrict__ blockpart)
 {
     constexpr int GPB = kBlock / LPR;
-    constexpr int U = Unroll<NV>::value;
+    constexpr int U = PassUnroll<NV>::value;
+    constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
+    static_assert(U % 4 == 0, "fields are read back four pairs at a time");
+    // [group][field][pair]: 0 partner, 1 w2 = 2 w inv_batch, 2 y, 3 e slot in col order
+    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][4][kFieldStride];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
-    const int n_chunks = counts[0];
+    const int n_chunks = n_host >= 0 ? n_host : counts[0];
     const float g = scalars[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
+
+    // loss partials: [0] sum e diff (= 2 inv_batch sum w diff^2), [1] sum |r|^2+|c|^2, [2] sum b^2, [3] sum e
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
+
     for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
         const int32_t u = chunk_id[j];
         const int s = chunk_start[j];
         const int n = chunk_start[j + 1] - s;
-        int32_t my_partner[kSlots], my_epos[kSlots];
-        float my_w[kSlots], my_y[kSlots], my_e[kSlots];
 #pragma unroll
-        for (int sl = 0; sl < kSlots; ++sl) {
+        for (int sl = 0; sl < SL; ++sl) {
             const int t = lg + sl * LPR;
             const int k = s + (t < n ? t : 0);
-            my_partner[sl] = partner[k];
-            my_epos[sl] = r_to_c[k];
+            const int32_t pv = partner[k];
+            const int32_t ev = r_to_c[k];
             const float wv = w[k];
-            my_w[sl] = t < n ? wv : 0.f;
-            my_y[sl] = y[k];
-            my_e[sl] = 0.f;
+            const float yv = y[k];
+            if (t < kChunkMax) {
+                fld[grp][0][t] = (uint32_t)pv;
+                fld[grp][1][t] = __float_as_uint(t < n ? 2.0f * inv_batch * wv : 0.f);   // tail slots weigh 0
+                fld[grp][2][t] = __float_as_uint(yv);
+                fld[grp][3][t] = (uint32_t)ev;
+            }
         }
         f4 r[NV], acc[NV];
         load_row<LPR, NV>(r, R, u, d4, lg);
-        const float bru = br[u];
+        const float bg = br[u] + g;
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
-        float rr = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
-        float se = 0.f, cc_sum = 0.f;
+        float se = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
+        // fields written by this wave's own lanes: LDS ops of one wave complete in order
+
         for (int q0 = 0; q0 < n; q0 += U) {
             int32_t col[U];
-            float wq[U], yq[U];
+            float w2[U], yq[U];
 #pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int q = q0 + a < n ? q0 + a : 0;
-                col[a] = group_bcast<LPR>(my_partner, q);
-                const float wv = group_bcast<LPR>(my_w, q);
-                wq[a] = q0 + a < n ? wv : 0.f;
-                yq[a] = group_bcast<LPR>(my_y, q);
+            for (int a4 = 0; a4 < U; a4 += 4) {
+                const uint4 pc = *reinterpret_cast<const uint4 *>(&fld[grp][0][q0 + a4]);
+                const uint4 pw = *reinterpret_cast<const uint4 *>(&fld[grp][1][q0 + a4]);
+                const uint4 py = *reinterpret_cast<const uint4 *>(&fld[grp][2][q0 + a4]);
+                col[a4] = (int32_t)pc.x; col[a4 + 1] = (int32_t)pc.y; col[a4 + 2] = (int32_t)pc.z; col[a4 + 3] = (int32_t)pc.w;
+                w2[a4] = __uint_as_float(pw.x); w2[a4 + 1] = __uint_as_float(pw.y);
+                w2[a4 + 2] = __uint_as_float(pw.z); w2[a4 + 3] = __uint_as_float(pw.w);
+                yq[a4] = __uint_as_float(py.x); yq[a4 + 1] = __uint_as_float(py.y);
+                yq[a4 + 2] = __uint_as_float(py.z); yq[a4 + 3] = __uint_as_float(py.w);
             }
             f4 c[U][NV];
             float bcv[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
-                load_row<LPR, NV>(c[a], C, col[a], d4, lg);
-                bcv[a] = bc[col[a]];
+                load_row_fast<LPR, NV, FULL>(c[a], C, col[a], d4, lg);
+                bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(bc) + (uint32_t)col[a] * 4u);
             }
+            float dp[U], cc[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
-                const bool ok = q0 + a < n;
-                float dp = 0.f, cc = 0.f;
+                dp[a] = 0.f; cc[a] = 0.f;
 #pragma unroll
-                for (int k = 0; k < NV; ++k) { dp += dot4(r[k], c[a][k]); cc += dot4(c[a][k], c[a][k]); }
-                const float dot = group_sum<LPR>(dp);
-                const float diff = dot + bru + bcv[a] + g - yq[a];
-                const float e = 2.0f * wq[a] * diff * inv_batch;
+                for (int k = 0; k < NV; ++k) { dp[a] += dot4(r[k], c[a][k]); cc[a] += dot4(c[a][k], c[a][k]); }
+            }
+            // the U butterflies are independent: stage by stage so the DPP hazards overlap
+#pragma unroll
+            for (int a = 0; a < U; ++a) dp[a] = dpp_add<0xB1>(dp[a]);
+#pragma unroll
+            for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x4E>(dp[a]);
+#pragma unroll
+            for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x141>(dp[a]);
+            if (LPR >= 16) {
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x140>(dp[a]);
+            }
+            if (LPR >= 32) {
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 16, 64);
+            }
+            if (LPR >= 64) {
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 32, 64);
+            }
+            float e_mine = 0.f;
+#pragma unroll
+            for (int a = 0; a < U; ++a) {
+                const float valid = (q0 + a < n) ? 1.0f : 0.f;
+                const float diff = (dp[a] + bg) + (bcv[a] - yq[a]);
+                const float e = w2[a] * diff;                       // 0 on tail slots
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
                 se += e;
-                cc_sum += ok ? cc : 0.f;
-                const int q = q0 + a;
-                if (ok && lg == (q & (LPR - 1))) { if (q >= LPR) my_e[1] = e; else my_e[0] = e; }
-                if (lg == 0) {
-                    part[0] += wq[a] * diff * diff;
-                    part[2] += ok ? bcv[a] * bcv[a] : 0.f;
-                }
+                ed += e * diff;
+                cc_sum += valid * cc[a];
+                bsq += valid * bcv[a] * bcv[a];
+                e_mine = (lg == (a % LPR)) ? e : e_mine;            // lane a keeps pair q0+a's e (U <= LPR)
             }
+            if (lg < U && q0 + lg < n) e_col[fld[grp][3][q0 + lg]] = e_mine;   // col-sorted slot, for colpass
         }
-#pragma unroll
-        for (int sl = 0; sl < kSlots; ++sl)
-            if (lg + sl * LPR < n) e_col[my_epos[sl]] = my_e[sl];
         store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
+        float rr = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
         part[1] += cc_sum + (float)n * rr;
         if (lg == 0) {
             gb[j] = se;
-            part[2] += (float)n * bru * bru;
+            const float bru = bg - g;
+            part[0] += ed;
+            part[2] += bsq + (float)n * bru * bru;
             part[3] += se;
         }
     }
+    part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
     block_partials_store(part, blockpart);
 }
 
-template <int LPR, int NV>
-__global__ __launch_bounds__(kBlock) void colpass_kernel(
-    const int32_t *__restrict__ counts, const int32_t *__restrict__ partner,
+template <int LPR, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock) void colpass_lds_kernel(
+    const int32_t *__restrict__ counts, int n_host, const int32_t *__restrict__ partner,
     const int32_t *__restrict__ chunk_start,
     const float *__restrict__ R, const float *__restrict__ e_col, int d4,
     float *__restrict__ gp, float *__restrict__ gb)
 {
     constexpr int GPB = kBlock / LPR;
-    constexpr int U = Unroll<NV>::value;
+    constexpr int U = PassUnroll<NV>::value;
+    constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;
+    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][2][kFieldStride];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
-    const int n_chunks = counts[2];
+    const int n_chunks = n_host >= 0 ? n_host : counts[2];
     for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
         const int s = chunk_start[j];
         const int n = chunk_start[j + 1] - s;
-        int32_t my_partner[kSlots];
-        float my_e[kSlots];
 #pragma unroll
-        for (int sl = 0; sl < kSlots; ++sl) {
+        for (int sl = 0; sl < SL; ++sl) {
             const int t = lg + sl * LPR;
             const int k = s + (t < n ? t : 0);
-            my_partner[sl] = partner[k];
+            const int32_t pv = partner[k];
             const float ev = e_col[k];
-            my_e[sl] = t < n ? ev : 0.f;
+            if (t < kChunkMax) {
+                fld[grp][0][t] = (uint32_t)pv;
+                fld[grp][1][t] = __float_as_uint(t < n ? ev : 0.f);
+            }
         }
         f4 acc[NV];
 #pragma unroll
@@ -227,15 +290,16 @@ __global__ __launch_bounds__(kBlock) void colpass_kernel(
             int32_t rid[U];
             float eq[U];
 #pragma unroll
-            for (int a = 0; a < U; ++a) {
-                const int q = q0 + a < n ? q0 + a : 0;
-                rid[a] = group_bcast<LPR>(my_partner, q);
-                const float ev = group_bcast<LPR>(my_e, q);
-                eq[a] = q0 + a < n ? ev : 0.f;
+            for (int a4 = 0; a4 < U; a4 += 4) {
+                const uint4 pr = *reinterpret_cast<const uint4 *>(&fld[grp][0][q0 + a4]);
+                const uint4 pe = *reinterpret_cast<const uint4 *>(&fld[grp][1][q0 + a4]);
+                rid[a4] = (int32_t)pr.x; rid[a4 + 1] = (int32_t)pr.y; rid[a4 + 2] = (int32_t)pr.z; rid[a4 + 3] = (int32_t)pr.w;
+                eq[a4] = __uint_as_float(pe.x); eq[a4 + 1] = __uint_as_float(pe.y);
+                eq[a4 + 2] = __uint_as_float(pe.z); eq[a4 + 3] = __uint_as_float(pe.w);
             }
             f4 r[U][NV];
 #pragma unroll
-            for (int a = 0; a < U; ++a) load_row<LPR, NV>(r[a], R, rid[a], d4, lg);
+            for (int a = 0; a < U; ++a) load_row_fast<LPR, NV, FULL>(r[a], R, rid[a], d4, lg);
 #pragma unroll
             for (int a = 0; a < U; ++a) {
 #pragma unroll
@@ -273,7 +337,6 @@ template <int LPR, int NV>
 __device__ inline void sum_partials(const SideBufs &sb, int first, int last, int stride, int d4, int lg,
                                     f4 (&G)[NV], float &Gb)
 {
-#pragma unroll 4
     for (int sl = first; sl < last; sl += stride) {
         f4 p[NV];
         load_row<LPR, NV>(p, sb.gp, sl, d4, lg);
@@ -289,7 +352,8 @@ __device__ inline void sum_partials(const SideBufs &sb, int first, int last, int
 //                                                   with the table row so the latencies overlap
 //   fn.finish(is_row, id, G, Wv, Gb, bval, P, pb)   G = summed gradient incl. the activity-L2 term
 template <int LPR, int NV, class F>
-__device__ inline void for_each_id(const int32_t *__restrict__ counts, const SideBufs &rs, const SideBufs &cs,
+__device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host,
+                                   const SideBufs &rs, const SideBufs &cs,
                                    int d4, const StepConsts &k, F fn)
 {
     constexpr int GPB = kBlock / LPR;
@@ -299,7 +363,9 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
     __shared__ float redb[GPB];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
-    const int nu_r = counts[1], nu_c = counts[3];
+    GLOVE_STAMP(0);
+    const int nu_r = nu_r_host >= 0 ? nu_r_host : counts[1];
+    const int nu_c = nu_c_host >= 0 ? nu_c_host : counts[3];
     const int total = nu_r + nu_c;
     if (threadIdx.x == 0) heavy_n = 0;
     __syncthreads();
@@ -320,8 +386,10 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
                 continue;
             }
         }
+        GLOVE_DRAIN(); GLOVE_STAMP(1);      // uniq_slot arrived
         const int32_t id = sb.chunk_id[sl0];
         const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
+        GLOVE_DRAIN(); GLOVE_STAMP(2);      // id arrived
         f4 G[NV], Wv[NV], P[NV];
         load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);        // first partial: independent of id
         float Gb = sb.gb[sl0];
@@ -334,9 +402,12 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, const Sid
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
         Gb += k.kappa_b * cnt * bval;
+        GLOVE_DRAIN(); GLOVE_STAMP(3);      // rows arrived
         fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
+        GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
     }
     __syncthreads();
+    GLOVE_STAMP(5);
     const int nh = heavy_n < kHeavyCap ? heavy_n : kHeavyCap;
     for (int hq = 0; hq < nh; ++hq) {
         const int q = heavy_q[hq];
@@ -444,11 +515,11 @@ struct AdagradApply {
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
-    const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ scalars, const float *__restrict__ blockpart, int nblocks_rowpass,
     float *__restrict__ loss_out)
 {
-    for_each_id<LPR, NV>(counts, rs, cs, d4, k,
+    for_each_id<LPR, NV>(counts, nu_r_host, nu_c_host, rs, cs, d4, k,
                          AdagradApply<LPR, NV>{rs, cs, d4, (int)(threadIdx.x % LPR), k.lr, k.eps});
     // global bias (dense Adagrad) + loss scalars: first wave of block 0
     if (blockIdx.x == 0) {
@@ -465,6 +536,7 @@ __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
             if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
         }
     }
+    GLOVE_DRAIN(); GLOVE_STAMP(6);
 }
 
 // Adds this plan's summed gradients into the dense buffers (no two work items share an id
@@ -491,11 +563,11 @@ struct DenseGradAdd {
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void dense_grad_kernel(
-    const int32_t *__restrict__ counts, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ G_R, float *__restrict__ G_C, float *__restrict__ G_br, float *__restrict__ G_bc,
     float *__restrict__ tail, const float *__restrict__ blockpart, int nblocks_rowpass)
 {
-    for_each_id<LPR, NV>(counts, rs, cs, d4, k,
+    for_each_id<LPR, NV>(counts, nu_r_host, nu_c_host, rs, cs, d4, k,
                          DenseGradAdd<LPR, NV>{G_R, G_C, G_br, G_bc, d4, (int)(threadIdx.x % LPR)});
     if (blockIdx.x == 0) {
         float tot[kPartials];
@@ -587,6 +659,8 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static inline RowShape pass_shape(int d4) { return pick_pass_shape(d4); }
+
 static int check_common(const glove_plan *p, const glove_tables *t, const glove_hyper *h, const void *ws)
 {
     if (!p || !t || !h || !ws) return GLOVE_E_BADARG;
@@ -596,7 +670,9 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
                      !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
-    if (shape.lpr == 0 || p->chunk_cap <= 0 || p->chunk_cap > kSlots * shape.lpr) return GLOVE_E_BADARG;
+    if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
+    if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;   // 32-bit row offsets
+    if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     return 0;
 }
 
@@ -638,6 +714,9 @@ using namespace glove;
 extern "C" {
 
 int glove_abi_version(void) { return GLOVE_ABI_VERSION; }
+#ifdef GLOVE_STAMPS
+int glove_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#endif
 
 size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d)
 {
@@ -654,15 +733,18 @@ int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
-    const RowShape shape = pick_row_shape(d4);
+    const RowShape shape = pass_shape(d4);
     const int nb = rowpass_blocks(p, shape.lpr);
     hipStream_t st = (hipStream_t)stream;
-#define CALL(LPR, NV)                                                                                           \
-    hipLaunchKernelGGL((rowpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->r_partner,      \
-                       p->r_w, p->r_y, p->r_to_c, p->r_chunk_id, p->r_chunk_start, t->R, t->C, t->br, t->bc,  \
-                       t->scalars, t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart)
-    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+    const int32_t *hc = p->host_counts;
+#define ARGS p->counts, hc[0], p->r_partner, p->r_w, p->r_y, p->r_to_c, p->r_chunk_id, p->r_chunk_start, t->R, t->C, \
+             t->br, t->bc, t->scalars, t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart
+#define CALL(LPR, NV)                                                                                       \
+    if (LPR * NV == d4) hipLaunchKernelGGL((rowpass_lds_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else hipLaunchKernelGGL((rowpass_lds_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+        GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
+#undef ARGS
     return (int)hipGetLastError();
 }
 
@@ -673,14 +755,17 @@ int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
-    const RowShape shape = pick_row_shape(d4);
+    const RowShape shape = pass_shape(d4);
     const int nb = rowpass_blocks(p, shape.lpr);
     hipStream_t st = (hipStream_t)stream;
-#define CALL(LPR, NV)                                                                                      \
-    hipLaunchKernelGGL((colpass_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, p->c_partner, \
-                       p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c)
-    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+    const int32_t *hc = p->host_counts;
+#define ARGS p->counts, hc[2], p->c_partner, p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c
+#define CALL(LPR, NV)                                                                                  \
+    if (LPR * NV == d4) hipLaunchKernelGGL((colpass_lds_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else hipLaunchKernelGGL((colpass_lds_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+        GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
+#undef ARGS
     return (int)hipGetLastError();
 }
 
@@ -694,12 +779,13 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
     const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
-    const int nb_row = rowpass_blocks(p, shape.lpr);
+    const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     hipStream_t st = (hipStream_t)stream;
+    const int32_t *hc = p->host_counts;
 #define CALL(LPR, NV)                                                                                          \
-    hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, d4, \
+    hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, hc[1], hc[3], rs, cs, d4, \
                        k, t->scalars, w.blockpart, nb_row, loss_out)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
@@ -716,14 +802,15 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
     const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
-    const int nb_row = rowpass_blocks(p, shape.lpr);
+    const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     const size_t Vd = (size_t)t->V * t->d;
     float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V, *tail = G_bc + t->V;
     hipStream_t st = (hipStream_t)stream;
+    const int32_t *hc = p->host_counts;
 #define CALL(LPR, NV)                                                                                       \
-    hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, d4, \
+    hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, hc[1], hc[3], rs, cs, d4, \
                        k, G_R, G_C, G_br, G_bc, tail, w.blockpart, nb_row)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL

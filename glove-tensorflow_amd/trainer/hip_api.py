@@ -45,7 +45,7 @@ class GloveHyper(C.Structure):
 
 class GlovePlan(C.Structure):
     _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
-                ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp),
+                ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 4),
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp),
                 ("c_partner", _fp), ("c_perm", _fp),
@@ -216,6 +216,7 @@ class Plan:
         f32 = dict(dtype=torch.float32, device=dev)
         n = max(self.B, 1)
         self.counts = torch.zeros(4, **i32)
+        self.host_counts = [-1, -1, -1, -1]      # unknown until the build has been synchronised
         self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
@@ -228,6 +229,8 @@ class Plan:
             s = GlovePlan()
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
             s.counts = _ptr(self.counts)
+            for i in range(4):
+                s.host_counts[i] = self.host_counts[i]
             s.r_w, s.r_y = _ptr(self.r_w), _ptr(self.r_y)
             for n in self.INT_FIELDS:
                 setattr(s, n, _ptr(getattr(self, n)))
@@ -241,6 +244,7 @@ class Plan:
         out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
         out.counts = self.counts.clone()
+        out.host_counts = [nc_r, nu_r, nc_c, nu_c]
         out.r_partner, out.r_w, out.r_y, out.r_to_c = self.r_partner, self.r_w, self.r_y, self.r_to_c
         out.c_partner, out.c_perm = self.c_partner, self.c_perm
         out.r_chunk_id = self.r_chunk_id[:max(out.cap_chunks, 1)].clone()

@@ -75,6 +75,9 @@ typedef struct glove_plan {
     int32_t cap_uniq;           /* capacity of the *_uniq_slot arrays minus one */
     int32_t reserved;
     int32_t *counts;            /* int32[4]: chunks_row, uniq_row, chunks_col, uniq_col */
+    /* host copy of counts for plans whose build has completed (a resident plan of a static
+     * stream): saves the kernels one dependent load.  -1 = unknown, read `counts` on the device. */
+    int32_t host_counts[4];
     /* row side: position k = k-th pair in (row id, original order) order */
     int32_t *r_partner;         /* [B] col id of pair k */
     float   *r_w;               /* [B] glove_weight */
