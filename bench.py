@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="text8_d64", choices=["text8_d64", "text8_v50k_d300", "zipf_v400k_d300"])
     ap.add_argument("--batch-size", type=int, default=131072)
-    ap.add_argument("--chunk-cap", type=int, default=32)
+    ap.add_argument("--chunk-cap", type=int, default=0, help="0 = auto (hip_api.auto_chunk_cap)")
+    ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form (dense gradient buffer + all-reduce) also on one GPU")
     ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad"])
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
@@ -123,17 +124,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    dense = world > 1 or args.force_dense
+    if dense:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:      # --force-dense on a single GPU without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from trainer import synthetic
     from trainer.hip_api import DeviceTables, GloveHip, make_hyper
 
     hip = GloveHip(dev)
-    B, cap = args.batch_size, args.chunk_cap
+    B = args.batch_size
     wl = synthetic.make_workload(args.workload, seed=rank, device=dev, work_device=dev)
     V, d = wl["V"], wl["d"]
+    from trainer.hip_api import auto_chunk_cap
+    cap = args.chunk_cap or auto_chunk_cap(B, V)
     nnz = wl["row"].numel()
     nb = min(max(1, nnz // B), args.max_batches)
     if nnz < B:
@@ -159,12 +165,12 @@ def main():
     ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
                      else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     loss_out = torch.zeros(4, device=dev)
-    G = hip.dense_grad_buffer(tables) if world > 1 else None
+    G = hip.dense_grad_buffer(tables) if dense else None
 
     def step(i):
         bt = batches[i % nb]
         plan = hip.build_plan(*bt, V, chunk_cap=cap) if args.dynamic else plans[i % nb]
-        if world == 1:
+        if not dense:
             hip.step_adagrad(plan, tables, hyper, loss_out, ws)
         else:
             hip.rowpass(plan, tables, hyper, ws)
@@ -174,13 +180,13 @@ def main():
             hip.dense_adagrad(tables, hyper, G, loss_out)
 
     def barrier():
-        if world > 1:
+        if dense:
             dist.barrier()
         torch.cuda.synchronize()
 
     # One hipGraph holds a full sweep over the resident batches (nb steps); it is replayed
     # steps // nb times and the remainder runs eagerly, so exactly `steps` steps are timed.
-    use_graph = world == 1 and not args.dynamic and not args.no_graph
+    use_graph = not dense and not args.dynamic and not args.no_graph
     graph = None
     if use_graph:
         side = torch.cuda.Stream()
@@ -224,10 +230,12 @@ def main():
     kern = {}
     reps = max(nb, min(200, args.steps))
     calls = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws), "colpass": lambda p: hip.colpass(p, tables, hyper, ws)}
-    if world == 1:
+    if not dense:
         calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
     else:
         calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
+        calls["all_reduce"] = lambda p: dist.all_reduce(G)                 # RCCL over xGMI, broken out
+        calls["dense_adagrad"] = lambda p: hip.dense_adagrad(tables, hyper, G, loss_out)
     for name, fn in calls.items():
         for i in range(4):
             fn(plans[i % nb])
@@ -244,7 +252,7 @@ def main():
     alg = algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
 
-    traffic, traffic_src = measured_traffic(args.workload, B, cap) if world == 1 else (None, None)
+    traffic, traffic_src = measured_traffic(args.workload, B, cap) if not dense else (None, None)
 
     if rank == 0:
         out = {
@@ -256,7 +264,7 @@ def main():
                        "resident_batches": nb, "chunk_cap": cap,
                        "index": "rebuilt every step" if args.dynamic else "static, built at load",
                        "launch": "hipGraph replay" if graph is not None else "eager",
-                       "parallelism": "dp%d dense-grad all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": "dp%d dense-grad all-reduce" % world if dense else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one step = " + " + ".join(kern),
@@ -264,10 +272,10 @@ def main():
                          "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.force_dense:
             out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dense:
         dist.destroy_process_group()
 
 

@@ -69,32 +69,37 @@ __device__ inline void store_row(float *table, size_t row_index, int d4, int lg,
 }
 
 // ---- optimizer arithmetic (Keras-legacy forms) -------------------------
+// x / (sqrt(a) + eps) uses the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE
+// expansions: ~3 ulp on the update term, far inside the 1e-5 parity tolerance, and a third of the
+// instructions and registers of the apply kernels.
+__device__ inline float inv_sqrt_eps(float a, float eps) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(a) + eps); }
+
 __device__ inline void adagrad_elem(float &Wv, float &A, float g, float lr, float eps)
 {
     A += g * g;
-    Wv -= lr * g / (sqrtf(A) + eps);
+    Wv -= lr * g * inv_sqrt_eps(A, eps);
 }
-
-__device__ inline f4 sqrt4(const f4 v) { return f4{sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w)}; }
 
 __device__ inline void adagrad_vec(f4 &Wv, f4 &A, const f4 g, float lr, float eps)
 {
     A += g * g;
-    Wv -= (lr * g) / (sqrt4(A) + eps);
+    const f4 inv = f4{inv_sqrt_eps(A.x, eps), inv_sqrt_eps(A.y, eps), inv_sqrt_eps(A.z, eps), inv_sqrt_eps(A.w, eps)};
+    Wv -= (lr * g) * inv;
 }
 
 __device__ inline void adam_elem(float &Wv, float &M, float &Vv, float g, float lr_t, float b1, float b2, float eps)
 {
     M = b1 * M + (1.0f - b1) * g;
     Vv = b2 * Vv + (1.0f - b2) * g * g;
-    Wv -= lr_t * M / (sqrtf(Vv) + eps);
+    Wv -= lr_t * M * inv_sqrt_eps(Vv, eps);
 }
 
 __device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, float b1, float b2, float eps)
 {
     M = b1 * M + (1.0f - b1) * g;
     Vv = b2 * Vv + (1.0f - b2) * g * g;
-    Wv -= (lr_t * M) / (sqrt4(Vv) + eps);
+    const f4 inv = f4{inv_sqrt_eps(Vv.x, eps), inv_sqrt_eps(Vv.y, eps), inv_sqrt_eps(Vv.z, eps), inv_sqrt_eps(Vv.w, eps)};
+    Wv -= (lr_t * M) * inv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void colpass_lds_kernel(
 // queue and then summed by the whole workgroup, GPB groups striding over the partial rows.
 // ------------------------------------------------------------------------------------------
 struct SideBufs {
-    const int32_t *chunk_id, *chunk_start, *uniq_slot;
+    const int32_t *chunk_id, *chunk_start, *uniq_slot, *uniq_rec;
     const float *gp, *gb;
     float *W, *S1, *bias, *S1b;
 };
@@ -376,8 +381,9 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
-        const int sl0 = sb.uniq_slot[qq], sl1 = sb.uniq_slot[qq + 1];
-        if (sl1 - sl0 > kHeavyChunks) {
+        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];   // {id, first chunk, chunks, pairs}
+        const int sl0 = rec.y, sl1 = rec.y + rec.z;
+        if (rec.z > kHeavyChunks) {
             int slot = 0;
             if (lg == 0) slot = atomicAdd(&heavy_n, 1);
             slot = __shfl(slot, 0, LPR);
@@ -386,10 +392,10 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_
                 continue;
             }
         }
-        GLOVE_DRAIN(); GLOVE_STAMP(1);      // uniq_slot arrived
-        const int32_t id = sb.chunk_id[sl0];
-        const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
-        GLOVE_DRAIN(); GLOVE_STAMP(2);      // id arrived
+        GLOVE_DRAIN(); GLOVE_STAMP(1);      // record arrived
+        const int32_t id = rec.x;
+        const float cnt = (float)rec.w;
+        GLOVE_STAMP(2);
         f4 G[NV], Wv[NV], P[NV];
         load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);        // first partial: independent of id
         float Gb = sb.gb[sl0];
@@ -414,8 +420,9 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
-        const int sl0 = sb.uniq_slot[qq], sl1 = sb.uniq_slot[qq + 1];
-        const int32_t id = sb.chunk_id[sl0];
+        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];
+        const int sl0 = rec.y, sl1 = rec.y + rec.z;
+        const int32_t id = rec.x;
         f4 G[NV], Wv[NV], P[NV];
         float Gb = 0.f, bval = 0.f, pb = 0.f;
 #pragma unroll
@@ -436,7 +443,7 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_
                 for (int kk = 0; kk < NV; ++kk) G[kk] += red[g2][lg + kk * LPR];
                 Gb += redb[g2];
             }
-            const float cnt = (float)(sb.chunk_start[sl1] - sb.chunk_start[sl0]);
+            const float cnt = (float)rec.w;
             const float kc = k.kappa * cnt;
 #pragma unroll
             for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
@@ -530,9 +537,10 @@ __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
             float loss, L, reg;
             loss_from_partials(tot, k, g, loss, L, reg);
             const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
-            const float Ag = scalars[1] + dg * dg;
+            float gn = g, Ag = scalars[1];
+            adagrad_elem(gn, Ag, dg, k.lr, k.eps);
             scalars[1] = Ag;
-            scalars[0] = g - k.lr * dg / (sqrtf(Ag) + k.eps);
+            scalars[0] = gn;
             if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
         }
     }
@@ -667,7 +675,7 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
-                     !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+                     !p->r_uniq_rec || !p->c_uniq_rec || !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
@@ -698,6 +706,7 @@ static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tabl
     s.chunk_id = row ? p->r_chunk_id : p->c_chunk_id;
     s.chunk_start = row ? p->r_chunk_start : p->c_chunk_start;
     s.uniq_slot = row ? p->r_uniq_slot : p->c_uniq_slot;
+    s.uniq_rec = row ? p->r_uniq_rec : p->c_uniq_rec;
     s.gp = row ? w.gp_r : w.gp_c;
     s.gb = row ? w.gb_r : w.gb_c;
     s.W = row ? t->R : t->C;

@@ -94,7 +94,7 @@ def build_parser():
                              "behaviour of the pinned TF 2.11, 1 = TF 2.1" + d)
     parser.add_argument("--seed", type=int, default=None, help="seed of the init and of the batch shuffle "
                         "(the reference is unseeded)" + d)
-    parser.add_argument("--chunk-cap", type=int, default=32, help="max nonzeros per dedup-index chunk" + d)
+    parser.add_argument("--chunk-cap", type=int, default=0, help="max nonzeros per dedup-index chunk, 0 = choose from batch size / vocab size" + d)
     parser.add_argument("--log-every", type=int, default=100, help="steps between loss log lines" + d)
     parser.add_argument("--save-checkpoints-secs", type=float, default=300.0, help="checkpoint cadence" + d)
     parser.add_argument("--keep-checkpoint-max", type=int, default=5, help="checkpoints kept" + d)

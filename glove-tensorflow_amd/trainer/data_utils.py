@@ -108,7 +108,7 @@ class NonzeroStream:
     """
 
     def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
-                 chunk_cap=32):
+                 chunk_cap=0):
         self.B, self.V, self.backend, self.device = int(batch_size), int(V), backend, torch.device(device)
         self.chunk_cap = chunk_cap
         self.gen = torch.Generator(device="cpu")

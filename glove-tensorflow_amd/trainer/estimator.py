@@ -75,7 +75,7 @@ class Estimator:
                                        cache_dir=self.params["job_dir"] if self.rank == 0 else None)
             self._stream = NonzeroStream(coo, a["batch_size"], self.vocab_size, self.backend, self.device,
                                          rank=self.rank, world=self.world, seed=self.params.get("seed"),
-                                         chunk_cap=self.params.get("chunk_cap", 32))
+                                         chunk_cap=self.params.get("chunk_cap", 0))
         return self._stream
 
     def _log(self, name, record):

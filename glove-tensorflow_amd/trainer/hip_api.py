@@ -18,6 +18,14 @@ LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 GLOVE_ABI_VERSION = 1
 DEFAULT_CHUNK_CAP = 32
 
+
+def auto_chunk_cap(B: int, V: int) -> int:
+    """Chunk length used when the caller does not choose one.  Short chunks shorten the dependent
+    chain of the gather passes (fewer partner-row round trips per chunk) and win while a batch holds
+    few pairs per id; long chunks mean fewer partial rows and win for dense batches (measured with
+    tools/ab_kernels.py: B = 131072, V = 10000: 16 -> 27.1 us/step vs 32 -> 29.3; B = 1048576: 91.8 vs 68.1)."""
+    return 16 if B <= 20 * V else 32
+
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
     "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_step_workspace_bytes",
@@ -47,9 +55,9 @@ class GlovePlan(C.Structure):
     _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
                 ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 4),
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
-                ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp),
+                ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp),
-                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp)]
+                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp)]
 
 
 class GloveHipError(RuntimeError):
@@ -203,8 +211,8 @@ class DeviceTables:
 class Plan:
     """Device-resident dedup index of one batch (see glove_plan in include/glove_hip.h)."""
 
-    INT_FIELDS = ("r_partner", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot",
-                  "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot")
+    INT_FIELDS = ("r_partner", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot", "r_uniq_rec",
+                  "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
                  cap_uniq: int | None = None):
@@ -222,6 +230,7 @@ class Plan:
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
         self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
         self.r_uniq_slot, self.c_uniq_slot = (torch.zeros(self.cap_uniq + 1, **i32) for _ in range(2))
+        self.r_uniq_rec, self.c_uniq_rec = (torch.zeros(4 * max(self.cap_uniq, 1), **i32) for _ in range(2))
         self._struct = None
 
     def struct(self) -> GlovePlan:
@@ -253,6 +262,8 @@ class Plan:
         out.c_chunk_start = self.c_chunk_start[:out.cap_chunks + 1].clone()
         out.r_uniq_slot = self.r_uniq_slot[:out.cap_uniq + 1].clone()
         out.c_uniq_slot = self.c_uniq_slot[:out.cap_uniq + 1].clone()
+        out.r_uniq_rec = self.r_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
+        out.c_uniq_rec = self.c_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out._struct = None
         return out
 
@@ -290,9 +301,11 @@ class GloveHip:
         return self._ws("_step_ws", self.lib.glove_step_workspace_bytes(plan.B, plan.cap_chunks, d))
 
     # ---- index build
-    def build_plan(self, row, col, w, y, V: int, chunk_cap: int = DEFAULT_CHUNK_CAP, compact=False) -> Plan:
+    def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False) -> Plan:
         _require_cuda(row, col, w, y)
         B = int(row.numel())
+        if not chunk_cap:
+            chunk_cap = auto_chunk_cap(B, V)
         plan = Plan(B, V, chunk_cap, row.device)
         ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),

@@ -87,12 +87,15 @@ typedef struct glove_plan {
     int32_t *r_chunk_id;        /* [cap_chunks]   row id of the chunk */
     int32_t *r_chunk_start;     /* [cap_chunks+1] first pair of the chunk; [chunks] = B */
     int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
+    int32_t *r_uniq_rec;        /* [cap_uniq][4]  {id, first chunk, chunks, pairs} of the q-th distinct
+                                 * row id: everything the apply kernels need in one 16-B load */
     /* col side: position k = k-th row-sorted pair in (col id, row-sorted position) order */
     int32_t *c_partner;         /* [B] row id */
     int32_t *c_perm;            /* [B] row-sorted position of the pair */
     int32_t *c_chunk_id;
     int32_t *c_chunk_start;
     int32_t *c_uniq_slot;
+    int32_t *c_uniq_rec;
 } glove_plan;
 
 int glove_abi_version(void);

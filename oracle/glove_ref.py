@@ -260,18 +260,20 @@ def build_plan(row, col, chunk_cap):
                 chunk_start.append(cs)
         chunk_start.append(B)
         uniq_slot.append(len(chunk_id))
+        rec = [[chunk_id[a], a, b - a, chunk_start[b] - chunk_start[a]] for a, b in zip(uniq_slot[:-1], uniq_slot[1:])]
         return (np.asarray(chunk_id, np.int32), np.asarray(chunk_start, np.int32),
-                np.asarray(uniq_slot, np.int32))
+                np.asarray(uniq_slot, np.int32), np.asarray(rec, np.int32).reshape(-1, 4))
 
     perm_r = np.argsort(row, kind="stable")
     s_row, s_col = row[perm_r], col[perm_r]
-    r_chunk_id, r_chunk_start, r_uniq_slot = side(s_row)
+    r_chunk_id, r_chunk_start, r_uniq_slot, r_uniq_rec = side(s_row)
     perm_c = np.argsort(s_col, kind="stable")
-    c_chunk_id, c_chunk_start, c_uniq_slot = side(s_col[perm_c])
+    c_chunk_id, c_chunk_start, c_uniq_slot, c_uniq_rec = side(s_col[perm_c])
     r_to_c = np.empty(B, np.int64)
     r_to_c[perm_c] = np.arange(B)
     return dict(perm_r=perm_r.astype(np.int32), r_partner=s_col.astype(np.int32), r_to_c=r_to_c.astype(np.int32),
                 r_chunk_id=r_chunk_id, r_chunk_start=r_chunk_start, r_uniq_slot=r_uniq_slot,
+                r_uniq_rec=r_uniq_rec, c_uniq_rec=c_uniq_rec,
                 c_perm=perm_c.astype(np.int32), c_partner=s_row[perm_c].astype(np.int32),
                 c_chunk_id=c_chunk_id, c_chunk_start=c_chunk_start, c_uniq_slot=c_uniq_slot,
                 counts=np.asarray([len(r_chunk_id), len(r_uniq_slot) - 1,

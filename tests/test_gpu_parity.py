@@ -44,6 +44,8 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(plan.c_chunk_id.cpu().numpy()[:nc_c], want["c_chunk_id"])
     np.testing.assert_array_equal(plan.c_chunk_start.cpu().numpy()[:nc_c + 1], want["c_chunk_start"])
     np.testing.assert_array_equal(plan.c_uniq_slot.cpu().numpy()[:nu_c + 1], want["c_uniq_slot"])
+    np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
+    np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
     # compacted copy describes the same index
     cp = plan.compact()
     assert cp.cap_chunks == max(nc_r, nc_c) and cp.cap_uniq == max(nu_r, nu_c)

@@ -85,3 +85,34 @@ def test_loss_curve_and_neighbours_match_cpu_restatement(hip, optimizer, lr):
     _, want = ref.cosine_topk(t.R, probes, 20)
     overlap = [len(set(a) & set(b)) / 20 for a, b in zip(idx.cpu().numpy().tolist(), want.tolist())]
     assert min(overlap) >= 0.9, overlap
+
+
+def test_data_parallel_form_on_one_gpu_matches_sparse_step(hip):
+    """The N > 1 code path (dense gradient buffer -> nccl all-reduce -> dense apply) with world size 1:
+    RCCL is really called, and the result is bit-identical to the single-GPU sparse step."""
+    import os
+    import torch.distributed as dist
+    from helpers import make_batch, tables_from_oracle, to_dev
+    from trainer.hip_api import DeviceTables
+    from trainer.stepper import HipBackend, Stepper
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        B, V, d = 4096, 300, 64
+        backend = HipBackend("cuda:0")
+        t = ref.Tables(V, d, "Adagrad", dtype=np.float32, seed=2).astype(np.float64)
+        a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+        kw = dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05)
+        sparse = Stepper(backend, a, kw, B)
+        dp = Stepper(backend, b, kw, B, world=1, dist=dist)
+        dp.dense, dp.world, dp.G = True, 2, backend.dense_grad_buffer(b)      # force the collective path
+        dp.hyper = backend.make_hyper(batch_size=B, **kw)
+        for s in range(5):
+            plan = backend.build_plan(*to_dev(*make_batch(s, B, V)), V, 0)
+            sparse.step(plan)
+            dp.step(plan)
+        for n in ("R", "C", "br", "bc"):
+            assert torch.equal(getattr(a, n), getattr(b, n)), n
+        assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step == 5
+    finally:
+        dist.destroy_process_group()
