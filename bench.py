@@ -156,6 +156,7 @@ def main():
     torch.cuda.synchronize()
     plan_build_ms = (time.perf_counter() - t0) * 1e3 / nb
     counts = [p.counts.tolist() for p in plans]
+    n_heavy = sum(c[4] for c in counts) / nb
     u_row = sum(c[1] for c in counts) / nb
     u_col = sum(c[3] for c in counts) / nb
     chunks = sum(c[0] + c[2] for c in counts) / nb
@@ -269,7 +270,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one step = " + " + ".join(kern),
                          "algorithmic_bytes_per_step": alg, "kernel_us": kern,
-                         "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
+                         "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1 and not args.force_dense:

@@ -85,14 +85,20 @@ __global__ void emit_side(const int32_t *__restrict__ keys, const uint64_t *__re
 }
 
 // {id, first chunk, chunks, pairs} per distinct id, from the arrays emit_side wrote
+// also appends the ids with more than heavy_chunks chunks to the plan's heavy list (any order)
 __global__ void emit_uniq_rec(const int32_t *__restrict__ counts, const int32_t *__restrict__ chunk_id,
                               const int32_t *__restrict__ chunk_start, const int32_t *__restrict__ uniq_slot,
-                              int32_t *__restrict__ rec)
+                              int32_t *__restrict__ rec, int side, int heavy_chunks, int cap_heavy,
+                              int32_t *__restrict__ heavy, int32_t *__restrict__ n_heavy)
 {
     const int nu = counts[1];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nu; q += gridDim.x * blockDim.x) {
         const int a = uniq_slot[q], b = uniq_slot[q + 1];
         reinterpret_cast<int4 *>(rec)[q] = make_int4(chunk_id[a], a, b - a, chunk_start[b] - chunk_start[a]);
+        if (b - a > heavy_chunks) {
+            const int slot = atomicAdd(n_heavy, 1);
+            if (slot < cap_heavy) heavy[slot] = (side << 30) | q;
+        }
     }
 }
 
@@ -137,7 +143,7 @@ static int ceil_log2(int32_t v)
 
 static int build_side(const int32_t *keys_sorted, int64_t B, int32_t chunk_cap, const PlanWs &w, int32_t *chunk_id,
                       int32_t *chunk_start, int32_t *uniq_slot, int32_t *uniq_rec, int32_t cap_uniq, int32_t *counts,
-                      hipStream_t st)
+                      int side, const glove_plan *plan, hipStream_t st)
 {
     const int nb = blocks_for(B, kBlock);
     hipLaunchKernelGGL(mark_runs, dim3(nb), dim3(kBlock), 0, st, keys_sorted, B, w.run_start);
@@ -152,7 +158,8 @@ static int build_side(const int32_t *keys_sorted, int64_t B, int32_t chunk_cap, 
     hipLaunchKernelGGL(emit_side, dim3(nb), dim3(kBlock), 0, st, keys_sorted, w.flags, w.scanned, B, chunk_id,
                        chunk_start, uniq_slot, counts);
     hipLaunchKernelGGL(emit_uniq_rec, dim3(blocks_for(cap_uniq, kBlock)), dim3(kBlock), 0, st, counts, chunk_id,
-                       chunk_start, uniq_slot, uniq_rec);
+                       chunk_start, uniq_slot, uniq_rec, side, plan->heavy_chunks, plan->cap_heavy, plan->heavy,
+                       plan->counts + 4);
     return (int)hipGetLastError();
 }
 
@@ -175,13 +182,17 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (!plan || !ws || B < 0 || V <= 0 || plan->chunk_cap <= 0 || plan->B != B || !plan->counts) return GLOVE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
-        HIP_TRY(hipMemsetAsync(plan->counts, 0, 4 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
         return 0;
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
         !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->r_to_c || !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
         return GLOVE_E_BADARG;
+    if (!plan->heavy || plan->heavy_chunks < 1 ||
+        plan->cap_heavy < 2 * B / ((int64_t)plan->heavy_chunks * plan->chunk_cap) + 2)
+        return GLOVE_E_WORKSPACE;
+    HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
     // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     const PlanWs pw = carve_plan_ws(ws, B);
@@ -199,7 +210,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, col, w, y, B, plan->r_partner,
                        plan->r_w, plan->r_y);
     if (int rc = build_side(pw.row_sorted, B, plan->chunk_cap, pw, plan->r_chunk_id, plan->r_chunk_start,
-                            plan->r_uniq_slot, plan->r_uniq_rec, plan->cap_uniq, plan->counts + 0, st))
+                            plan->r_uniq_slot, plan->r_uniq_rec, plan->cap_uniq, plan->counts + 0, 0, plan, st))
         return rc;
 
     // ---- col side: stable sort of the row-sorted pairs by col id
@@ -211,7 +222,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, B, plan->c_partner,
                        plan->r_to_c);
     if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
-                            plan->c_uniq_slot, plan->c_uniq_rec, plan->cap_uniq, plan->counts + 2, st))
+                            plan->c_uniq_slot, plan->c_uniq_rec, plan->cap_uniq, plan->counts + 2, 1, plan, st))
         return rc;
     return (int)hipGetLastError();
 }

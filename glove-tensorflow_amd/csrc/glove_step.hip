@@ -319,18 +319,25 @@ __global__ __launch_bounds__(kBlock) void colpass_lds_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Summed gradient of one distinct id: chunk partials in a fixed order + activity-L2 term.
-// Ids with at most kHeavyChunks chunks are summed by one group of LPR lanes; heavier ids
-// (Zipf head: "the", "<UNK>" own thousands of pairs of a large batch) are parked in an LDS
-// queue and then summed by the whole workgroup, GPB groups striding over the partial rows.
+// Light ids (at most plan.heavy_chunks chunks: almost all of them) are summed by one group of LPR
+// lanes.  The ids of the Zipf head ("the", "<UNK>" own thousands of pairs of a large batch) are
+// listed in plan.heavy; each gets a whole workgroup (the first `heavy_blocks` blocks of the grid, so
+// they start ahead of the light work and run beside it): GPB groups stride over the partial rows,
+// then group 0 adds the GPB sums in order.
 // ------------------------------------------------------------------------------------------
 struct SideBufs {
-    const int32_t *chunk_id, *chunk_start, *uniq_slot, *uniq_rec;
+    const int32_t *uniq_rec;
     const float *gp, *gb;
     float *W, *S1, *bias, *S1b;
 };
 
-constexpr int kHeavyChunks = 8;
-constexpr int kHeavyCap = 128;
+struct IdWork {
+    const int32_t *counts;      // device counts[8]
+    int nu_r_host, nu_c_host, n_heavy_host;   // host copies, -1 = read the device counts
+    const int32_t *heavy;       // (side << 30) | q
+    int heavy_blocks;           // leading blocks of the grid reserved for heavy ids
+    int heavy_chunks;           // threshold
+};
 
 struct StepConsts {
     float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
@@ -338,89 +345,57 @@ struct StepConsts {
     float l2, m, inv_batch, inv_d;
 };
 
+// G += partial rows first, first+stride, ... (< last), PB loads in flight at a time, added in order
 template <int LPR, int NV>
 __device__ inline void sum_partials(const SideBufs &sb, int first, int last, int stride, int d4, int lg,
                                     f4 (&G)[NV], float &Gb)
 {
-    for (int sl = first; sl < last; sl += stride) {
-        f4 p[NV];
-        load_row<LPR, NV>(p, sb.gp, sl, d4, lg);
+    constexpr int PB = NV == 1 ? 4 : 2;
+    for (int sl = first; sl < last; sl += stride * PB) {
+        f4 p[PB][NV];
+        float pbias[PB];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) G[k] += p[k];
-        Gb += sb.gb[sl];
+        for (int a = 0; a < PB; ++a) {
+            const int x = sl + a * stride;
+            const int xs = x < last ? x : first;
+            load_row<LPR, NV>(p[a], sb.gp, xs, d4, lg);
+            pbias[a] = sb.gb[xs];
+        }
+#pragma unroll
+        for (int a = 0; a < PB; ++a) {
+            const float on = (sl + a * stride < last) ? 1.0f : 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) G[k] += on * p[a][k];
+            Gb += on * pbias[a];
+        }
     }
 }
 
-// Visits every distinct id of both sides once, on the LPR lanes of one group.  `fn` supplies
+// Visits every distinct id of both sides once.  `fn` supplies
 //   fn.prefetch(is_row, id, P, pb)                  its own row + bias slot (Adagrad accumulator,
 //                                                   or the dense gradient row), requested together
 //                                                   with the table row so the latencies overlap
 //   fn.finish(is_row, id, G, Wv, Gb, bval, P, pb)   G = summed gradient incl. the activity-L2 term
+// Returns true in the workgroup that should also do the once-per-step scalar work.
 template <int LPR, int NV, class F>
-__device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host,
-                                   const SideBufs &rs, const SideBufs &cs,
+__device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const SideBufs &cs,
                                    int d4, const StepConsts &k, F fn)
 {
     constexpr int GPB = kBlock / LPR;
-    __shared__ int heavy_q[kHeavyCap];
-    __shared__ int heavy_n;
     __shared__ f4 red[GPB][LPR * NV];
     __shared__ float redb[GPB];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     GLOVE_STAMP(0);
-    const int nu_r = nu_r_host >= 0 ? nu_r_host : counts[1];
-    const int nu_c = nu_c_host >= 0 ? nu_c_host : counts[3];
-    const int total = nu_r + nu_c;
-    if (threadIdx.x == 0) heavy_n = 0;
-    __syncthreads();
 
-    // ids are dealt round-robin over the grid: the heavy ones are the low (frequent) ids and
-    // would otherwise all land in the first few workgroups
-    for (int q = blockIdx.x + grp * gridDim.x; q < total; q += gridDim.x * GPB) {
-        const bool is_row = q < nu_r;
+    if ((int)blockIdx.x < wk.heavy_blocks) {
+        // ---- one heavy id for the whole workgroup
+        const int n_heavy = wk.n_heavy_host >= 0 ? wk.n_heavy_host : wk.counts[4];
+        if ((int)blockIdx.x >= n_heavy) return false;
+        const int code = wk.heavy[blockIdx.x];
+        const bool is_row = (code >> 30) == 0;
         const SideBufs &sb = is_row ? rs : cs;
-        const int qq = is_row ? q : q - nu_r;
-        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];   // {id, first chunk, chunks, pairs}
-        const int sl0 = rec.y, sl1 = rec.y + rec.z;
-        if (rec.z > kHeavyChunks) {
-            int slot = 0;
-            if (lg == 0) slot = atomicAdd(&heavy_n, 1);
-            slot = __shfl(slot, 0, LPR);
-            if (slot < kHeavyCap) {
-                if (lg == 0) heavy_q[slot] = q;
-                continue;
-            }
-        }
-        GLOVE_DRAIN(); GLOVE_STAMP(1);      // record arrived
-        const int32_t id = rec.x;
-        const float cnt = (float)rec.w;
-        GLOVE_STAMP(2);
-        f4 G[NV], Wv[NV], P[NV];
-        load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);        // first partial: independent of id
-        float Gb = sb.gb[sl0];
-        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
-        const float bval = sb.bias[id];
-        float pb;
-        fn.prefetch(is_row, id, P, pb);
-        sum_partials<LPR, NV>(sb, sl0 + 1, sl1, 1, d4, lg, G, Gb);
-        const float kc = k.kappa * cnt;
-#pragma unroll
-        for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
-        Gb += k.kappa_b * cnt * bval;
-        GLOVE_DRAIN(); GLOVE_STAMP(3);      // rows arrived
-        fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
-        GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
-    }
-    __syncthreads();
-    GLOVE_STAMP(5);
-    const int nh = heavy_n < kHeavyCap ? heavy_n : kHeavyCap;
-    for (int hq = 0; hq < nh; ++hq) {
-        const int q = heavy_q[hq];
-        const bool is_row = q < nu_r;
-        const SideBufs &sb = is_row ? rs : cs;
-        const int qq = is_row ? q : q - nu_r;
-        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];
+        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[code & 0x3fffffff];
         const int sl0 = rec.y, sl1 = rec.y + rec.z;
         const int32_t id = rec.x;
         f4 G[NV], Wv[NV], P[NV];
@@ -450,8 +425,42 @@ __device__ inline void for_each_id(const int32_t *__restrict__ counts, int nu_r_
             Gb += k.kappa_b * cnt * bval;
             fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
         }
-        __syncthreads();
+        return false;
     }
+
+    // ---- light ids: one group each, dealt round-robin over the light blocks
+    const int nu_r = wk.nu_r_host >= 0 ? wk.nu_r_host : wk.counts[1];
+    const int nu_c = wk.nu_c_host >= 0 ? wk.nu_c_host : wk.counts[3];
+    const int total = nu_r + nu_c;
+    const int lb = blockIdx.x - wk.heavy_blocks, nlb = gridDim.x - wk.heavy_blocks;
+    for (int q = lb + grp * nlb; q < total; q += nlb * GPB) {
+        const bool is_row = q < nu_r;
+        const SideBufs &sb = is_row ? rs : cs;
+        const int qq = is_row ? q : q - nu_r;
+        const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];   // {id, first chunk, chunks, pairs}
+        if (rec.z > wk.heavy_chunks) continue;                               // a heavy block has it
+        GLOVE_DRAIN(); GLOVE_STAMP(1);      // record arrived
+        const int sl0 = rec.y, sl1 = rec.y + rec.z;
+        const int32_t id = rec.x;
+        const float cnt = (float)rec.w;
+        f4 G[NV], Wv[NV], P[NV];
+        load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);
+        float Gb = sb.gb[sl0];
+        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
+        const float bval = sb.bias[id];
+        float pb;
+        fn.prefetch(is_row, id, P, pb);
+        sum_partials<LPR, NV>(sb, sl0 + 1, sl1, 1, d4, lg, G, Gb);
+        const float kc = k.kappa * cnt;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
+        Gb += k.kappa_b * cnt * bval;
+        GLOVE_DRAIN(); GLOVE_STAMP(3);      // rows arrived
+        fn.finish(is_row, id, G, Wv, Gb, bval, P, pb);
+        GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
+    }
+    GLOVE_STAMP(5);
+    return blockIdx.x == gridDim.x - 1;
 }
 
 // Deterministic sum of the rowpass block partials by the whole workgroup (thread t takes blocks
@@ -522,14 +531,14 @@ struct AdagradApply {
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void apply_adagrad_kernel(
-    const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    IdWork wk, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ scalars, const float *__restrict__ blockpart, int nblocks_rowpass,
     float *__restrict__ loss_out)
 {
-    for_each_id<LPR, NV>(counts, nu_r_host, nu_c_host, rs, cs, d4, k,
-                         AdagradApply<LPR, NV>{rs, cs, d4, (int)(threadIdx.x % LPR), k.lr, k.eps});
-    // global bias (dense Adagrad) + loss scalars: first wave of block 0
-    if (blockIdx.x == 0) {
+    const bool scalar_duty = for_each_id<LPR, NV>(wk, rs, cs, d4, k,
+                                                  AdagradApply<LPR, NV>{rs, cs, d4, (int)(threadIdx.x % LPR), k.lr, k.eps});
+    // global bias (dense Adagrad) + loss scalars: one (light) workgroup
+    if (scalar_duty) {
         float tot[kPartials];
         sum_blockpart(blockpart, nblocks_rowpass, tot);
         if (threadIdx.x == 0) {
@@ -571,13 +580,13 @@ struct DenseGradAdd {
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void dense_grad_kernel(
-    const int32_t *__restrict__ counts, int nu_r_host, int nu_c_host, SideBufs rs, SideBufs cs, int d4, StepConsts k,
+    IdWork wk, SideBufs rs, SideBufs cs, int d4, StepConsts k,
     float *__restrict__ G_R, float *__restrict__ G_C, float *__restrict__ G_br, float *__restrict__ G_bc,
     float *__restrict__ tail, const float *__restrict__ blockpart, int nblocks_rowpass)
 {
-    for_each_id<LPR, NV>(counts, nu_r_host, nu_c_host, rs, cs, d4, k,
-                         DenseGradAdd<LPR, NV>{G_R, G_C, G_br, G_bc, d4, (int)(threadIdx.x % LPR)});
-    if (blockIdx.x == 0) {
+    const bool scalar_duty = for_each_id<LPR, NV>(wk, rs, cs, d4, k,
+                                                  DenseGradAdd<LPR, NV>{G_R, G_C, G_br, G_bc, d4, (int)(threadIdx.x % LPR)});
+    if (scalar_duty) {
         float tot[kPartials];
         sum_blockpart(blockpart, nblocks_rowpass, tot);
         if (threadIdx.x == 0) {
@@ -599,8 +608,10 @@ __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
     DenseSegs segs, StepConsts k, float *__restrict__ scalars, float *__restrict__ tail,
     float *__restrict__ loss_out)
 {
+    // segments 0,1 = [V,d] tables (float4 body); 2,3 = bias vectors, whose G pointers are only 16-B
+    // aligned when V % 4 == 0 and which are tiny: swept scalar by the same launch
     const DenseSeg sg = segs.s[blockIdx.y];
-    const int64_t n4 = sg.n / 4;
+    const int64_t n4 = blockIdx.y < 2 ? sg.n / 4 : 0;
     f4 *W4 = reinterpret_cast<f4 *>(sg.W), *A4 = reinterpret_cast<f4 *>(sg.S1), *G4 = reinterpret_cast<f4 *>(sg.G);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
         const f4 gv = G4[i];
@@ -609,11 +620,9 @@ __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
         adagrad_vec(wv, a, gv, k.lr, k.eps);
         A4[i] = a; W4[i] = wv; G4[i] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    if (blockIdx.x == 0) {
-        for (int64_t i = n4 * 4 + threadIdx.x; i < sg.n; i += kBlock) {
-            const float gv = sg.G[i];
-            if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
-        }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
+        const float gv = sg.G[i];
+        if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const float g = scalars[0];
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
     const double t = (double)(*step);
     const float lr_t = (float)((double)k.lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
     const float b1 = (float)beta1, b2 = (float)beta2;
-    const int64_t n4 = sg.n / 4;
+    const int64_t n4 = blockIdx.y < 2 ? sg.n / 4 : 0;
     f4 *W4 = reinterpret_cast<f4 *>(sg.W), *M4 = reinterpret_cast<f4 *>(sg.S1), *V4 = reinterpret_cast<f4 *>(sg.S2),
        *G4 = reinterpret_cast<f4 *>(sg.G);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
@@ -646,11 +655,9 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
         M4[i] = m; V4[i] = v; W4[i] = wv;
         if (gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f) G4[i] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    if (blockIdx.x == 0) {
-        for (int64_t i = n4 * 4 + threadIdx.x; i < sg.n; i += kBlock) {
-            adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
-            sg.G[i] = 0.f;
-        }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
+        adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
+        sg.G[i] = 0.f;
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const float g = scalars[0];
@@ -675,13 +682,26 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
-                     !p->r_uniq_rec || !p->c_uniq_rec || !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+                     !p->heavy || p->heavy_chunks < 1 || !p->r_uniq_rec || !p->c_uniq_rec || !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;   // 32-bit row offsets
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     return 0;
+}
+
+static IdWork id_work(const glove_plan *p)
+{
+    IdWork w;
+    w.counts = p->counts;
+    w.nu_r_host = p->host_counts[1];
+    w.nu_c_host = p->host_counts[3];
+    w.n_heavy_host = p->host_counts[4];
+    w.heavy = p->heavy;
+    w.heavy_blocks = p->host_counts[4] >= 0 ? p->host_counts[4] : p->cap_heavy;
+    w.heavy_chunks = p->heavy_chunks;
+    return w;
 }
 
 static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
@@ -703,9 +723,6 @@ static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_f
 static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tables *t, bool row)
 {
     SideBufs s;
-    s.chunk_id = row ? p->r_chunk_id : p->c_chunk_id;
-    s.chunk_start = row ? p->r_chunk_start : p->c_chunk_start;
-    s.uniq_slot = row ? p->r_uniq_slot : p->c_uniq_slot;
     s.uniq_rec = row ? p->r_uniq_rec : p->c_uniq_rec;
     s.gp = row ? w.gp_r : w.gp_c;
     s.gb = row ? w.gb_r : w.gb_c;
@@ -787,14 +804,14 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
-    const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const IdWork wk = id_work(p);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     hipStream_t st = (hipStream_t)stream;
-    const int32_t *hc = p->host_counts;
 #define CALL(LPR, NV)                                                                                          \
-    hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, hc[1], hc[3], rs, cs, d4, \
+    hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4,        \
                        k, t->scalars, w.blockpart, nb_row, loss_out)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
@@ -810,16 +827,16 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
-    const int nb = blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const IdWork wk = id_work(p);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     const size_t Vd = (size_t)t->V * t->d;
     float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V, *tail = G_bc + t->V;
     hipStream_t st = (hipStream_t)stream;
-    const int32_t *hc = p->host_counts;
 #define CALL(LPR, NV)                                                                                       \
-    hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, p->counts, hc[1], hc[3], rs, cs, d4, \
+    hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4,        \
                        k, G_R, G_C, G_br, G_bc, tail, w.blockpart, nb_row)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
@@ -838,7 +855,6 @@ static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_fl
     tail = G_bc + t->V;
     segs.s[0] = {t->R, t->s1_R, t->s2_R, G_R, Vd};
     segs.s[1] = {t->C, t->s1_C, t->s2_C, G_C, Vd};
-    // bias segments: the float4 body needs 16-B aligned G pointers; V may be odd, so sweep them scalar
     segs.s[2] = {t->br, t->s1_br, t->s2_br, G_br, (int64_t)t->V};
     segs.s[3] = {t->bc, t->s1_bc, t->s2_bc, G_bc, (int64_t)t->V};
     nbx = blocks_for(Vd / 4, kBlock);
@@ -847,31 +863,6 @@ static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_fl
 
 }  // extern "C"
 
-namespace glove {
-// Bias segments of G_flat start at float offsets 2Vd and 2Vd+V, which are only 16-B aligned when
-// V % 4 == 0; they are tiny ([V]), so they get their own scalar kernels.
-__global__ __launch_bounds__(kBlock) void dense_adagrad_bias_kernel(DenseSeg a, DenseSeg b, StepConsts k)
-{
-    const DenseSeg sg = blockIdx.y == 0 ? a : b;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
-        const float gv = sg.G[i];
-        if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void dense_adam_bias_kernel(DenseSeg a, DenseSeg b, StepConsts k, double beta1,
-                                                                 double beta2, const int64_t *__restrict__ step)
-{
-    const DenseSeg sg = blockIdx.y == 0 ? a : b;
-    const double t = (double)(*step);
-    const float lr_t = (float)((double)k.lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
-    const float b1 = (float)beta1, b2 = (float)beta2;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
-        adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
-        sg.G[i] = 0.f;
-    }
-}
-}  // namespace glove
 
 extern "C" {
 
@@ -881,11 +872,7 @@ int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *
     if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx)) return rc;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-    // biases first: the embedding kernel's block (0,0) consumes and clears the tail last
-    hipLaunchKernelGGL(dense_adagrad_bias_kernel, dim3(blocks_for(t->V, kBlock), 2), dim3(kBlock), 0, st, segs.s[2],
-                       segs.s[3], k);
-    DenseSegs two = segs; two.s[2] = two.s[0]; two.s[3] = two.s[1];
-    hipLaunchKernelGGL(dense_adagrad_kernel, dim3(nbx, 2), dim3(kBlock), 0, st, two, k, t->scalars, tail, loss_out);
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, t->scalars, tail, loss_out);
     return (int)hipGetLastError();
 }
 
@@ -895,10 +882,7 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
     if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx)) return rc;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_adam_bias_kernel, dim3(blocks_for(t->V, kBlock), 2), dim3(kBlock), 0, st, segs.s[2],
-                       segs.s[3], k, h->beta1, h->beta2, t->step);
-    DenseSegs two = segs; two.s[2] = two.s[0]; two.s[3] = two.s[1];
-    hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 2), dim3(kBlock), 0, st, two, k, h->beta1, h->beta2, t->step,
+    hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, h->beta1, h->beta2, t->step,
                        t->scalars, tail, loss_out);
     return (int)hipGetLastError();
 }

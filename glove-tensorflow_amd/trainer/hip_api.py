@@ -17,6 +17,7 @@ LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
 GLOVE_ABI_VERSION = 1
 DEFAULT_CHUNK_CAP = 32
+HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
 def auto_chunk_cap(B: int, V: int) -> int:
@@ -53,11 +54,12 @@ class GloveHyper(C.Structure):
 
 class GlovePlan(C.Structure):
     _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
-                ("cap_uniq", C.c_int32), ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 4),
+                ("cap_uniq", C.c_int32), ("heavy_chunks", C.c_int32), ("cap_heavy", C.c_int32),
+                ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 8),
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp),
-                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp)]
+                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp)]
 
 
 class GloveHipError(RuntimeError):
@@ -212,7 +214,7 @@ class Plan:
     """Device-resident dedup index of one batch (see glove_plan in include/glove_hip.h)."""
 
     INT_FIELDS = ("r_partner", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot", "r_uniq_rec",
-                  "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec")
+                  "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
                  cap_uniq: int | None = None):
@@ -223,8 +225,11 @@ class Plan:
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         n = max(self.B, 1)
-        self.counts = torch.zeros(4, **i32)
-        self.host_counts = [-1, -1, -1, -1]      # unknown until the build has been synchronised
+        self.heavy_chunks = HEAVY_CHUNKS
+        self.cap_heavy = 2 * self.B // (self.heavy_chunks * self.chunk_cap) + 2
+        self.counts = torch.zeros(8, **i32)
+        self.host_counts = [-1] * 8      # unknown until the build has been synchronised
+        self.heavy = torch.zeros(self.cap_heavy, **i32)
         self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
@@ -237,8 +242,9 @@ class Plan:
         if self._struct is None:
             s = GlovePlan()
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
+            s.heavy_chunks, s.cap_heavy = self.heavy_chunks, self.cap_heavy
             s.counts = _ptr(self.counts)
-            for i in range(4):
+            for i in range(8):
                 s.host_counts[i] = self.host_counts[i]
             s.r_w, s.r_y = _ptr(self.r_w), _ptr(self.r_y)
             for n in self.INT_FIELDS:
@@ -248,12 +254,14 @@ class Plan:
 
     def compact(self) -> "Plan":
         """Exact-size copy (one host sync): used when plans of a static stream stay resident."""
-        nc_r, nu_r, nc_c, nu_c = (int(x) for x in self.counts.tolist())
+        nc_r, nu_r, nc_c, nu_c, n_heavy = (int(x) for x in self.counts.tolist()[:5])
         out = Plan.__new__(Plan)
         out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
         out.counts = self.counts.clone()
-        out.host_counts = [nc_r, nu_r, nc_c, nu_c]
+        out.host_counts = [nc_r, nu_r, nc_c, nu_c, n_heavy, -1, -1, -1]
+        out.heavy_chunks, out.cap_heavy = self.heavy_chunks, max(n_heavy, 1)
+        out.heavy = self.heavy[:max(n_heavy, 1)].clone()
         out.r_partner, out.r_w, out.r_y, out.r_to_c = self.r_partner, self.r_w, self.r_y, self.r_to_c
         out.c_partner, out.c_perm = self.c_partner, self.c_perm
         out.r_chunk_id = self.r_chunk_id[:max(out.cap_chunks, 1)].clone()

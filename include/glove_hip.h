@@ -73,11 +73,13 @@ typedef struct glove_plan {
     int32_t chunk_cap;          /* max pairs per chunk */
     int32_t cap_chunks;         /* capacity of the *_chunk_* arrays (>= chunks, <= B) */
     int32_t cap_uniq;           /* capacity of the *_uniq_slot arrays minus one */
+    int32_t heavy_chunks;       /* ids with more chunks than this go to the `heavy` list (default 8) */
+    int32_t cap_heavy;          /* capacity of `heavy` (>= 2 B / (heavy_chunks * chunk_cap) + 2) */
     int32_t reserved;
-    int32_t *counts;            /* int32[4]: chunks_row, uniq_row, chunks_col, uniq_col */
+    int32_t *counts;            /* int32[8]: chunks_row, uniq_row, chunks_col, uniq_col, heavy, 0.. */
     /* host copy of counts for plans whose build has completed (a resident plan of a static
      * stream): saves the kernels one dependent load.  -1 = unknown, read `counts` on the device. */
-    int32_t host_counts[4];
+    int32_t host_counts[8];
     /* row side: position k = k-th pair in (row id, original order) order */
     int32_t *r_partner;         /* [B] col id of pair k */
     float   *r_w;               /* [B] glove_weight */
@@ -96,6 +98,10 @@ typedef struct glove_plan {
     int32_t *c_chunk_start;
     int32_t *c_uniq_slot;
     int32_t *c_uniq_rec;
+    /* ids of the Zipf head (more than heavy_chunks chunks in this batch), both sides, in no
+     * particular order: (side << 30) | q with side 0 = row, 1 = col.  The apply kernels give each of
+     * them a whole workgroup that starts ahead of the per-lane-group work on the light ids. */
+    int32_t *heavy;
 } glove_plan;
 
 int glove_abi_version(void);

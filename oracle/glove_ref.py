@@ -238,7 +238,7 @@ def cosine_topk(R, query_ids, k):
 # --------------------------------------------------------------------------------------
 # Dedup index ("plan") — integer work, bit-exact target for glove_plan_build.
 # --------------------------------------------------------------------------------------
-def build_plan(row, col, chunk_cap):
+def build_plan(row, col, chunk_cap, heavy_chunks=8):
     """Reference construction of the per-batch dedup index the HIP library builds on device.
 
     Row side: pairs stably sorted by row id; each run of equal ids is cut into chunks of at
@@ -271,13 +271,16 @@ def build_plan(row, col, chunk_cap):
     c_chunk_id, c_chunk_start, c_uniq_slot, c_uniq_rec = side(s_col[perm_c])
     r_to_c = np.empty(B, np.int64)
     r_to_c[perm_c] = np.arange(B)
+    heavy = sorted([int(q) for q in np.flatnonzero(r_uniq_rec[:, 2] > heavy_chunks)] +
+                   [(1 << 30) | int(q) for q in np.flatnonzero(c_uniq_rec[:, 2] > heavy_chunks)]) if B else []
     return dict(perm_r=perm_r.astype(np.int32), r_partner=s_col.astype(np.int32), r_to_c=r_to_c.astype(np.int32),
+                heavy=np.asarray(heavy, np.int32),
                 r_chunk_id=r_chunk_id, r_chunk_start=r_chunk_start, r_uniq_slot=r_uniq_slot,
                 r_uniq_rec=r_uniq_rec, c_uniq_rec=c_uniq_rec,
                 c_perm=perm_c.astype(np.int32), c_partner=s_row[perm_c].astype(np.int32),
                 c_chunk_id=c_chunk_id, c_chunk_start=c_chunk_start, c_uniq_slot=c_uniq_slot,
                 counts=np.asarray([len(r_chunk_id), len(r_uniq_slot) - 1,
-                                   len(c_chunk_id), len(c_uniq_slot) - 1], np.int32))
+                                   len(c_chunk_id), len(c_uniq_slot) - 1, len(heavy), 0, 0, 0], np.int32))
 
 
 # --------------------------------------------------------------------------------------

@@ -49,14 +49,14 @@ def test_struct_layout_matches_the_c_header(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "glove_hip.h"\nint main(void){\n'
                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(glove_tables), sizeof(glove_hyper), '
                    'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
-                   'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, c_uniq_rec));\n'
+                   'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, heavy));\n'
                    'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     T, H, P = hip_api.GloveTables, hip_api.GloveHyper, hip_api.GlovePlan
     assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
-                   P.host_counts.offset, P.r_to_c.offset, P.c_uniq_rec.offset]
+                   P.host_counts.offset, P.r_to_c.offset, P.heavy.offset]
 
 
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):

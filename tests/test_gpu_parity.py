@@ -31,7 +31,8 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     want = ref.build_plan(row, col, cap)
     counts = plan.counts.cpu().numpy()
     np.testing.assert_array_equal(counts, want["counts"])
-    nc_r, nu_r, nc_c, nu_c = counts
+    nc_r, nu_r, nc_c, nu_c, n_heavy = counts[:5]
+    np.testing.assert_array_equal(np.sort(plan.heavy.cpu().numpy()[:n_heavy]), want["heavy"])   # order is free
     np.testing.assert_array_equal(plan.r_partner.cpu().numpy()[:B], want["r_partner"])
     np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
     np.testing.assert_array_equal(plan.r_y.cpu().numpy()[:B], y[want["perm_r"]])
@@ -56,7 +57,7 @@ def test_plan_empty_batch(hip):
     e = torch.empty(0, dtype=torch.int32, device="cuda:0")
     f = torch.empty(0, dtype=torch.float32, device="cuda:0")
     plan = hip.build_plan(e, e, f, f, 10)
-    assert plan.counts.tolist() == [0, 0, 0, 0]
+    assert plan.counts.tolist() == [0] * 8
 
 
 # (B, V, d, chunk_cap): d covers every (lanes-per-row, float4-per-lane) kernel shape

@@ -20,6 +20,9 @@ def report(name, st, nslots):
     st = st.reshape(-1, 8).astype(np.float64)
     live = st[:, 0] > 0
     st = st[live]
+    if len(st) == 0:
+        print("%s: no stamps in this kernel" % name)
+        return
     t0 = st[:, 0].min()
     us = lambda x: (x - t0) / 100.0          # 100 MHz -> us
     q = lambda a: "p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(a, [10, 50, 90, 100]))
