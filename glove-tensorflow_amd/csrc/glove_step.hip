@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][4][kFieldStride];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
+    GLOVE_STAMP(0);
     const int n_chunks = n_host >= 0 ? n_host : counts[0];
     const float g = scalars[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
         const int32_t u = chunk_id[j];
         const int s = chunk_start[j];
         const int n = chunk_start[j + 1] - s;
+        GLOVE_DRAIN(); GLOVE_STAMP(1);      // descriptor arrived
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
             const int t = lg + sl * LPR;
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
         float se = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
+        GLOVE_DRAIN(); GLOVE_STAMP(2);      // pair fields staged, own row arrived
         // fields written by this wave's own lanes: LDS ops of one wave complete in order
 
         for (int q0 = 0; q0 < n; q0 += U) {
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
             }
             if (lg < U && q0 + lg < n) e_col[fld[grp][3][q0 + lg]] = e_mine;   // col-sorted slot, for colpass
         }
+        GLOVE_STAMP(3);                     // all partner-row trips issued and consumed
         store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
         float rr = 0.f;
 #pragma unroll
@@ -255,8 +259,10 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
             part[3] += se;
         }
     }
+    GLOVE_DRAIN(); GLOVE_STAMP(4);          // stores retired
     part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
     block_partials_store(part, blockpart);
+    GLOVE_DRAIN(); GLOVE_STAMP(5);
 }
 
 template <int LPR, int NV, bool FULL>
