@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
+    "glove_cooc_workspace_bytes", "glove_cooccurrence_i32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -99,6 +100,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
         "glove_topk_cosine_f32": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "glove_cooc_workspace_bytes": (sz, [i64, i32]),
+        "glove_cooccurrence_i32": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, sz, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
@@ -386,3 +389,25 @@ class GloveHip:
         _check(self.lib.glove_topk_cosine_f32(_ptr(R), V, d, _ptr(query_ids), n, k, _ptr(sims), _ptr(idx),
                                               _ptr(ws), ws.numel(), _stream()), "glove_topk_cosine_f32")
         return sims, idx
+
+    # ---- data prep
+    def cooccurrence(self, tokens: torch.Tensor, V: int, context: int, cap: int | None = None):
+        """(row i32, col i32, count i64, value f64) sorted by (row, col): the symmetrised window
+        co-occurrence table of reference src/data/text8.py:84-108 (one host sync for the size)."""
+        _require_cuda(tokens)
+        n = int(tokens.numel())
+        cap = int(cap if cap is not None else max(1, 2 * context * n))
+        dev = tokens.device
+        row = torch.empty(cap, dtype=torch.int32, device=dev)
+        col = torch.empty(cap, dtype=torch.int32, device=dev)
+        cnt = torch.empty(cap, dtype=torch.int64, device=dev)
+        val = torch.empty(cap, dtype=torch.float64, device=dev)
+        nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(self.lib.glove_cooc_workspace_bytes(n, context), dtype=torch.uint8, device=dev)
+        _check(self.lib.glove_cooccurrence_i32(_ptr(tokens), n, V, context, _ptr(row), _ptr(col), _ptr(cnt), _ptr(val),
+                                               _ptr(nnz), cap, _ptr(ws), ws.numel(), _stream()),
+               "glove_cooccurrence_i32")
+        m = int(nnz.item())
+        if m > cap:
+            raise GloveHipError("co-occurrence table has %d entries, capacity %d" % (m, cap))
+        return row[:m], col[:m], cnt[:m], val[:m]

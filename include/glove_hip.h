@@ -167,6 +167,18 @@ int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *q
                           int32_t k, float *sims_out, int32_t *idx_out,
                           void *ws, size_t ws_bytes, void *stream);
 
+/* ---- data prep: windowed co-occurrence counts (reference src/data/text8.py:84-108) ----------------
+ * tokens: int32[n] vocabulary ids of the corpus in order (OOV already mapped to 0, text8.py:86).
+ * For every position p and offset k in 1..context with a = tok[p] != b = tok[p+k]:
+ * count(a,b) += 1, value(a,b) += 1/k, and the same for (b,a) (the reference's union with the swapped
+ * table).  Output sorted by (row, col): out_row/out_col int32[cap], out_count int64[cap],
+ * out_value double[cap]; *out_nnz (device int64) = number of distinct (row, col) — may exceed cap, in
+ * which case only the first cap entries were written. */
+size_t glove_cooc_workspace_bytes(int64_t n_tokens, int32_t context);
+int glove_cooccurrence_i32(const int32_t *tokens, int64_t n_tokens, int32_t V, int32_t context,
+                           int32_t *out_row, int32_t *out_col, int64_t *out_count, double *out_value,
+                           int64_t *out_nnz, int64_t cap, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
