@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--chunk-cap", type=int, default=0, help="0 = auto (hip_api.auto_chunk_cap)")
     ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form (dense gradient buffer + all-reduce) also on one GPU")
-    ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad"])
+    ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad", "Adam"],
+                    help="Adam = Keras-legacy dense-decay Adam (config 1 of BASELINE.json), single GPU only")
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
@@ -51,6 +52,12 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
     return ap.parse_args()
+
+
+def algorithmic_bytes_adam(B, V, d):
+    """Keras-legacy Adam sweeps W, m, v (read + write) of both tables and bias vectors
+    every step, independent of the batch, plus the nonzero stream."""
+    return 16 * B + 2 * 24 * V * (d + 1)
 
 
 def algorithmic_bytes(B, d, u_row, u_col):
@@ -75,12 +82,12 @@ def measured_traffic(workload, B, cap):
     return None, None
 
 
-def cpu_baseline(workload, B, hp_kwargs, seconds):
+def cpu_baseline(workload, B, hp_kwargs, seconds, optimizer="Adagrad"):
     sys.path.insert(0, str(REPO / "oracle"))
     import numpy as np
     import glove_ref as ref
     import glove_ref_c
-    t = ref.Tables(workload["V"], workload["d"], "Adagrad", dtype=np.float32, seed=1)
+    t = ref.Tables(workload["V"], workload["d"], optimizer, dtype=np.float32, seed=1)
     port = glove_ref_c.CPort(t, B)
     hp = ref.Hyper(**hp_kwargs)
     row, col = workload["row"].cpu().numpy(), workload["col"].cpu().numpy()
@@ -105,7 +112,7 @@ def cpu_baseline(workload, B, hp_kwargs, seconds):
     except OSError:
         pass
     return {"value": n * B / el, "unit": "nonzeros/s", "cores": 1, "kind": "port",
-            "sample": "%d Adagrad steps of %d nonzeros (same batches, oracle/glove_ref.c, -O2 scalar fp32)" % (n, B),
+            "sample": "%d %s steps of %d nonzeros (same batches, oracle/glove_ref.c, -O2 scalar fp32)" % (n, optimizer, B),
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
 
@@ -125,6 +132,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     dense = world > 1 or args.force_dense
+    adam = args.optimizer == "Adam"
+    if adam and dense:
+        raise SystemExit("--optimizer Adam is benchmarked on one GPU")
     if dense:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:      # --force-dense on a single GPU without a launcher
@@ -166,12 +176,14 @@ def main():
     ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
                      else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     loss_out = torch.zeros(4, device=dev)
-    G = hip.dense_grad_buffer(tables) if dense else None
+    G = hip.dense_grad_buffer(tables) if dense or adam else None
 
     def step(i):
         bt = batches[i % nb]
         plan = hip.build_plan(*bt, V, chunk_cap=cap) if args.dynamic else plans[i % nb]
-        if not dense:
+        if adam:
+            hip.step_adam(plan, tables, hyper, G, loss_out, ws)
+        elif not dense:
             hip.step_adagrad(plan, tables, hyper, loss_out, ws)
         else:
             hip.rowpass(plan, tables, hyper, ws)
@@ -231,7 +243,10 @@ def main():
     kern = {}
     reps = max(nb, min(200, args.steps))
     calls = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws), "colpass": lambda p: hip.colpass(p, tables, hyper, ws)}
-    if not dense:
+    if adam:
+        calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
+        calls["dense_adam"] = lambda p: hip.dense_adam(tables, hyper, G, loss_out)
+    elif not dense:
         calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
     else:
         calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
@@ -250,7 +265,7 @@ def main():
     if G is not None:
         G.zero_()
     step_us = sum(kern.values())
-    alg = algorithmic_bytes(B, d, u_row, u_col)
+    alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
 
     traffic, traffic_src = measured_traffic(args.workload, B, cap) if not dense else (None, None)
@@ -274,7 +289,8 @@ def main():
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1 and not args.force_dense:
-            out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds,
+                                               args.optimizer)
         print(json.dumps(out), flush=True)
     if dense:
         dist.destroy_process_group()

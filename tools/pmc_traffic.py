@@ -24,13 +24,13 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     meta = dict(kv.split("=", 1) for kv in sys.argv[4:])
     out = {"meta": meta, "kernels": {}}
-    step = ("rowpass_kernel", "colpass_kernel", "apply_adagrad_kernel")
+    step = ("rowpass", "colpass", "apply_adagrad")          # the three kernels of one sparse-Adagrad step
     total = 0.0
     for k in sorted(set(fetch) | set(write)):
         rd, wr = 2.0 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
         out["kernels"][k] = {"FETCH_SIZE_KiB_raw": fetch.get(k), "WRITE_SIZE_KiB_raw": write.get(k),
                              "read_bytes_corrected": rd, "write_bytes": wr}
-        if k.startswith(step):
+        if any(k.startswith(x) for x in step):
             total += rd + wr
     out["traffic_bytes_per_step"] = total
     json.dump(out, open(sys.argv[3], "w"), indent=1)
