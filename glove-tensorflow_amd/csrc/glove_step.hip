@@ -343,6 +343,7 @@ struct IdWork {
     const int32_t *heavy;       // (side << 30) | q
     int heavy_blocks;           // leading blocks of the grid reserved for heavy ids
     int heavy_chunks;           // threshold
+    int sides;                  // 1 = rows only, 2 = cols only, 3 = both
 };
 
 struct StepConsts {
@@ -400,6 +401,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         if ((int)blockIdx.x >= n_heavy) return false;
         const int code = wk.heavy[blockIdx.x];
         const bool is_row = (code >> 30) == 0;
+        if (!(wk.sides & (is_row ? 1 : 2))) return false;
         const SideBufs &sb = is_row ? rs : cs;
         const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[code & 0x3fffffff];
         const int sl0 = rec.y, sl1 = rec.y + rec.z;
@@ -437,9 +439,10 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
     // ---- light ids: one group each, dealt round-robin over the light blocks
     const int nu_r = wk.nu_r_host >= 0 ? wk.nu_r_host : wk.counts[1];
     const int nu_c = wk.nu_c_host >= 0 ? wk.nu_c_host : wk.counts[3];
-    const int total = nu_r + nu_c;
+    const int q_begin = (wk.sides & 1) ? 0 : nu_r;
+    const int total = (wk.sides & 2) ? nu_r + nu_c : nu_r;
     const int lb = blockIdx.x - wk.heavy_blocks, nlb = gridDim.x - wk.heavy_blocks;
-    for (int q = lb + grp * nlb; q < total; q += nlb * GPB) {
+    for (int q = q_begin + lb + grp * nlb; q < total; q += nlb * GPB) {
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
@@ -466,7 +469,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
     }
     GLOVE_STAMP(5);
-    return blockIdx.x == gridDim.x - 1;
+    return blockIdx.x == gridDim.x - 1 && (wk.sides & 2);     // scalar work goes with the col side
 }
 
 // Deterministic sum of the rowpass block partials by the whole workgroup (thread t takes blocks
@@ -612,7 +615,7 @@ struct DenseSegs { DenseSeg s[4]; };
 
 __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
     DenseSegs segs, StepConsts k, float *__restrict__ scalars, float *__restrict__ tail,
-    float *__restrict__ loss_out)
+    float *__restrict__ loss_out, int do_scalars)
 {
     // segments 0,1 = [V,d] tables (float4 body); 2,3 = bias vectors, whose G pointers are only 16-B
     // aligned when V % 4 == 0 and which are tiny: swept scalar by the same launch
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
         const float gv = sg.G[i];
         if (gv != 0.f) { adagrad_elem(sg.W[i], sg.S1[i], gv, k.lr, k.eps); sg.G[i] = 0.f; }
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (do_scalars && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const float g = scalars[0];
         const float tot[kPartials] = {tail[1], tail[2], tail[3], tail[0]};
         float loss, L, reg;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
 
 __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
     DenseSegs segs, StepConsts k, double beta1, double beta2, const int64_t *__restrict__ step,
-    float *__restrict__ scalars, float *__restrict__ tail, float *__restrict__ loss_out)
+    float *__restrict__ scalars, float *__restrict__ tail, float *__restrict__ loss_out, int do_scalars)
 {
     const DenseSeg sg = segs.s[blockIdx.y];
     // t = global_step after rowpass advanced it; lr_t = lr sqrt(1-b2^t)/(1-b1^t)  (Keras legacy Adam)
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
         adam_elem(sg.W[i], sg.S1[i], sg.S2[i], sg.G[i], lr_t, b1, b2, k.eps);
         sg.G[i] = 0.f;
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (do_scalars && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const float g = scalars[0];
         const float tot[kPartials] = {tail[1], tail[2], tail[3], tail[0]};
         float loss, L, reg;
@@ -692,9 +695,26 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
         return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
-    if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;   // 32-bit row offsets
+    if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     return 0;
+}
+
+static inline int sides_of(const glove_hyper *h) { return (h->sides & 3) ? (h->sides & 3) : 3; }
+static inline int v_row(const glove_tables *t) { return t->V_row > 0 ? t->V_row : t->V; }
+
+struct GradLayout { int64_t G_R, G_br, G_C, G_bc, tail, total; };
+static GradLayout grad_layout(int32_t Vr, int32_t V, int32_t d)
+{
+    GradLayout L;
+    auto up4 = [](int64_t x) { return (x + 3) / 4 * 4; };
+    L.G_R = 0;
+    L.G_br = (int64_t)Vr * d;
+    L.G_C = up4(L.G_br + Vr);
+    L.G_bc = L.G_C + (int64_t)V * d;
+    L.tail = up4(L.G_bc + V);
+    L.total = L.tail + 8;
+    return L;
 }
 
 static IdWork id_work(const glove_plan *p)
@@ -707,6 +727,7 @@ static IdWork id_work(const glove_plan *p)
     w.heavy = p->heavy;
     w.heavy_blocks = p->host_counts[4] >= 0 ? p->host_counts[4] : p->cap_heavy;
     w.heavy_chunks = p->heavy_chunks;
+    w.sides = 3;
     return w;
 }
 
@@ -756,7 +777,14 @@ size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d)
     return carve_step_ws(nullptr, B, cap_chunks, d).bytes;
 }
 
-size_t glove_dense_grad_floats(int32_t V, int32_t d) { return (size_t)2 * V * d + (size_t)2 * V + 8; }
+size_t glove_dense_grad_floats(int32_t V, int32_t d) { return (size_t)grad_layout(V, V, d).total; }
+
+size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *offs)
+{
+    const GradLayout L = grad_layout(V_row > 0 ? V_row : V, V, d);
+    if (offs) { offs[0] = L.G_R; offs[1] = L.G_br; offs[2] = L.G_C; offs[3] = L.G_bc; offs[4] = L.tail; }
+    return (size_t)L.total;
+}
 
 int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                       void *stream)
@@ -810,7 +838,8 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
-    const IdWork wk = id_work(p);
+    IdWork wk = id_work(p);
+    wk.sides = sides_of(h);
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
@@ -833,13 +862,15 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
-    const IdWork wk = id_work(p);
+    IdWork wk = id_work(p);
+    wk.sides = sides_of(h);
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
-    const size_t Vd = (size_t)t->V * t->d;
-    float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V, *tail = G_bc + t->V;
+    const GradLayout L = grad_layout(v_row(t), t->V, t->d);
+    float *G_R = G_flat + L.G_R, *G_C = G_flat + L.G_C, *G_br = G_flat + L.G_br, *G_bc = G_flat + L.G_bc,
+          *tail = G_flat + L.tail;
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                       \
     hipLaunchKernelGGL((dense_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4,        \
@@ -850,46 +881,45 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
 }
 
 static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_flat, bool adam, DenseSegs &segs,
-                        float *&tail, int &nbx)
+                        float *&tail, int &nbx, int &sides)
 {
     if (!t || !h || !G_flat || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
     if (adam && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;
-    const int64_t Vd = (int64_t)t->V * t->d;
-    float *G_R = G_flat, *G_C = G_flat + Vd, *G_br = G_flat + 2 * Vd, *G_bc = G_br + t->V;
-    tail = G_bc + t->V;
-    segs.s[0] = {t->R, t->s1_R, t->s2_R, G_R, Vd};
-    segs.s[1] = {t->C, t->s1_C, t->s2_C, G_C, Vd};
-    segs.s[2] = {t->br, t->s1_br, t->s2_br, G_br, (int64_t)t->V};
-    segs.s[3] = {t->bc, t->s1_bc, t->s2_bc, G_bc, (int64_t)t->V};
-    nbx = blocks_for(Vd / 4, kBlock);
+    const int32_t Vr = v_row(t);
+    const GradLayout L = grad_layout(Vr, t->V, t->d);
+    tail = G_flat + L.tail;
+    sides = sides_of(h);
+    // segment order = grid.y: 0 R, 1 C (float4 bodies), 2 br, 3 bc (scalar); a side that is not covered gets n = 0
+    const int64_t nr = (sides & 1) ? 1 : 0, nc = (sides & 2) ? 1 : 0;
+    segs.s[0] = {t->R, t->s1_R, t->s2_R, G_flat + L.G_R, nr * Vr * t->d};
+    segs.s[1] = {t->C, t->s1_C, t->s2_C, G_flat + L.G_C, nc * t->V * t->d};
+    segs.s[2] = {t->br, t->s1_br, t->s2_br, G_flat + L.G_br, nr * Vr};
+    segs.s[3] = {t->bc, t->s1_bc, t->s2_bc, G_flat + L.G_bc, nc * t->V};
+    nbx = blocks_for((int64_t)(Vr > t->V ? Vr : t->V) * t->d / 4, kBlock);
     return 0;
 }
 
-}  // extern "C"
-
-
-extern "C" {
-
 int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
 {
-    DenseSegs segs; float *tail; int nbx;
-    if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx)) return rc;
+    DenseSegs segs; float *tail; int nbx, sides;
+    if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx, sides)) return rc;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_adagrad_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, t->scalars, tail, loss_out);
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, t->scalars, tail, loss_out,
+                       (sides & 2) ? 1 : 0);
     return (int)hipGetLastError();
 }
 
 int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
 {
-    DenseSegs segs; float *tail; int nbx;
-    if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx)) return rc;
+    DenseSegs segs; float *tail; int nbx, sides;
+    if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx, sides)) return rc;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, h->beta1, h->beta2, t->step,
-                       t->scalars, tail, loss_out);
+                       t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -33,14 +33,14 @@ EXPORTED_SYMBOLS = (
     "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
-    "glove_cooc_workspace_bytes", "glove_cooccurrence_i32",
+    "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
 
 
 class GloveTables(C.Structure):
-    _fields_ = [("V", C.c_int32), ("d", C.c_int32),
+    _fields_ = [("V", C.c_int32), ("d", C.c_int32), ("V_row", C.c_int32), ("reserved", C.c_int32),
                 ("R", _fp), ("C", _fp), ("br", _fp), ("bc", _fp),
                 ("s1_R", _fp), ("s1_C", _fp), ("s1_br", _fp), ("s1_bc", _fp),
                 ("s2_R", _fp), ("s2_C", _fp), ("s2_br", _fp), ("s2_bc", _fp),
@@ -50,7 +50,7 @@ class GloveTables(C.Structure):
 class GloveHyper(C.Structure):
     _fields_ = [("beta1", C.c_double), ("beta2", C.c_double),
                 ("l2_reg", C.c_float), ("reg_mult", C.c_float), ("learning_rate", C.c_float),
-                ("epsilon", C.c_float), ("inv_batch", C.c_float), ("reserved", C.c_float)]
+                ("epsilon", C.c_float), ("inv_batch", C.c_float), ("sides", C.c_int32)]
 
 
 class GlovePlan(C.Structure):
@@ -92,6 +92,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_colpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_apply_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_dense_grad_floats": (sz, [i32, i32]),
+        "glove_dense_grad_layout": (sz, [i32, i32, i32, vp]),
         "glove_dense_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_dense_adagrad_f32": (C.c_int, [P(GloveTables), P(GloveHyper), vp, vp, vp]),
         "glove_dense_adam_f32": (C.c_int, [P(GloveTables), P(GloveHyper), vp, vp, vp]),
@@ -138,12 +139,18 @@ class DeviceTables:
 
     NAMES = ("R", "C", "br", "bc")
 
-    def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None):
+    def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None,
+                 V_row: int | None = None):
+        """`V_row` < V: this process holds only a shard of the row table (row ids handed to the kernels
+        are then local indices into the shard); the col table always has V rows."""
         if d % 4 != 0:
             raise ValueError("embedding size must be a multiple of 4 (16-byte rows), got %d" % d)
         if optimizer not in ("Adagrad", "Adam"):
             raise ValueError("optimizer must be 'Adagrad' or 'Adam' (Keras names), got %r" % (optimizer,))
         self.V, self.d, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
+        self.V_row = int(V if V_row is None else V_row)
+        if not 0 < self.V_row <= self.V:
+            raise ValueError("V_row must be in (0, V]")
         gen = torch.Generator(device="cpu")
         if seed is not None:
             gen.manual_seed(seed)
@@ -153,8 +160,8 @@ class DeviceTables:
         def uni(*shape):  # Keras Embedding default: U(-0.05, 0.05)
             return ((torch.rand(*shape, generator=gen, dtype=torch.float32) - 0.5) * 0.1).to(self.device)
 
-        self.R, self.C = uni(V, d), uni(V, d)
-        self.br, self.bc = uni(V), uni(V)
+        self.R, self.C = uni(self.V_row, d), uni(V, d)
+        self.br, self.bc = uni(self.V_row), uni(V)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.s1, self.s2 = {}, {}
@@ -172,7 +179,7 @@ class DeviceTables:
     def struct(self) -> GloveTables:
         if self._struct is None:
             s = GloveTables()
-            s.V, s.d = self.V, self.d
+            s.V, s.d, s.V_row = self.V, self.d, (0 if self.V_row == self.V else self.V_row)
             for n in self.NAMES:
                 setattr(s, n, _ptr(getattr(self, n)))
                 setattr(s, "s1_" + n, _ptr(self.s1[n]))
@@ -183,7 +190,7 @@ class DeviceTables:
 
     # ---- (de)serialisation used by the checkpoint code and the tests
     def state_dict(self) -> dict:
-        out = {"V": self.V, "d": self.d, "optimizer": self.optimizer,
+        out = {"V": self.V, "d": self.d, "V_row": self.V_row, "optimizer": self.optimizer,
                "scalars": self.scalars.cpu(), "global_step": self.step.cpu()}
         for n in self.NAMES:
             out[n] = getattr(self, n).cpu()
@@ -193,7 +200,7 @@ class DeviceTables:
         return out
 
     def load_state_dict(self, sd: dict):
-        if (sd["V"], sd["d"], sd["optimizer"]) != (self.V, self.d, self.optimizer):
+        if (sd["V"], sd["d"], sd["optimizer"], sd.get("V_row", sd["V"])) != (self.V, self.d, self.optimizer, self.V_row):
             raise ValueError("checkpoint is for V=%s d=%s %s, model is V=%d d=%d %s" % (
                 sd["V"], sd["d"], sd["optimizer"], self.V, self.d, self.optimizer))
         self.scalars.copy_(sd["scalars"])
@@ -283,8 +290,10 @@ class Plan:
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
-               batch_size=None, inv_batch=None) -> GloveHyper:
+               batch_size=None, inv_batch=None, sides=0) -> GloveHyper:
+    """`sides`: 0/3 both sides, 1 row side only, 2 col side only (see glove_hyper in the header)."""
     h = GloveHyper()
+    h.sides = sides
     h.beta1, h.beta2 = beta1, beta2
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
     h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
@@ -353,9 +362,14 @@ class GloveHip:
         _check(self.lib.glove_dense_adam_f32(C.byref(tables.struct()), C.byref(hyper), _ptr(G_flat),
                                              _ptr(loss_out), _stream()), "glove_dense_adam_f32")
 
+    def grad_layout(self, tables) -> dict:
+        """Float offsets of the sections of the flat dense-gradient buffer."""
+        offs = (C.c_int64 * 5)()
+        total = self.lib.glove_dense_grad_layout(tables.V_row, tables.V, tables.d, C.cast(offs, C.c_void_p))
+        return dict(G_R=offs[0], G_br=offs[1], G_C=offs[2], G_bc=offs[3], tail=offs[4], total=int(total))
+
     def dense_grad_buffer(self, tables) -> torch.Tensor:
-        return torch.zeros(self.lib.glove_dense_grad_floats(tables.V, tables.d), dtype=torch.float32,
-                           device=tables.device)
+        return torch.zeros(self.grad_layout(tables)["total"], dtype=torch.float32, device=tables.device)
 
     # ---- whole steps
     def step_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):

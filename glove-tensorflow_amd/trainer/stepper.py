@@ -51,6 +51,21 @@ class HipBackend:
         else:
             self.hip.dense_adam(tables, hyper, G, loss_out)
 
+    # ---- pieces of the row-sharded step (hyper.sides selects the side)
+    def passes(self, plan, tables, hyper):
+        self.hip.rowpass(plan, tables, hyper)
+        self.hip.colpass(plan, tables, hyper)
+
+    def apply_sparse(self, plan, tables, hyper):
+        self.hip.apply_adagrad(plan, tables, hyper)
+
+    def dense_grad(self, plan, tables, hyper, G):
+        self.hip.dense_grad(plan, tables, hyper, G)
+
+    def col_half(self, tables, G):
+        """The contiguous [G_C | G_bc | tail] part of the flat buffer."""
+        return G[self.hip.grad_layout(tables)["G_C"]:]
+
     def eval_sums(self, row, col, w, y, tables, sums):
         return self.hip.eval_sums(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), tables, sums)
 
@@ -80,5 +95,71 @@ class Stepper:
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
+        loss, L, reg, _ = self.loss_out.tolist()
+        return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}
+
+
+def owned_rows(V: int, world: int, rank: int) -> int:
+    """Rows of the row table held by `rank` when row id u lives on rank u % world at local index u // world."""
+    return (V - rank + world - 1) // world
+
+
+def route_by_row_owner(coo: dict, world: int, rank: int, dist) -> dict:
+    """All-to-all of a rank's nonzeros to the owners of their rows (BASELINE config 5: "row-embedding table
+    sharded across 8 GPUs with all-to-all token-id routing").  `coo`: dict of equally long 1-D tensors
+    row/col (int32) and w/y (float32) on the device the process group works on.  Returns the nonzeros this
+    rank owns, with `row` rewritten to the LOCAL row index (row // world).  For a static stream this runs
+    once at load time; a caller with fresh batches every step calls it per batch."""
+    owner = (coo["row"] % world).long()
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    s_list, r_list = send_counts.tolist(), recv_counts.tolist()
+    out = {}
+    for k in ("row", "col", "w", "y"):
+        src = coo[k][order].contiguous()
+        dst = torch.empty(int(sum(r_list)), dtype=src.dtype, device=src.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=r_list, input_split_sizes=s_list)
+        out[k] = dst
+    assert bool((out["row"] % world == rank).all())
+    out["row"] = (out["row"] // world).to(coo["row"].dtype)
+    return out
+
+
+class RowShardedStepper:
+    """Model-parallel form of BASELINE config 5.  The row table R / br (and their Adagrad accumulators) are
+    sharded by row id % world; the col table, the global bias and their slots are replicated.  Every rank
+    steps on nonzeros whose rows it owns (see route_by_row_owner), so
+
+      * the row side is completely local: rowpass / colpass, then a sparse Adagrad apply restricted to the
+        row side (hyper.sides = 1) — no communication;
+      * the col side is data parallel: the rank's summed col gradients (hyper.sides = 2) go into the
+        contiguous [G_C | G_bc | tail] half of the flat buffer, ONE all-reduce sums it over the ranks, and
+        every rank applies the identical dense update of C, bc and the global bias.
+
+    With inv_batch = 1 / (world * B) the result equals a single-GPU step on the union of the ranks'
+    batches (tests/test_dp_gloo.py)."""
+
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, dist):
+        if tables.optimizer != "Adagrad":
+            raise ValueError("the row-sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
+        self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
+        gb = batch_size * self.world
+        self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
+        self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
+        self.G = backend.dense_grad_buffer(tables)
+
+    def step(self, plan):
+        b, t = self.backend, self.tables
+        b.passes(plan, t, self.hyper_cols)
+        b.dense_grad(plan, t, self.hyper_cols, self.G)        # reads C (activity-L2 term): before any update
+        b.apply_sparse(plan, t, self.hyper_rows)              # R, br: local, no communication
+        if self.world > 1:
+            self.dist.all_reduce(b.col_half(t, self.G))
+        b.apply_dense(t, self.hyper_cols, self.G, self.loss_out)
+
+    def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
         return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}

@@ -36,6 +36,10 @@ extern "C" {
 typedef struct glove_tables {
     int32_t V;                  /* vocab size = lines of vocab.txt (reference estimator.py:31) */
     int32_t d;                  /* embedding size (--embedding-size) */
+    int32_t V_row;              /* rows of R / br held by this process; 0 = V.  Smaller than V when the
+                                 * row table is sharded over ranks (BASELINE config 5): row ids in the
+                                 * plans are then LOCAL indices into the shard */
+    int32_t reserved;
     float *R, *C;               /* row_embedding / col_embedding [V,d] (model_utils.py:31-34) */
     float *br, *bc;             /* row_bias / col_bias [V]         (model_utils.py:32-36) */
     float *s1_R, *s1_C, *s1_br, *s1_bc;   /* slot 1, same shapes */
@@ -56,7 +60,10 @@ typedef struct glove_hyper {
     float learning_rate;        /* --learning-rate */
     float epsilon;              /* Keras-legacy 1e-7 */
     float inv_batch;            /* 1 / (global batch size): RegressionHead SUM_OVER_BATCH_SIZE */
-    float reserved;
+    /* which sides a call of glove_apply_adagrad_f32 / glove_dense_grad_f32 / glove_dense_ad*_f32 covers:
+     * 0 or 3 = both, 1 = row side (R, br) only, 2 = col side (C, bc) only.  The once-per-step scalar work
+     * (global bias, loss, clearing the tail) goes with the col side. */
+    int32_t sides;
 } glove_hyper;
 
 /*
@@ -136,11 +143,15 @@ int glove_apply_adagrad_f32(const glove_plan *plan, const glove_tables *t, const
                             void *ws, size_t ws_bytes, float *loss_out, void *stream);
 
 /* ---- dense-gradient path (data-parallel all-reduce, and Keras-legacy Adam a11) -------------
- * G_flat layout: [G_R V*d | G_C V*d | G_br V | G_bc V | tail 8] floats, tail = {sum_e, sum
+ * G_flat layout (float offsets from glove_dense_grad_layout): [G_R V_row*d | G_br V_row | pad | G_C V*d |
+ * G_bc V | pad | tail 8]: each side is contiguous (the col half + tail can be all-reduced alone when the row
+ * table is sharded), sections 16-B aligned, tail = {sum_e, sum
  * w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, 0...}.  glove_dense_grad_f32 ADDS this batch's
  * summed gradients (incl. the activity-L2 terms) into G_flat, which the caller keeps all-zero
  * between steps (the dense apply kernels zero what they consume). */
-size_t glove_dense_grad_floats(int32_t V, int32_t d);
+size_t glove_dense_grad_floats(int32_t V, int32_t d);                 /* V_row = V */
+/* offs[5] = float offsets of G_R, G_br, G_C, G_bc, tail; returns the total float count */
+size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *offs);
 int glove_dense_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                          void *ws, size_t ws_bytes, float *G_flat, void *stream);
 int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,

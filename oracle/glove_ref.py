@@ -152,8 +152,8 @@ def gradients(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
     np.add.at(G_C, col, e[:, None] * r + kappa * c)
     np.add.at(G_br, row, e + kappa_b * t.br[row])
     np.add.at(G_bc, col, e + kappa_b * t.bc[col])
-    touched_r = np.zeros(t.V, bool)
-    touched_c = np.zeros(t.V, bool)
+    touched_r = np.zeros(len(t.R), bool)      # len(R) < V when the row table is a shard (config 5)
+    touched_c = np.zeros(len(t.C), bool)
     touched_r[row] = True
     touched_c[col] = True
     return dict(G_R=G_R, G_C=G_C, G_br=G_br, G_bc=G_bc, sum_e=e.sum(), e=e,

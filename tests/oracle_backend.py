@@ -1,6 +1,6 @@
-"""TEST-ONLY kernel provider: the numpy oracle behind the interface `trainer.stepper.Stepper`
-expects, so the data-parallel host logic (sharding, flat-buffer all-reduce, 1/(world*B) scaling)
-can be exercised with gloo on CPU.  Never imported by the product."""
+"""TEST-ONLY kernel provider: the numpy oracle behind the interface `trainer.stepper.Stepper` /
+`RowShardedStepper` expect, so the multi-rank host logic (sharding, routing, flat-buffer all-reduce,
+1/(world*B) scaling, side selection) can be exercised with gloo on CPU.  Never imported by the product."""
 import numpy as np
 import torch
 
@@ -12,7 +12,7 @@ class OracleTables:
         self.t = t
         self.device = torch.device("cpu")
         self.optimizer = t.optimizer
-        self.V, self.d = t.V, t.d
+        self.V, self.d, self.V_row = len(t.C), t.d, len(t.R)
 
     @property
     def global_step(self):
@@ -23,39 +23,62 @@ class OracleBackend:
     def build_plan(self, row, col, w, y, V, chunk_cap):
         return tuple(np.asarray(a) for a in (row, col, w, y))
 
-    def make_hyper(self, batch_size, l2_reg=0.01, reg_mult=2.0, learning_rate=0.001):
+    def make_hyper(self, batch_size, l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, sides=0):
         return dict(hp=ref.Hyper(l2_reg=l2_reg, reg_mult=reg_mult, learning_rate=learning_rate),
-                    inv_batch=1.0 / batch_size)
+                    inv_batch=1.0 / batch_size, sides=sides or 3)
+
+    # flat layout [G_R | G_br | G_C | G_bc | tail 8], as the product's (without alignment padding)
+    def _views(self, tables, G):
+        t, g = tables.t, G.numpy()
+        nr, nc, d = len(t.R), len(t.C), t.d
+        o = np.cumsum([0, nr * d, nr, nc * d, nc])
+        return (g[o[0]:o[1]].reshape(nr, d), g[o[1]:o[2]], g[o[2]:o[3]].reshape(nc, d), g[o[3]:o[4]], g[o[4]:o[4] + 8])
 
     def dense_grad_buffer(self, tables):
-        return torch.zeros(2 * tables.V * tables.d + 2 * tables.V + 8, dtype=torch.float64)
+        t = tables.t
+        return torch.zeros((len(t.R) + len(t.C)) * (t.d + 1) + 8, dtype=torch.float64)
+
+    def col_half(self, tables, G):
+        t = tables.t
+        return G[len(t.R) * (t.d + 1):]
+
+    def passes(self, plan, tables, hyper):
+        row, col, w, y = plan
+        self._gr = ref.gradients(tables.t, row, col, w, y, hyper["hp"], inv_batch=hyper["inv_batch"])
+
+    def dense_grad(self, plan, tables, hyper, G):
+        gr = self._gr
+        G_R, G_br, G_C, G_bc, tail = self._views(tables, G)
+        if hyper["sides"] & 1:
+            G_R += gr["G_R"]; G_br += gr["G_br"]
+        if hyper["sides"] & 2:
+            G_C += gr["G_C"]; G_bc += gr["G_bc"]
+            tail[0] += gr["sum_e"]
+            tail[1] += gr["L"] / hyper["inv_batch"]
 
     def local_dense_grad(self, plan, tables, hyper, G):
-        t = tables.t
-        row, col, w, y = plan
-        gr = ref.gradients(t, row, col, w, y, hyper["hp"], inv_batch=hyper["inv_batch"])
-        Vd = t.V * t.d
-        g = G.numpy()
-        g[:Vd] += gr["G_R"].ravel()
-        g[Vd:2 * Vd] += gr["G_C"].ravel()
-        g[2 * Vd:2 * Vd + t.V] += gr["G_br"]
-        g[2 * Vd + t.V:2 * Vd + 2 * t.V] += gr["G_bc"]
-        tail = g[2 * Vd + 2 * t.V:]
-        tail[0] += gr["sum_e"]
-        tail[1] += gr["L"] / hyper["inv_batch"]
+        self.passes(plan, tables, hyper)
+        self.dense_grad(plan, tables, hyper, G)
+
+    def apply_sparse(self, plan, tables, hyper):
+        t, gr, hp = tables.t, self._gr, hyper["hp"]
+        assert hyper["sides"] == 1 and t.optimizer == "Adagrad"
+        ref._adagrad(t.R, t.A_R, gr["G_R"], gr["touched_r"], hp.learning_rate, hp.epsilon)
+        ref._adagrad(t.br, t.A_br, gr["G_br"], gr["touched_r"], hp.learning_rate, hp.epsilon)
 
     def apply_dense(self, tables, hyper, G, loss_out):
-        t = tables.t
-        Vd = t.V * t.d
-        g = G.numpy()
-        G_R, G_C = g[:Vd].reshape(t.V, t.d), g[Vd:2 * Vd].reshape(t.V, t.d)
-        G_br, G_bc = g[2 * Vd:2 * Vd + t.V], g[2 * Vd + t.V:2 * Vd + 2 * t.V]
-        tail = g[2 * Vd + 2 * t.V:]
-        hp = hyper["hp"]
-        gr = dict(G_R=G_R.copy(), G_C=G_C.copy(), G_br=G_br.copy(), G_bc=G_bc.copy(), sum_e=tail[0],
-                  dg_reg=2.0 * hp.reg_mult * hp.l2_reg * t.g,
-                  touched_r=(G_R != 0).any(1) | (G_br != 0), touched_c=(G_C != 0).any(1) | (G_bc != 0))
+        t, hp, sides = tables.t, hyper["hp"], hyper["sides"]
+        G_R, G_br, G_C, G_bc, tail = self._views(tables, G)
+        zero_r, zero_c = np.zeros_like(t.R), np.zeros_like(t.C)
+        gr = dict(G_R=G_R.copy() if sides & 1 else zero_r, G_br=G_br.copy() if sides & 1 else zero_r[:, 0] * 0,
+                  G_C=G_C.copy() if sides & 2 else zero_c, G_bc=G_bc.copy() if sides & 2 else zero_c[:, 0] * 0,
+                  sum_e=tail[0], dg_reg=2.0 * hp.reg_mult * hp.l2_reg * t.g)
+        gr["touched_r"] = (gr["G_R"] != 0).any(1) | (gr["G_br"] != 0)
+        gr["touched_c"] = (gr["G_C"] != 0).any(1) | (gr["G_bc"] != 0)
+        assert sides & 2, "the scalar work goes with the col side"
         loss_out[1] = tail[1] * hyper["inv_batch"]
+        if t.optimizer == "Adam" and not sides & 1:
+            raise AssertionError("Adam has no side-restricted form")
         ref.apply_update(t, gr, hp)
         G.zero_()
 

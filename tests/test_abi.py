@@ -36,7 +36,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_size_queries_are_pure_host_functions(lib):
-    assert lib.glove_dense_grad_floats(100, 64) == 2 * 100 * 64 + 2 * 100 + 8
+    assert lib.glove_dense_grad_floats(100, 64) == 2 * 100 * 64 + 2 * 100 + 8       # V % 4 == 0: no padding
+    assert lib.glove_dense_grad_floats(101, 8) == 101 * 8 + 104 + 101 * 8 + 104 + 8   # sections 16-B aligned
     small, big = lib.glove_step_workspace_bytes(1024, 1024, 64), lib.glove_step_workspace_bytes(4096, 4096, 64)
     assert 0 < small < big
     assert lib.glove_plan_workspace_bytes(1024, 1000) > 1024 * 4 * 5
@@ -47,16 +48,17 @@ def test_struct_layout_matches_the_c_header(tmp_path):
     from trainer import hip_api
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "glove_hip.h"\nint main(void){\n'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(glove_tables), sizeof(glove_hyper), '
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(glove_tables), sizeof(glove_hyper), '
                    'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
                    'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, heavy));\n'
+                   'printf("%zu %zu\\n", offsetof(glove_tables, R), offsetof(glove_hyper, sides));\n'
                    'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     T, H, P = hip_api.GloveTables, hip_api.GloveHyper, hip_api.GlovePlan
     assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
-                   P.host_counts.offset, P.r_to_c.offset, P.heavy.offset]
+                   P.host_counts.offset, P.r_to_c.offset, P.heavy.offset, T.R.offset, H.sides.offset]
 
 
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):

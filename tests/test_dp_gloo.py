@@ -59,3 +59,53 @@ def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer):
         np.testing.assert_array_equal(ranks[0][name], ranks[1][name])           # replicas stay identical
         np.testing.assert_allclose(ranks[0][name], getattr(t, name), rtol=1e-10, atol=1e-13)
     assert int(ranks[0]["step"]) == STEPS
+
+
+# ---- BASELINE config 5: row table sharded over the ranks, nonzeros routed to the owners of their rows
+def _sharded_worker(rank, port, out_dir):
+    for p in (HERE.parent, HERE.parent / "oracle", HERE):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import glove_ref as ref
+    from oracle_backend import OracleBackend, OracleTables
+    from trainer.stepper import RowShardedStepper, owned_rows, route_by_row_owner
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    full = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    assert owned_rows(V, WORLD, rank) == len(range(rank, V, WORLD))
+    shard = full.copy()                                   # R / br / their accumulators: rows rank, rank+W, ...
+    for n in ("R", "br", "A_R", "A_br"):
+        setattr(shard, n, getattr(full, n)[rank::WORLD].copy())
+    tables = OracleTables(shard)
+    backend = OracleBackend()
+    stepper = RowShardedStepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist)
+    routed_sizes = []
+    for step_batches in _batches():
+        mine = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in zip(("row", "col", "w", "y"), step_batches[rank])}
+        routed = route_by_row_owner(mine, WORLD, rank, dist)
+        routed_sizes.append(int(routed["row"].numel()))
+        assert int(routed["row"].max()) < tables.V_row
+        stepper.step(backend.build_plan(routed["row"].numpy(), routed["col"].numpy(), routed["w"].numpy(),
+                                        routed["y"].numpy(), V, 32))
+    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), R=shard.R, br=shard.br, C=shard.C, bc=shard.bc, g=shard.g,
+             sizes=np.asarray(routed_sizes))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
+    sys.path.insert(0, str(HERE.parent / "oracle"))
+    import glove_ref as ref
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_sharded_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    hp = ref.Hyper(learning_rate=0.05)
+    for step_batches in _batches():
+        ref.train_step(t, *[np.concatenate([b[i] for b in step_batches]) for i in range(4)], hp)
+    shards = [np.load(tmp_path / ("shard%d.npz" % r)) for r in range(WORLD)]
+    assert sum(int(s["sizes"].sum()) for s in shards) == STEPS * WORLD * B      # every nonzero routed exactly once
+    for r, s in enumerate(shards):
+        np.testing.assert_allclose(s["R"], t.R[r::WORLD], rtol=1e-10, atol=1e-13)    # each rank owns its rows
+        np.testing.assert_allclose(s["br"], t.br[r::WORLD], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(s["C"], t.C, rtol=1e-10, atol=1e-13)              # replicas agree with the oracle
+        np.testing.assert_allclose(s["bc"], t.bc, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(s["g"], t.g, rtol=1e-10)
+    np.testing.assert_array_equal(shards[0]["C"], shards[1]["C"])
