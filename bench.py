@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="text8_d64", choices=["text8_d64", "text8_v50k_d300", "zipf_v400k_d300"])
+    ap.add_argument("--workload", default="text8_d64", choices=["text8_d64", "text8_v50k_d300", "zipf_v400k_d300", "zipf_v2m_d128"])
+    ap.add_argument("--row-sharded", action="store_true",
+                    help="BASELINE config 5: row table sharded by id %% N, nonzeros routed to row owners (all-to-all at load), "
+                         "col side data parallel")
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--chunk-cap", type=int, default=0, help="0 = auto (hip_api.auto_chunk_cap)")
     ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form (dense gradient buffer + all-reduce) also on one GPU")
@@ -131,7 +134,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    dense = world > 1 or args.force_dense
+    dense = world > 1 or args.force_dense or args.row_sharded
     adam = args.optimizer == "Adam"
     if adam and dense:
         raise SystemExit("--optimizer Adam is benchmarked on one GPU")
@@ -148,6 +151,11 @@ def main():
     B = args.batch_size
     wl = synthetic.make_workload(args.workload, seed=rank, device=dev, work_device=dev)
     V, d = wl["V"], wl["d"]
+    V_row = V
+    if args.row_sharded:
+        from trainer.stepper import owned_rows, route_by_row_owner
+        V_row = owned_rows(V, world, rank)
+        wl.update(route_by_row_owner({k: wl[k] for k in ("row", "col", "w", "y")}, world, rank, dist))
     from trainer.hip_api import auto_chunk_cap
     cap = args.chunk_cap or auto_chunk_cap(B, V)
     nnz = wl["row"].numel()
@@ -171,12 +179,16 @@ def main():
     u_col = sum(c[3] for c in counts) / nb
     chunks = sum(c[0] + c[2] for c in counts) / nb
 
-    tables = DeviceTables(V, d, args.optimizer, device=dev, seed=1)      # identical init on every rank
+    tables = DeviceTables(V, d, args.optimizer, device=dev, seed=1, V_row=V_row)      # identical replicas on every rank
     hyper = make_hyper(learning_rate=args.learning_rate, batch_size=B * world)
     ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
                      else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     loss_out = torch.zeros(4, device=dev)
     G = hip.dense_grad_buffer(tables) if dense or adam else None
+    if args.row_sharded:
+        hyper_rows = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, sides=1)
+        hyper_cols = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, sides=2)
+        G_col_half = G[hip.grad_layout(tables)["G_C"]:]
 
     def step(i):
         bt = batches[i % nb]
@@ -185,6 +197,13 @@ def main():
             hip.step_adam(plan, tables, hyper, G, loss_out, ws)
         elif not dense:
             hip.step_adagrad(plan, tables, hyper, loss_out, ws)
+        elif args.row_sharded:
+            hip.rowpass(plan, tables, hyper, ws)
+            hip.colpass(plan, tables, hyper, ws)
+            hip.dense_grad(plan, tables, hyper_cols, G, ws)
+            hip.apply_adagrad(plan, tables, hyper_rows, None, ws)
+            dist.all_reduce(G_col_half)
+            hip.dense_adagrad(tables, hyper_cols, G, loss_out)
         else:
             hip.rowpass(plan, tables, hyper, ws)
             hip.colpass(plan, tables, hyper, ws)
@@ -249,9 +268,15 @@ def main():
     elif not dense:
         calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
     else:
-        calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
-        calls["all_reduce"] = lambda p: dist.all_reduce(G)                 # RCCL over xGMI, broken out
-        calls["dense_adagrad"] = lambda p: hip.dense_adagrad(tables, hyper, G, loss_out)
+        if args.row_sharded:
+            calls["dense_grad_cols"] = lambda p: hip.dense_grad(p, tables, hyper_cols, G, ws)
+            calls["apply_adagrad_rows"] = lambda p: hip.apply_adagrad(p, tables, hyper_rows, None, ws)
+            calls["all_reduce"] = lambda p: dist.all_reduce(G_col_half)    # RCCL over xGMI, broken out
+            calls["dense_adagrad_cols"] = lambda p: hip.dense_adagrad(tables, hyper_cols, G, loss_out)
+        else:
+            calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
+            calls["all_reduce"] = lambda p: dist.all_reduce(G)             # RCCL over xGMI, broken out
+            calls["dense_adagrad"] = lambda p: hip.dense_adagrad(tables, hyper, G, loss_out)
     for name, fn in calls.items():
         for i in range(4):
             fn(plans[i % nb])
@@ -280,7 +305,8 @@ def main():
                        "resident_batches": nb, "chunk_cap": cap,
                        "index": "rebuilt every step" if args.dynamic else "static, built at load",
                        "launch": "hipGraph replay" if graph is not None else "eager",
-                       "parallelism": "dp%d dense-grad all-reduce" % world if dense else "single GPU"},
+                       "parallelism": ("row-sharded x%d + col all-reduce" % world if args.row_sharded else
+                                       "dp%d dense-grad all-reduce" % world if dense else "single GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one step = " + " + ".join(kern),

@@ -84,6 +84,7 @@ WORKLOADS = {
     "text8_d64": ("text8_shaped", dict(V=10000), 64),
     "text8_v50k_d300": ("zipf_sampled", dict(V=50000, nnz=8_000_000), 300),
     "zipf_v400k_d300": ("zipf_sampled", dict(V=400000, nnz=25_000_000), 300),
+    "zipf_v2m_d128": ("zipf_sampled", dict(V=2_000_000, nnz=25_000_000), 128),      # configs[4], per-GPU shard
 }
 
 
