@@ -201,7 +201,10 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
 #pragma unroll
             for (int a = 0; a < U; ++a) {
                 load_row_fast<LPR, NV, FULL>(c[a], C, col[a], d4, lg);
-                bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(bc) + (uint32_t)col[a] * 4u);
+                // the col bias enters the dot once, through lane 0 of the group (a masked 1-lane-per-group load
+                // instead of a 64-lane gather of the same 4 bytes), and the butterfly spreads it
+                bcv[a] = 0.f;
+                if (lg == 0) bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(bc) + (uint32_t)col[a] * 4u);
             }
             float dp[U], cc[U];
 #pragma unroll
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
                 dp[a] = 0.f; cc[a] = 0.f;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) { dp[a] += dot4(r[k], c[a][k]); cc[a] += dot4(c[a][k], c[a][k]); }
+                dp[a] += bcv[a];                                     // non-zero in lane 0 only
             }
             // the U butterflies are independent: stage by stage so the DPP hazards overlap
 #pragma unroll
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
 #pragma unroll
             for (int a = 0; a < U; ++a) {
                 const float valid = (q0 + a < n) ? 1.0f : 0.f;
-                const float diff = (dp[a] + bg) + (bcv[a] - yq[a]);
+                const float diff = (dp[a] + bg) - yq[a];
                 const float e = w2[a] * diff;                       // 0 on tail slots
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
