@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
 #pragma unroll
                 for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 32, 64);
             }
-            float e_mine = 0.f;
+            constexpr int ES = (U + LPR - 1) / LPR;          // pairs of this trip whose e a lane keeps
+            float e_mine[ES];
+#pragma unroll
+            for (int x = 0; x < ES; ++x) e_mine[x] = 0.f;
 #pragma unroll
             for (int a = 0; a < U; ++a) {
                 const float valid = (q0 + a < n) ? 1.0f : 0.f;
@@ -245,9 +248,13 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
                 ed += e * diff;
                 cc_sum += valid * cc[a];
                 bsq += valid * bcv[a] * bcv[a];
-                e_mine = (lg == (a % LPR)) ? e : e_mine;            // lane a keeps pair q0+a's e (U <= LPR)
+                e_mine[a / LPR] = (lg == (a % LPR)) ? e : e_mine[a / LPR];   // lane a % LPR keeps pair q0+a's e
             }
-            if (lg < U && q0 + lg < n) e_col[fld[grp][3][q0 + lg]] = e_mine;   // col-sorted slot, for colpass
+#pragma unroll
+            for (int x = 0; x < ES; ++x) {
+                const int q = q0 + lg + x * LPR;               // col-sorted slot, for colpass
+                if (lg + x * LPR < U && q < n) e_col[fld[grp][3][q]] = e_mine[x];
+            }
         }
         GLOVE_STAMP(3);                     // all partner-row trips issued and consumed
         store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
