@@ -349,3 +349,79 @@ def test_row_sharded_pieces_on_one_gpu(hip):
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(getattr(a, n), getattr(b, n)), n
     assert torch.equal(a.scalars, b.scalars)
+
+
+EDGE_CASES = [
+    # (B, V, d, cap)  — degenerate shapes the reference's data can produce
+    (1, 2, 4, 1), (5, 2, 4, 32), (64, 3, 4, 1), (1000, 7, 12, 1), (4096, 4096, 64, 32), (2000, 2, 64, 16),
+    (513, 1000, 20, 7),
+]
+
+
+@pytest.mark.parametrize("B,V,d,cap", EDGE_CASES)
+def test_adagrad_edge_shapes(hip, B, V, d, cap):
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B + 5 * V + d, B, V, zipf=(V > 3))
+    if V == 4096:                                       # every id exactly once on each side
+        row = np.random.default_rng(0).permutation(V).astype(np.int32)
+        col = ((row.astype(np.int64) * 7 + 1) % V).astype(np.int32)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    want = ref.build_plan(row, col, cap)
+    np.testing.assert_array_equal(plan.counts.cpu().numpy(), want["counts"])
+    loss_out = torch.zeros(4, device="cuda:0")
+    for _ in range(2):
+        hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+        loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss_out[0].item(), loss, rtol=2e-5)
+    assert_tables_close(dt, t, 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("workload,B", [("text8_d64", 131072), ("zipf_v400k_d300", 1048576)])
+def test_full_size_spot_check_against_oracle(hip, workload, B):
+    """BASELINE-size batches: a full float64 oracle step is out of reach (2.4 GB of gathers), so
+    (1) the sparse and the dense (data-parallel) paths must agree bit for bit, (2) rows no pair touches must
+    not move, and (3) for a sample of ids the float64 restatement of exactly their pairs must match."""
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, make_hyper
+    wl = synthetic.make_workload(workload, seed=3, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    row, col, w, y = (wl[k][:B].contiguous() for k in ("row", "col", "w", "y"))
+    a = DeviceTables(V, d, "Adagrad", seed=5)
+    b = DeviceTables(V, d, "Adagrad", seed=5)
+    R0, C0, br0, bc0 = a.R.clone(), a.C.clone(), a.br.clone(), a.bc.clone()
+    lr, l2, m = 0.05, 0.01, 2.0
+    h = make_hyper(learning_rate=lr, batch_size=B)
+    plan = hip.build_plan(row, col, w, y, V, chunk_cap=0, compact=True)
+    hip.step_adagrad(plan, a, h)
+    G = hip.dense_grad_buffer(b)
+    hip.rowpass(plan, b, h); hip.colpass(plan, b, h); hip.dense_grad(plan, b, h, G); hip.dense_adagrad(b, h, G)
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n                       # (1)
+    touched = torch.zeros(V, dtype=torch.bool, device="cuda:0")
+    touched[row.long()] = True
+    assert torch.equal(a.R[~touched], R0[~touched])                               # (2)
+    assert bool((a.R[touched] != R0[touched]).any(dim=1).all())
+    # (3) float64 restatement for sampled row ids (heaviest, lightest and random ones)
+    rid = row.long()
+    cnt = torch.bincount(rid, minlength=V)
+    ids = torch.cat([cnt.argsort(descending=True)[:4], torch.nonzero(cnt == 1)[:4, 0],
+                     torch.nonzero(cnt > 0)[:: max(1, int((cnt > 0).sum()) // 24), 0]]).unique()
+    g = 0.0
+    kappa, kappa_b = 2 * m * l2 / d / B, 2 * m * l2 / B
+    for u in ids.tolist():
+        sel = rid == u
+        c = C0[col[sel].long()].double()
+        r = R0[u].double()
+        p = c @ r + br0[u].double() + bc0[col[sel].long()].double() + g
+        e = 2.0 * w[sel].double() * (p - y[sel].double()) / B
+        n = int(sel.sum())
+        G_u = (e[:, None] * c).sum(0) + kappa * n * r
+        A = 0.1 + G_u ** 2
+        want = r - lr * G_u / (A.sqrt() + 1e-7)
+        np.testing.assert_allclose(a.R[u].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg="row %d" % u)
+        gb = e.sum() + kappa_b * n * br0[u].double()
+        want_b = br0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
+        np.testing.assert_allclose(a.br[u].item(), want_b.item(), rtol=2e-5, atol=1e-6)
