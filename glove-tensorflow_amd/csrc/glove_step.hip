@@ -452,7 +452,9 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
     const int nu_c = wk.nu_c_host >= 0 ? wk.nu_c_host : wk.counts[3];
     const int q_begin = (wk.sides & 1) ? 0 : nu_r;
     const int total = (wk.sides & 2) ? nu_r + nu_c : nu_r;
-    const int lb = blockIdx.x - wk.heavy_blocks, nlb = gridDim.x - wk.heavy_blocks;
+    // the last workgroup of the grid only does the once-per-step scalar work, beside everyone else
+    if (blockIdx.x == gridDim.x - 1) return (wk.sides & 2) != 0;
+    const int lb = blockIdx.x - wk.heavy_blocks, nlb = gridDim.x - wk.heavy_blocks - 1;
     for (int q = q_begin + lb + grp * nlb; q < total; q += nlb * GPB) {
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
@@ -480,7 +482,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
     }
     GLOVE_STAMP(5);
-    return blockIdx.x == gridDim.x - 1 && (wk.sides & 2);     // scalar work goes with the col side
+    return false;
 }
 
 // Deterministic sum of the rowpass block partials by the whole workgroup (thread t takes blocks
@@ -851,7 +853,7 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     const RowShape shape = pick_row_shape(d4);
     IdWork wk = id_work(p);
     wk.sides = sides_of(h);
-    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
@@ -875,7 +877,7 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
     const RowShape shape = pick_row_shape(d4);
     IdWork wk = id_work(p);
     wk.sides = sides_of(h);
-    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
