@@ -80,7 +80,7 @@ __device__ inline void block_partials_store(float (&acc)[kPartials], float *out)
 
 // ---- step workspace layout ----------------------------------------------------------------
 struct StepWs {
-    float *e;        // [B]            per-pair error coefficient e_i, COL-sorted order
+    float *e;        // [B]            per-pair error coefficient e_i, row-sorted order (diagnostics / eval)
     float *gp_r;     // [cap_chunks*d] row-side chunk partial gradient rows
     float *gp_c;     // [cap_chunks*d] col-side
     float *gb_r;     // [cap_chunks]   row-side chunk partial bias gradients (sum e)

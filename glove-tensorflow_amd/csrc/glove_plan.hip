@@ -36,13 +36,17 @@ __global__ void gather_row_side(const int32_t *__restrict__ perm, const int32_t 
 }
 
 // col side: partner = row id of the row-sorted pair the permutation points at; r_to_c = inverse
-__global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ sorted_row, int64_t n,
-                                int32_t *__restrict__ partner, int32_t *__restrict__ r_to_c)
+__global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ sorted_row,
+                                const float *__restrict__ r_w, const float *__restrict__ r_y, int64_t n,
+                                int32_t *__restrict__ partner, int32_t *__restrict__ r_to_c,
+                                float *__restrict__ c_w, float *__restrict__ c_y)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t p = perm[i];
         partner[i] = sorted_row[p];
         r_to_c[p] = (int32_t)i;
+        c_w[i] = r_w[p];
+        c_y[i] = r_y[p];
     }
 }
 
@@ -187,7 +191,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
-        !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->r_to_c || !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
+        !plan->c_w || !plan->c_y || !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->r_to_c || !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
         return GLOVE_E_BADARG;
     if (!plan->heavy || plan->heavy_chunks < 1 ||
         plan->cap_heavy < 2 * B / ((int64_t)plan->heavy_chunks * plan->chunk_cap) + 2)
@@ -219,8 +223,8 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
     HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
                                       plan->c_perm, (size_t)B, 0, bits, st));
-    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, B, plan->c_partner,
-                       plan->r_to_c);
+    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, plan->r_w, plan->r_y, B,
+                       plan->c_partner, plan->r_to_c, plan->c_w, plan->c_y);
     if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
                             plan->c_uniq_slot, plan->c_uniq_rec, plan->cap_uniq, plan->counts + 2, 1, plan, st))
         return rc;

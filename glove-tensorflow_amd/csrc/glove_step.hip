@@ -103,7 +103,15 @@ __device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, f
 }
 
 // ------------------------------------------------------------------------------------------
-// Gather passes (rowpass / colpass): one GROUP of LPR lanes per chunk, 64/LPR chunks per wave.
+// Gather passes: one GROUP of LPR lanes per chunk, 64/LPR chunks per wave, BOTH sides in one launch.
+//
+// The two sides are symmetric and independent.  A row-side chunk (row u, pairs i) gathers the
+// partner rows C[col_i]; a col-side chunk (col v, pairs i) gathers R[row_i].  Either side forms
+// p_i = own . partner + own_bias + partner_bias + g and e_i = 2 w_i (p_i - y_i) / B by itself (the plan
+// carries w, y in both orders), so the col side needs nothing the row side produces: the first
+// blocks of the grid take the row chunks, the rest the col chunks, and a step is TWO dependent kernels
+// (passes -> apply) instead of three.  The second dot product per pair is cheap next to a kernel
+// boundary in the latency-bound regime (B = 131072, d = 64: 9.7 + 7.5 us as two kernels, ~10 us fused).
 //
 // The step is latency-bound at realistic batch sizes (a few pairs per lane over the whole chip), so
 // a chunk is a short dependent chain  descriptor -> pair fields -> partner rows:
@@ -114,68 +122,81 @@ __device__ inline void adam_vec(f4 &Wv, f4 &M, f4 &Vv, const f4 g, float lr_t, f
 //   * groups are 8 lanes wide at d <= 64 (8 lanes x 2 float4 = one 128-B line per load), so a wave
 //     carries 8 chunks and the per-pair bookkeeping (addresses, DPP butterfly, diff, e) is issued
 //     once for 8 pairs;
-//   * chunks are dealt to groups round-robin over the grid so the full-length chunks of the Zipf head
-//     do not pile up in a few workgroups.
-// Measured in-process (tools/ab_kernels.py) against two earlier forms: a wave per chunk (-40 %) and
-// per-pair ds_bpermute broadcasts on 16-lane groups (-7 % at B = 131072, -20 % at B = 1048576, d = 64).
+//   * chunks are dealt to groups round-robin over the side's blocks so the full-length chunks of the
+//     Zipf head do not pile up in a few workgroups.
+// Measured in-process (tools/ab_kernels.py) against earlier forms: a wave per chunk (-40 %), per-pair
+// ds_bpermute broadcasts on 16-lane groups (-7 % at B = 131072, -20 % at B = 1048576, d = 64).
 // kChunkMax bounds chunk_cap.
 // ------------------------------------------------------------------------------------------
 constexpr int kChunkMax = 32;
 constexpr int kFieldStride = kChunkMax + 4;      // dwords; +16 B staggers the groups over the LDS banks
 
-template <int NV> struct PassUnroll { static constexpr int value = NV <= 2 ? 8 : 4; };
+// partner rows in flight per group, and the occupancy the register allocator is held to.  With both sides
+// in one launch the grid at B = 131072, d = 64 is ~3700 waves: U = 4 + 4 waves/SIMD keeps all of them
+// resident at once (A/B in-process: 12.1 us vs 13.8 us for U = 8 at 2 waves/SIMD; 42.9 vs 45.5 us at B = 1 M).
+template <int NV> struct PassUnroll { static constexpr int value = NV == 1 ? 8 : 4; };
+template <int LPR> struct PassWaves { static constexpr int value = LPR == 8 ? 4 : 1; };
+
+struct PassSide {
+    const int32_t *partner;        // [B] id of the other side's row, this side's sorted order
+    const float *w, *y;            // [B] glove_weight / glove_value in the same order
+    const int32_t *chunk_id, *chunk_start;
+    const float *own, *other;      // own table (rows of this side's ids) / partner table
+    const float *own_bias, *other_bias;
+    float *gp, *gb;                // per-chunk partial gradient rows / bias gradients of this side
+    float *e_out;                  // optional [B]: e_i in this side's order (row side: diagnostics, eval)
+    int n_host;                    // chunks of this side if known on the host, else -1
+    int count_index;               // counts[0] (row) or counts[2] (col)
+};
 
 template <int LPR, int NV, bool FULL>
-__global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
-    const int32_t *__restrict__ counts, int n_host, const int32_t *__restrict__ partner,
-    const float *__restrict__ w, const float *__restrict__ y, const int32_t *__restrict__ r_to_c,
-    const int32_t *__restrict__ chunk_id, const int32_t *__restrict__ chunk_start,
-    const float *__restrict__ R, const float *__restrict__ C,
-    const float *__restrict__ br, const float *__restrict__ bc,
-    const float *__restrict__ scalars, int64_t *__restrict__ step,
-    int d4, float inv_batch,
-    float *__restrict__ e_col, float *__restrict__ gp, float *__restrict__ gb,
+__global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel(
+    const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
+    const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart)
 {
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
     static_assert(U % 4 == 0, "fields are read back four pairs at a time");
-    // [group][field][pair]: 0 partner, 1 w2 = 2 w inv_batch, 2 y, 3 e slot in col order
-    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][4][kFieldStride];
+    // [group][field][pair]: 0 partner, 1 w2 = 2 w inv_batch, 2 y
+    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][3][kFieldStride];
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
+    const bool is_row = (int)blockIdx.x < row_blocks;
+    const PassSide &sd = is_row ? rowside : colside;
+    const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
+    const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
     GLOVE_STAMP(0);
-    const int n_chunks = n_host >= 0 ? n_host : counts[0];
+    const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
+    if (is_row && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
 
-    // loss partials: [0] sum e diff (= 2 inv_batch sum w diff^2), [1] sum |r|^2+|c|^2, [2] sum b^2, [3] sum e
+    // loss partials (row side only): [0] sum e diff (= 2 inv_batch sum w diff^2), [1] sum |r|^2+|c|^2,
+    // [2] sum b^2, [3] sum e
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
-        const int32_t u = chunk_id[j];
-        const int s = chunk_start[j];
-        const int n = chunk_start[j + 1] - s;
+    for (int j = bid + grp * nblk; j < n_chunks; j += nblk * GPB) {
+        const int32_t u = sd.chunk_id[j];
+        const int s = sd.chunk_start[j];
+        const int n = sd.chunk_start[j + 1] - s;
         GLOVE_DRAIN(); GLOVE_STAMP(1);      // descriptor arrived
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
             const int t = lg + sl * LPR;
             const int k = s + (t < n ? t : 0);
-            const int32_t pv = partner[k];
-            const int32_t ev = r_to_c[k];
-            const float wv = w[k];
-            const float yv = y[k];
+            const int32_t pv = sd.partner[k];
+            const float wv = sd.w[k];
+            const float yv = sd.y[k];
             if (t < kChunkMax) {
                 fld[grp][0][t] = (uint32_t)pv;
                 fld[grp][1][t] = __float_as_uint(t < n ? 2.0f * inv_batch * wv : 0.f);   // tail slots weigh 0
                 fld[grp][2][t] = __float_as_uint(yv);
-                fld[grp][3][t] = (uint32_t)ev;
             }
         }
         f4 r[NV], acc[NV];
-        load_row<LPR, NV>(r, R, u, d4, lg);
-        const float bg = br[u] + g;
+        load_row<LPR, NV>(r, sd.own, u, d4, lg);
+        const float bg = sd.own_bias[u] + g;
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
         float se = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
@@ -200,11 +221,11 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
             float bcv[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
-                load_row_fast<LPR, NV, FULL>(c[a], C, col[a], d4, lg);
-                // the col bias enters the dot once, through lane 0 of the group (a masked 1-lane-per-group load
-                // instead of a 64-lane gather of the same 4 bytes), and the butterfly spreads it
+                load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                // the partner bias enters the dot once, through lane 0 of the group (a masked 1-lane-per-group
+                // load instead of a 64-lane gather of the same 4 bytes), and the butterfly spreads it
                 bcv[a] = 0.f;
-                if (lg == 0) bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(bc) + (uint32_t)col[a] * 4u);
+                if (lg == 0) bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sd.other_bias) + (uint32_t)col[a] * 4u);
             }
             float dp[U], cc[U];
 #pragma unroll
@@ -250,88 +271,36 @@ __global__ __launch_bounds__(kBlock) void rowpass_lds_kernel(
                 bsq += valid * bcv[a] * bcv[a];
                 e_mine[a / LPR] = (lg == (a % LPR)) ? e : e_mine[a / LPR];   // lane a % LPR keeps pair q0+a's e
             }
+            if (sd.e_out) {
 #pragma unroll
-            for (int x = 0; x < ES; ++x) {
-                const int q = q0 + lg + x * LPR;               // col-sorted slot, for colpass
-                if (lg + x * LPR < U && q < n) e_col[fld[grp][3][q]] = e_mine[x];
+                for (int x = 0; x < ES; ++x) {
+                    const int q = q0 + lg + x * LPR;
+                    if (lg + x * LPR < U && q < n) sd.e_out[s + q] = e_mine[x];
+                }
             }
         }
         GLOVE_STAMP(3);                     // all partner-row trips issued and consumed
-        store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
-        float rr = 0.f;
+        store_row<LPR, NV>(sd.gp, (size_t)j, d4, lg, acc);
+        if (lg == 0) sd.gb[j] = se;
+        if (is_row) {
+            float rr = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
-        part[1] += cc_sum + (float)n * rr;
-        if (lg == 0) {
-            gb[j] = se;
-            const float bru = bg - g;
-            part[0] += ed;
-            part[2] += bsq + (float)n * bru * bru;
-            part[3] += se;
+            for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
+            part[1] += cc_sum + (float)n * rr;
+            if (lg == 0) {
+                const float bru = bg - g;
+                part[0] += ed;
+                part[2] += bsq + (float)n * bru * bru;
+                part[3] += se;
+            }
         }
     }
     GLOVE_DRAIN(); GLOVE_STAMP(4);          // stores retired
-    part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
-    block_partials_store(part, blockpart);
-    GLOVE_DRAIN(); GLOVE_STAMP(5);
-}
-
-template <int LPR, int NV, bool FULL>
-__global__ __launch_bounds__(kBlock) void colpass_lds_kernel(
-    const int32_t *__restrict__ counts, int n_host, const int32_t *__restrict__ partner,
-    const int32_t *__restrict__ chunk_start,
-    const float *__restrict__ R, const float *__restrict__ e_col, int d4,
-    float *__restrict__ gp, float *__restrict__ gb)
-{
-    constexpr int GPB = kBlock / LPR;
-    constexpr int U = PassUnroll<NV>::value;
-    constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;
-    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][2][kFieldStride];
-    const int lg = threadIdx.x % LPR;
-    const int grp = threadIdx.x / LPR;
-    const int n_chunks = n_host >= 0 ? n_host : counts[2];
-    for (int j = blockIdx.x + grp * gridDim.x; j < n_chunks; j += gridDim.x * GPB) {
-        const int s = chunk_start[j];
-        const int n = chunk_start[j + 1] - s;
-#pragma unroll
-        for (int sl = 0; sl < SL; ++sl) {
-            const int t = lg + sl * LPR;
-            const int k = s + (t < n ? t : 0);
-            const int32_t pv = partner[k];
-            const float ev = e_col[k];
-            if (t < kChunkMax) {
-                fld[grp][0][t] = (uint32_t)pv;
-                fld[grp][1][t] = __float_as_uint(t < n ? ev : 0.f);
-            }
-        }
-        f4 acc[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
-        float se = 0.f;
-        for (int q0 = 0; q0 < n; q0 += U) {
-            int32_t rid[U];
-            float eq[U];
-#pragma unroll
-            for (int a4 = 0; a4 < U; a4 += 4) {
-                const uint4 pr = *reinterpret_cast<const uint4 *>(&fld[grp][0][q0 + a4]);
-                const uint4 pe = *reinterpret_cast<const uint4 *>(&fld[grp][1][q0 + a4]);
-                rid[a4] = (int32_t)pr.x; rid[a4 + 1] = (int32_t)pr.y; rid[a4 + 2] = (int32_t)pr.z; rid[a4 + 3] = (int32_t)pr.w;
-                eq[a4] = __uint_as_float(pe.x); eq[a4 + 1] = __uint_as_float(pe.y);
-                eq[a4 + 2] = __uint_as_float(pe.z); eq[a4 + 3] = __uint_as_float(pe.w);
-            }
-            f4 r[U][NV];
-#pragma unroll
-            for (int a = 0; a < U; ++a) load_row_fast<LPR, NV, FULL>(r[a], R, rid[a], d4, lg);
-#pragma unroll
-            for (int a = 0; a < U; ++a) {
-#pragma unroll
-                for (int k = 0; k < NV; ++k) acc[k] += eq[a] * r[a][k];
-                se += eq[a];
-            }
-        }
-        store_row<LPR, NV>(gp, (size_t)j, d4, lg, acc);
-        if (lg == 0) gb[j] = se;
+    if (is_row) {                           // block-uniform
+        part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
+        block_partials_store(part, blockpart);
     }
+    GLOVE_DRAIN(); GLOVE_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -704,7 +673,7 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
-                     !p->heavy || p->heavy_chunks < 1 || !p->r_uniq_rec || !p->c_uniq_rec || !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+                     !p->heavy || p->heavy_chunks < 1 || !p->c_w || !p->c_y || !p->r_uniq_rec || !p->c_uniq_rec || !p->r_to_c || !p->c_partner || !p->c_perm || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
@@ -799,47 +768,66 @@ size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *off
     return (size_t)L.total;
 }
 
-int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
-                      void *stream)
+static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row)
+{
+    PassSide sd;
+    sd.partner = row ? p->r_partner : p->c_partner;
+    sd.w = row ? p->r_w : p->c_w;
+    sd.y = row ? p->r_y : p->c_y;
+    sd.chunk_id = row ? p->r_chunk_id : p->c_chunk_id;
+    sd.chunk_start = row ? p->r_chunk_start : p->c_chunk_start;
+    sd.own = row ? t->R : t->C;
+    sd.other = row ? t->C : t->R;
+    sd.own_bias = row ? t->br : t->bc;
+    sd.other_bias = row ? t->bc : t->br;
+    sd.gp = row ? w.gp_r : w.gp_c;
+    sd.gb = row ? w.gb_r : w.gb_c;
+    sd.e_out = row ? w.e : nullptr;
+    sd.n_host = p->host_counts[row ? 0 : 2];
+    sd.count_index = row ? 0 : 2;
+    return sd;
+}
+
+// which: 1 = row side, 2 = col side, 3 = both in one launch
+static int launch_passes(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                         void *stream, int which)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pass_shape(d4);
-    const int nb = rowpass_blocks(p, shape.lpr);
+    const int nb_side = rowpass_blocks(p, shape.lpr);
+    const int row_blocks = (which & 1) ? nb_side : 0;
+    const int nb = row_blocks + ((which & 2) ? nb_side : 0);
+    const PassSide rs = pass_side(p, t, w, true), cs = pass_side(p, t, w, false);
     hipStream_t st = (hipStream_t)stream;
-    const int32_t *hc = p->host_counts;
-#define ARGS p->counts, hc[0], p->r_partner, p->r_w, p->r_y, p->r_to_c, p->r_chunk_id, p->r_chunk_start, t->R, t->C, \
-             t->br, t->bc, t->scalars, t->step, d4, h->inv_batch, w.e, w.gp_r, w.gb_r, w.blockpart
-#define CALL(LPR, NV)                                                                                       \
-    if (LPR * NV == d4) hipLaunchKernelGGL((rowpass_lds_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else hipLaunchKernelGGL((rowpass_lds_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
-        GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
+#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart
+#define CALL(LPR, NV)                                                                                      \
+    if (LPR * NV == d4) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+    GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
 #undef ARGS
     return (int)hipGetLastError();
 }
 
+int glove_passes_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                     void *stream)
+{
+    return launch_passes(p, t, h, ws, ws_bytes, stream, 3);
+}
+
+int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                      void *stream)
+{
+    return launch_passes(p, t, h, ws, ws_bytes, stream, 1);
+}
+
 int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                       void *stream)
 {
-    if (int rc = check_common(p, t, h, ws)) return rc;
-    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
-    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
-    const int d4 = t->d / 4;
-    const RowShape shape = pass_shape(d4);
-    const int nb = rowpass_blocks(p, shape.lpr);
-    hipStream_t st = (hipStream_t)stream;
-    const int32_t *hc = p->host_counts;
-#define ARGS p->counts, hc[2], p->c_partner, p->c_chunk_start, t->R, w.e, d4, w.gp_c, w.gb_c
-#define CALL(LPR, NV)                                                                                  \
-    if (LPR * NV == d4) hipLaunchKernelGGL((colpass_lds_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else hipLaunchKernelGGL((colpass_lds_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
-        GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
-#undef CALL
-#undef ARGS
-    return (int)hipGetLastError();
+    return launch_passes(p, t, h, ws, ws_bytes, stream, 2);
 }
 
 int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
@@ -939,16 +927,14 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
 int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                            float *loss_out, void *stream)
 {
-    if (int rc = glove_rowpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
-    if (int rc = glove_colpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
     return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
 }
 
 int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                         float *G_flat, float *loss_out, void *stream)
 {
-    if (int rc = glove_rowpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
-    if (int rc = glove_colpass_f32(p, t, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
     if (int rc = glove_dense_grad_f32(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
     return glove_dense_adam_f32(t, h, G_flat, loss_out, stream);
 }

@@ -30,7 +30,7 @@ def auto_chunk_cap(B: int, V: int) -> int:
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
     "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_step_workspace_bytes",
-    "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
+    "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
@@ -59,7 +59,7 @@ class GlovePlan(C.Structure):
                 ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 8),
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
-                ("c_partner", _fp), ("c_perm", _fp),
+                ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp)]
 
 
@@ -88,6 +88,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_plan_workspace_bytes": (sz, [i64, i32]),
         "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
         "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
+        "glove_passes_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_rowpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_colpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_apply_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
@@ -242,6 +243,7 @@ class Plan:
         self.heavy = torch.zeros(self.cap_heavy, **i32)
         self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
+        self.c_w, self.c_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
         self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
         self.r_uniq_slot, self.c_uniq_slot = (torch.zeros(self.cap_uniq + 1, **i32) for _ in range(2))
@@ -257,6 +259,7 @@ class Plan:
             for i in range(8):
                 s.host_counts[i] = self.host_counts[i]
             s.r_w, s.r_y = _ptr(self.r_w), _ptr(self.r_y)
+            s.c_w, s.c_y = _ptr(self.c_w), _ptr(self.c_y)
             for n in self.INT_FIELDS:
                 setattr(s, n, _ptr(getattr(self, n)))
             self._struct = s
@@ -273,7 +276,7 @@ class Plan:
         out.heavy_chunks, out.cap_heavy = self.heavy_chunks, max(n_heavy, 1)
         out.heavy = self.heavy[:max(n_heavy, 1)].clone()
         out.r_partner, out.r_w, out.r_y, out.r_to_c = self.r_partner, self.r_w, self.r_y, self.r_to_c
-        out.c_partner, out.c_perm = self.c_partner, self.c_perm
+        out.c_partner, out.c_perm, out.c_w, out.c_y = self.c_partner, self.c_perm, self.c_w, self.c_y
         out.r_chunk_id = self.r_chunk_id[:max(out.cap_chunks, 1)].clone()
         out.c_chunk_id = self.c_chunk_id[:max(out.cap_chunks, 1)].clone()
         out.r_chunk_start = self.r_chunk_start[:out.cap_chunks + 1].clone()
@@ -286,7 +289,7 @@ class Plan:
         return out
 
     def nbytes(self) -> int:
-        return sum(getattr(self, n).numel() * 4 for n in self.INT_FIELDS + ("r_w", "r_y", "counts"))
+        return sum(getattr(self, n).numel() * 4 for n in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts"))
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
@@ -333,6 +336,12 @@ class GloveHip:
         return plan.compact() if compact else plan
 
     # ---- passes
+    def passes(self, plan, tables, hyper, ws=None):
+        """Both gather passes (row side and col side) in one launch."""
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_passes_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                         _ptr(ws), ws.numel(), _stream()), "glove_passes_f32")
+
     def rowpass(self, plan, tables, hyper, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
         _check(self.lib.glove_rowpass_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),

@@ -41,8 +41,7 @@ class HipBackend:
         self.hip.step_adagrad(plan, tables, hyper, loss_out)
 
     def local_dense_grad(self, plan, tables, hyper, G):
-        self.hip.rowpass(plan, tables, hyper)
-        self.hip.colpass(plan, tables, hyper)
+        self.hip.passes(plan, tables, hyper)
         self.hip.dense_grad(plan, tables, hyper, G)
 
     def apply_dense(self, tables, hyper, G, loss_out):
@@ -53,8 +52,7 @@ class HipBackend:
 
     # ---- pieces of the row-sharded step (hyper.sides selects the side)
     def passes(self, plan, tables, hyper):
-        self.hip.rowpass(plan, tables, hyper)
-        self.hip.colpass(plan, tables, hyper)
+        self.hip.passes(plan, tables, hyper)
 
     def apply_sparse(self, plan, tables, hyper):
         self.hip.apply_adagrad(plan, tables, hyper)

@@ -91,8 +91,7 @@ typedef struct glove_plan {
     int32_t *r_partner;         /* [B] col id of pair k */
     float   *r_w;               /* [B] glove_weight */
     float   *r_y;               /* [B] glove_value  */
-    int32_t *r_to_c;            /* [B] col-side position of pair k (inverse of c_perm): where
-                                 * rowpass drops e_k so that colpass reads it in order */
+    int32_t *r_to_c;            /* [B] col-side position of pair k (inverse of c_perm) */
     int32_t *r_chunk_id;        /* [cap_chunks]   row id of the chunk */
     int32_t *r_chunk_start;     /* [cap_chunks+1] first pair of the chunk; [chunks] = B */
     int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
@@ -101,6 +100,8 @@ typedef struct glove_plan {
     /* col side: position k = k-th row-sorted pair in (col id, row-sorted position) order */
     int32_t *c_partner;         /* [B] row id */
     int32_t *c_perm;            /* [B] row-sorted position of the pair */
+    float   *c_w;               /* [B] glove_weight, col-sorted order (the col side forms e_i by itself) */
+    float   *c_y;               /* [B] glove_value,  col-sorted order */
     int32_t *c_chunk_id;
     int32_t *c_chunk_start;
     int32_t *c_uniq_slot;
@@ -126,10 +127,14 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
 size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d);
 
 /* ---- fused forward + gradient passes (model_utils.py:41-54, estimator.py:48-56, autodiff) --
- * rowpass: per pair p = r.c + br + bc + g, e = 2 w (p - y) inv_batch, loss partials, and the
- *          row-side per-chunk sums  sum_i e_i C[col_i]  /  sum_i e_i.
- * colpass: col-side per-chunk sums  sum_i e_i R[row_i]  /  sum_i e_i.
- * Neither modifies the tables. */
+ * Per pair p = r.c + br + bc + g, e = 2 w (p - y) inv_batch; then
+ *   row side: loss partials and the per-chunk sums  sum_i e_i C[col_i]  /  sum_i e_i   (advances global_step)
+ *   col side: the per-chunk sums  sum_i e_i R[row_i]  /  sum_i e_i
+ * The sides are independent (each forms e_i itself): glove_passes_f32 runs both in ONE launch, which
+ * is what the step functions use; glove_rowpass_f32 / glove_colpass_f32 run one side each.
+ * None of them modifies the tables. */
+int glove_passes_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                     void *ws, size_t ws_bytes, void *stream);
 int glove_rowpass_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                       void *ws, size_t ws_bytes, void *stream);
 int glove_colpass_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,

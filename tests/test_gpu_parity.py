@@ -41,6 +41,8 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(plan.r_uniq_slot.cpu().numpy()[:nu_r + 1], want["r_uniq_slot"])
     np.testing.assert_array_equal(plan.c_perm.cpu().numpy()[:B], want["c_perm"])
     np.testing.assert_array_equal(plan.r_to_c.cpu().numpy()[:B], want["r_to_c"])
+    np.testing.assert_array_equal(plan.c_w.cpu().numpy()[:B], w[want["perm_r"]][want["c_perm"]])
+    np.testing.assert_array_equal(plan.c_y.cpu().numpy()[:B], y[want["perm_r"]][want["c_perm"]])
     np.testing.assert_array_equal(plan.c_partner.cpu().numpy()[:B], want["c_partner"])
     np.testing.assert_array_equal(plan.c_chunk_id.cpu().numpy()[:nc_c], want["c_chunk_id"])
     np.testing.assert_array_equal(plan.c_chunk_start.cpu().numpy()[:nc_c + 1], want["c_chunk_start"])
@@ -96,10 +98,10 @@ def test_per_pair_error_coefficients(hip):
     ws = hip.step_workspace(plan, d)
     hip.rowpass(plan, dt, _hyper(hp, B), ws)
     torch.cuda.synchronize()
-    e_dev = ws[:4 * B].view(torch.float32).cpu().numpy()     # first array of the workspace, col-sorted order
+    e_dev = ws[:4 * B].view(torch.float32).cpu().numpy()     # first array of the workspace, row-sorted order
     gr = ref.gradients(t, row, col, w, y, hp)
     want = ref.build_plan(row, col, 32)
-    np.testing.assert_allclose(e_dev, gr["e"][want["perm_r"]][want["c_perm"]], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(e_dev, gr["e"][want["perm_r"]], rtol=1e-5, atol=1e-7)
     assert dt.global_step == 1          # rowpass advances global_step
 
 

@@ -39,14 +39,15 @@ def main():
         for v in [int(x) for x in args.variants.split(",")]:
             configs.append((cap, v, plans))
     ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
-    res = {(c, v): {"rowpass": [], "colpass": [], "apply": [], "step": []} for c, v, _ in configs}
+    res = {(c, v): {"rowpass": [], "colpass": [], "passes": [], "apply": [], "step": []} for c, v, _ in configs}
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for rnd in range(args.rounds + 1):
         for cap, v, plans in configs:
             if set_variant is not None:
                 set_variant(v)
-            for name in ("rowpass", "colpass", "apply", "step"):
+            for name in ("rowpass", "colpass", "passes", "apply", "step"):
                 fn = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws),
+                      "passes": lambda p: hip.passes(p, tables, hyper, ws),
                       "colpass": lambda p: hip.colpass(p, tables, hyper, ws),
                       "apply": lambda p: hip.apply_adagrad(p, tables, hyper, loss, ws),
                       "step": lambda p: hip.step_adagrad(p, tables, hyper, loss, ws)}[name]

@@ -27,7 +27,7 @@ python tools/pmc_traffic.py $raw/fetch $raw/write $out/${tag}_${name}_traffic.js
 {
   echo "# rocprofv3 --pmc (separate passes; no trace domains), per-kernel averages per dispatch ($tag, text8_d64 B=131072)"
   for d in fetch write sq; do
-    python tools/pmc_summary.py $raw/$d "glove::rowpass"; python tools/pmc_summary.py $raw/$d "glove::colpass"; python tools/pmc_summary.py $raw/$d "glove::apply"
+    python tools/pmc_summary.py $raw/$d "glove::sidepass"; python tools/pmc_summary.py $raw/$d "glove::apply"
   done
 } > $out/${tag}_${name}_pmc.txt
 ls -la $out

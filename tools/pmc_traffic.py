@@ -24,7 +24,7 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     meta = dict(kv.split("=", 1) for kv in sys.argv[4:])
     out = {"meta": meta, "kernels": {}}
-    step = ("rowpass", "colpass", "apply_adagrad")          # the three kernels of one sparse-Adagrad step
+    step = ("sidepass", "rowpass", "colpass", "apply_adagrad")          # the kernels of one sparse-Adagrad step
     total = 0.0
     for k in sorted(set(fetch) | set(write)):
         rd, wr = 2.0 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024

@@ -61,11 +61,11 @@ def main():
             hip.step_adagrad(p, tables, hyper, loss, ws)
     torch.cuda.synchronize()
     assert hip.lib.glove_debug_set_stamps(stamps.data_ptr()) == 0
-    for name, fn, ns in (("rowpass", lambda: hip.rowpass(plans[0], tables, hyper, ws), 6),
+    for name, fn, ns in (("passes", lambda: hip.passes(plans[0], tables, hyper, ws), 6),
                          ("apply", lambda: hip.apply_adagrad(plans[0], tables, hyper, loss, ws), 7)):
         if name == "apply":
             hip.lib.glove_debug_set_stamps(None)
-            hip.rowpass(plans[0], tables, hyper, ws); hip.colpass(plans[0], tables, hyper, ws)
+            hip.passes(plans[0], tables, hyper, ws)
             torch.cuda.synchronize()
             hip.lib.glove_debug_set_stamps(stamps.data_ptr())
         stamps.zero_()
