@@ -190,9 +190,11 @@ def main():
         hyper_cols = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, sides=2)
         G_col_half = G[hip.grad_layout(tables)["G_C"]:]
 
+    staging = hip.build_plan(*batches[0], V, chunk_cap=cap) if args.dynamic else None   # refilled every step
+
     def step(i):
         bt = batches[i % nb]
-        plan = hip.build_plan(*bt, V, chunk_cap=cap) if args.dynamic else plans[i % nb]
+        plan = hip.build_plan(*bt, V, chunk_cap=cap, into=staging) if args.dynamic else plans[i % nb]
         if adam:
             hip.step_adam(plan, tables, hyper, G, loss_out, ws)
         elif not dense:

@@ -324,12 +324,21 @@ class GloveHip:
         return self._ws("_step_ws", self.lib.glove_step_workspace_bytes(plan.B, plan.cap_chunks, d))
 
     # ---- index build
-    def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False) -> Plan:
+    def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
+                   into: Plan | None = None) -> Plan:
+        """Builds the dedup index of one batch on the device.  `into`: a full-capacity Plan of the same
+        (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
+        allocations per step this way."""
         _require_cuda(row, col, w, y)
         B = int(row.numel())
         if not chunk_cap:
             chunk_cap = auto_chunk_cap(B, V)
-        plan = Plan(B, V, chunk_cap, row.device)
+        if into is not None:
+            if (into.B, into.V, into.chunk_cap) != (B, V, chunk_cap) or into.cap_chunks < B:
+                raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
+            plan = into
+        else:
+            plan = Plan(B, V, chunk_cap, row.device)
         ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
