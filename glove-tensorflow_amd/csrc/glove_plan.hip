@@ -16,6 +16,11 @@
 
 namespace glove {
 
+// glove_plan_small.hip: one-workgroup build for batches of at most kSmallPlanMax pairs
+constexpr int kSmallPlanMax = 4096;
+int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+                     const glove_plan *plan, hipStream_t st);
+
 __global__ void iota_kernel(int32_t *out, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -196,9 +201,10 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (!plan->heavy || plan->heavy_chunks < 1 ||
         plan->cap_heavy < 2 * B / ((int64_t)plan->heavy_chunks * plan->chunk_cap) + 2)
         return GLOVE_E_WORKSPACE;
-    HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
     // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
+    if (B <= kSmallPlanMax) return plan_build_small(row, col, w, y, B, plan, st);     // launch-bound regime
+    HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
     const PlanWs pw = carve_plan_ws(ws, B);
     if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
 
