@@ -111,6 +111,47 @@ __global__ void emit_uniq_rec(const int32_t *__restrict__ counts, const int32_t 
     }
 }
 
+// per-chunk records: one thread per (chunk, float4 of the record)
+__global__ void fill_records(const int32_t *__restrict__ counts, int count_index, const int32_t *__restrict__ chunk_id,
+                             const int32_t *__restrict__ chunk_start, const int32_t *__restrict__ partner,
+                             const float *__restrict__ w, const float *__restrict__ y, int capP,
+                             int32_t *__restrict__ crec)
+{
+    const int n_chunks = counts[count_index];
+    const int rq = 1 + 3 * capP / 4;                       // float4 per record
+    const int64_t total = (int64_t)n_chunks * rq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i / rq), f = (int)(i - (int64_t)j * rq);
+        const int s = chunk_start[j], n = chunk_start[j + 1] - s;
+        int4 v;
+        if (f == 0) {
+            v = make_int4(chunk_id[j], n, s, 0);
+        } else {
+            const int field = (f - 1) / (capP / 4), t0 = ((f - 1) % (capP / 4)) * 4;
+            int o[4];
+            for (int x = 0; x < 4; ++x) {
+                const int t = t0 + x;
+                const int k = s + (t < n ? t : 0);              // padding replays pair 0 with weight 0
+                o[x] = field == 0 ? partner[k] : field == 1 ? __float_as_int(t < n ? w[k] : 0.f) : __float_as_int(y[k]);
+            }
+            v = make_int4(o[0], o[1], o[2], o[3]);
+        }
+        reinterpret_cast<int4 *>(crec)[i] = v;
+    }
+}
+
+static int launch_fill_records(const glove_plan *plan, hipStream_t st)
+{
+    const int capP = (plan->chunk_cap + 7) & ~7;      // a trip of the pass kernel reads up to 8 slots from q0
+    const int64_t work = (int64_t)plan->cap_chunks * (1 + 3 * capP / 4);
+    const int nb = blocks_for(work, kBlock);
+    hipLaunchKernelGGL(fill_records, dim3(nb), dim3(kBlock), 0, st, plan->counts, 0, plan->r_chunk_id, plan->r_chunk_start,
+                       plan->r_partner, plan->r_w, plan->r_y, capP, plan->r_crec);
+    hipLaunchKernelGGL(fill_records, dim3(nb), dim3(kBlock), 0, st, plan->counts, 2, plan->c_chunk_id, plan->c_chunk_start,
+                       plan->c_partner, plan->c_w, plan->c_y, capP, plan->c_crec);
+    return (int)hipGetLastError();
+}
+
 struct PlanWs {
     int32_t *iota, *perm, *keys_sorted, *row_sorted, *run_start;
     uint64_t *flags, *scanned;
@@ -203,7 +244,11 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
         return GLOVE_E_WORKSPACE;
     // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
-    if (B <= kSmallPlanMax) return plan_build_small(row, col, w, y, B, plan, st);     // launch-bound regime
+    if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
+    if (B <= kSmallPlanMax) {                                                          // launch-bound regime
+        if (int rc = plan_build_small(row, col, w, y, B, plan, st)) return rc;
+        return plan->r_crec ? launch_fill_records(plan, st) : 0;
+    }
     HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
     const PlanWs pw = carve_plan_ws(ws, B);
     if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
@@ -234,7 +279,18 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
                             plan->c_uniq_slot, plan->c_uniq_rec, plan->cap_uniq, plan->counts + 2, 1, plan, st))
         return rc;
+    if (plan->r_crec) return launch_fill_records(plan, st);
     return (int)hipGetLastError();
+}
+
+int glove_plan_fill_records(const glove_plan *plan, void *stream)
+{
+    if (!plan || !plan->r_crec || !plan->c_crec || !plan->counts || plan->chunk_cap <= 0) return GLOVE_E_BADARG;
+    if (plan->B == 0) return 0;
+    if (!plan->r_chunk_id || !plan->r_chunk_start || !plan->r_partner || !plan->r_w || !plan->r_y || !plan->c_chunk_id ||
+        !plan->c_chunk_start || !plan->c_partner || !plan->c_w || !plan->c_y)
+        return GLOVE_E_BADARG;
+    return launch_fill_records(plan, (hipStream_t)stream);
 }
 
 }  // extern "C"

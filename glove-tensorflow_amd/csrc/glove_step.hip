@@ -134,6 +134,8 @@ constexpr int kFieldStride = kChunkMax + 4;      // dwords; +16 B staggers the g
 // partner rows in flight per group, and the occupancy the register allocator is held to.  With both sides
 // in one launch the grid at B = 131072, d = 64 is ~3700 waves: U = 4 + 4 waves/SIMD keeps all of them
 // resident at once (A/B in-process: 12.1 us vs 13.8 us for U = 8 at 2 waves/SIMD; 42.9 vs 45.5 us at B = 1 M).
+__device__ inline int grp_of(int tid, int lpr) { return tid / lpr; }
+
 template <int NV> struct PassUnroll { static constexpr int value = NV == 1 ? 8 : 4; };
 template <int LPR> struct PassWaves { static constexpr int value = LPR == 8 ? 4 : 1; };
 
@@ -147,9 +149,11 @@ struct PassSide {
     float *e_out;                  // optional [B]: e_i in this side's order (row side: diagnostics, eval)
     int n_host;                    // chunks of this side if known on the host, else -1
     int count_index;               // counts[0] (row) or counts[2] (col)
+    const int32_t *crec;           // per-chunk records {id, n, 0, 0 | partner | w | y} or nullptr
+    int capP;                      // chunk_cap rounded up to a multiple of 8 (record field length)
 };
 
-template <int LPR, int NV, bool FULL>
+template <int LPR, int NV, bool FULL, bool REC>
 __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
@@ -158,9 +162,13 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
-    static_assert(U % 4 == 0, "fields are read back four pairs at a time");
-    // [group][field][pair]: 0 partner, 1 w2 = 2 w inv_batch, 2 y
-    __shared__ __attribute__((aligned(16))) uint32_t fld[GPB][3][kFieldStride];
+    static_assert(U % 4 == 0 && U <= 8, "fields are read back four pairs at a time; record fields are padded to 8 slots");
+    // [group][field][pair]: 0 partner, 1 w (REC) or w2 = 2 w inv_batch, 2 y.  With records the group's LDS image
+    // is the record itself: header float4, then the three fields, each capP dwords
+    constexpr int kRecStride = 4 + 3 * kChunkMax + 4;        // dwords; +16 B staggers the groups over the banks
+    __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
+    uint32_t(*fld)[3][kFieldStride] = reinterpret_cast<uint32_t(*)[3][kFieldStride]>(fld_raw);
+    uint32_t *rec = fld_raw + grp_of(threadIdx.x, LPR) * kRecStride;
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const bool is_row = (int)blockIdx.x < row_blocks;
@@ -177,21 +185,37 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
 
     for (int j = bid + grp * nblk; j < n_chunks; j += nblk * GPB) {
-        const int32_t u = sd.chunk_id[j];
-        const int s = sd.chunk_start[j];
-        const int n = sd.chunk_start[j + 1] - s;
-        GLOVE_DRAIN(); GLOVE_STAMP(1);      // descriptor arrived
+        int32_t u;
+        int s = 0, n;
+        const int capP = sd.capP;
+        if (REC) {
+            // ONE round trip: the whole record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
+            const int rq = 1 + 3 * capP / 4;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rq;
+            uint4 *lrec = reinterpret_cast<uint4 *>(rec);
+            for (int f = lg; f < rq; f += LPR) lrec[f] = rp[f];
+            const uint4 hdr = lrec[0];          // same wave wrote it: LDS ops of one wave complete in order
+            u = (int32_t)hdr.x;
+            n = (int)hdr.y;
+            s = (int)hdr.z;
+            GLOVE_DRAIN(); GLOVE_STAMP(1);
+        } else {
+            u = sd.chunk_id[j];
+            s = sd.chunk_start[j];
+            n = sd.chunk_start[j + 1] - s;
+            GLOVE_DRAIN(); GLOVE_STAMP(1);      // descriptor arrived
 #pragma unroll
-        for (int sl = 0; sl < SL; ++sl) {
-            const int t = lg + sl * LPR;
-            const int k = s + (t < n ? t : 0);
-            const int32_t pv = sd.partner[k];
-            const float wv = sd.w[k];
-            const float yv = sd.y[k];
-            if (t < kChunkMax) {
-                fld[grp][0][t] = (uint32_t)pv;
-                fld[grp][1][t] = __float_as_uint(t < n ? 2.0f * inv_batch * wv : 0.f);   // tail slots weigh 0
-                fld[grp][2][t] = __float_as_uint(yv);
+            for (int sl = 0; sl < SL; ++sl) {
+                const int t = lg + sl * LPR;
+                const int k = s + (t < n ? t : 0);
+                const int32_t pv = sd.partner[k];
+                const float wv = sd.w[k];
+                const float yv = sd.y[k];
+                if (t < kChunkMax) {
+                    fld[grp][0][t] = (uint32_t)pv;
+                    fld[grp][1][t] = __float_as_uint(t < n ? wv : 0.f);     // tail slots weigh 0
+                    fld[grp][2][t] = __float_as_uint(yv);
+                }
             }
         }
         f4 r[NV], acc[NV];
@@ -208,12 +232,13 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
             float w2[U], yq[U];
 #pragma unroll
             for (int a4 = 0; a4 < U; a4 += 4) {
-                const uint4 pc = *reinterpret_cast<const uint4 *>(&fld[grp][0][q0 + a4]);
-                const uint4 pw = *reinterpret_cast<const uint4 *>(&fld[grp][1][q0 + a4]);
-                const uint4 py = *reinterpret_cast<const uint4 *>(&fld[grp][2][q0 + a4]);
+                const uint4 pc = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + q0 + a4] : &fld[grp][0][q0 + a4]);
+                const uint4 pw = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + capP + q0 + a4] : &fld[grp][1][q0 + a4]);
+                const uint4 py = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + 2 * capP + q0 + a4] : &fld[grp][2][q0 + a4]);
                 col[a4] = (int32_t)pc.x; col[a4 + 1] = (int32_t)pc.y; col[a4 + 2] = (int32_t)pc.z; col[a4 + 3] = (int32_t)pc.w;
-                w2[a4] = __uint_as_float(pw.x); w2[a4 + 1] = __uint_as_float(pw.y);
-                w2[a4 + 2] = __uint_as_float(pw.z); w2[a4 + 3] = __uint_as_float(pw.w);
+                const float sc2 = 2.0f * inv_batch;
+                w2[a4] = sc2 * __uint_as_float(pw.x); w2[a4 + 1] = sc2 * __uint_as_float(pw.y);
+                w2[a4 + 2] = sc2 * __uint_as_float(pw.z); w2[a4 + 3] = sc2 * __uint_as_float(pw.w);
                 yq[a4] = __uint_as_float(py.x); yq[a4 + 1] = __uint_as_float(py.y);
                 yq[a4 + 2] = __uint_as_float(py.z); yq[a4 + 3] = __uint_as_float(py.w);
             }
@@ -785,6 +810,8 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.e_out = row ? w.e : nullptr;
     sd.n_host = p->host_counts[row ? 0 : 2];
     sd.count_index = row ? 0 : 2;
+    sd.crec = row ? p->r_crec : p->c_crec;
+    sd.capP = (p->chunk_cap + 7) & ~7;
     return sd;
 }
 
@@ -803,9 +830,12 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     const PassSide rs = pass_side(p, t, w, true), cs = pass_side(p, t, w, false);
     hipStream_t st = (hipStream_t)stream;
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart
-#define CALL(LPR, NV)                                                                                      \
-    if (LPR * NV == d4) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+    const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;
+#define CALL(LPR, NV)                                                                                          \
+    if (LPR * NV == d4 && rec) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else if (LPR * NV == d4) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true, false>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else if (rec) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+    else hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
     GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
 #undef ARGS

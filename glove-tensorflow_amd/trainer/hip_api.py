@@ -17,6 +17,7 @@ LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
 GLOVE_ABI_VERSION = 1
 DEFAULT_CHUNK_CAP = 32
+RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
@@ -29,7 +30,7 @@ def auto_chunk_cap(B: int, V: int) -> int:
 
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
-    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_step_workspace_bytes",
+    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_fill_records", "glove_step_workspace_bytes",
     "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
@@ -60,7 +61,8 @@ class GlovePlan(C.Structure):
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
-                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp)]
+                ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp),
+                ("r_crec", _fp), ("c_crec", _fp)]
 
 
 class GloveHipError(RuntimeError):
@@ -87,6 +89,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_abi_version": (C.c_int, []),
         "glove_plan_workspace_bytes": (sz, [i64, i32]),
         "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
+        "glove_plan_fill_records": (C.c_int, [P(GlovePlan), vp]),
         "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
         "glove_passes_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_rowpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
@@ -241,6 +244,10 @@ class Plan:
         self.counts = torch.zeros(8, **i32)
         self.host_counts = [-1] * 8      # unknown until the build has been synchronised
         self.heavy = torch.zeros(self.cap_heavy, **i32)
+        # per-chunk records: carried by small (per-step) plans right away, added to big ones when compacted
+        self.r_crec = self.c_crec = None
+        if 0 < self.B <= RECORDS_AT_BUILD_MAX:
+            self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
         self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.c_w, self.c_y = torch.empty(n, **f32), torch.empty(n, **f32)
@@ -250,9 +257,14 @@ class Plan:
         self.r_uniq_rec, self.c_uniq_rec = (torch.zeros(4 * max(self.cap_uniq, 1), **i32) for _ in range(2))
         self._struct = None
 
+    @property
+    def rec_dwords(self) -> int:
+        return 4 + 3 * ((self.chunk_cap + 7) // 8 * 8)
+
     def struct(self) -> GlovePlan:
         if self._struct is None:
             s = GlovePlan()
+            s.r_crec, s.c_crec = _ptr(self.r_crec), _ptr(self.c_crec)
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
             s.heavy_chunks, s.cap_heavy = self.heavy_chunks, self.cap_heavy
             s.counts = _ptr(self.counts)
@@ -265,8 +277,9 @@ class Plan:
             self._struct = s
         return self._struct
 
-    def compact(self) -> "Plan":
-        """Exact-size copy (one host sync): used when plans of a static stream stay resident."""
+    def compact(self, lib=None) -> "Plan":
+        """Exact-size copy (one host sync): used when plans of a static stream stay resident.  With `lib`
+        (the loaded C library) the copy also gets its per-chunk records."""
         nc_r, nu_r, nc_c, nu_c, n_heavy = (int(x) for x in self.counts.tolist()[:5])
         out = Plan.__new__(Plan)
         out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
@@ -286,10 +299,17 @@ class Plan:
         out.r_uniq_rec = self.r_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out.c_uniq_rec = self.c_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out._struct = None
+        out.r_crec = out.c_crec = None
+        if lib is not None and out.B > 0:
+            n = max(out.cap_chunks, 1) * out.rec_dwords
+            out.r_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
+            out.c_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
+            _check(lib.glove_plan_fill_records(C.byref(out.struct()), _stream()), "glove_plan_fill_records")
         return out
 
     def nbytes(self) -> int:
-        return sum(getattr(self, n).numel() * 4 for n in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts"))
+        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts"))
+        return n + sum(t.numel() * 4 for t in (self.r_crec, self.c_crec) if t is not None)
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
@@ -342,7 +362,7 @@ class GloveHip:
         ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
-        return plan.compact() if compact else plan
+        return plan.compact(self.lib) if compact else plan
 
     # ---- passes
     def passes(self, plan, tables, hyper, ws=None):

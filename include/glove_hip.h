@@ -110,6 +110,14 @@ typedef struct glove_plan {
      * particular order: (side << 30) | q with side 0 = row, 1 = col.  The apply kernels give each of
      * them a whole workgroup that starts ahead of the per-lane-group work on the light ids. */
     int32_t *heavy;
+    /* Optional per-chunk records (NULL = absent): chunk j of a side owns rec_dwords = 4 + 3*capP dwords
+     * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, first pair, 0 | partner[capP] | w[capP] |
+     * y[capP]}, padding slots carrying weight 0.  With them the pass kernel gets a chunk's descriptor AND
+     * its pair fields in ONE memory round trip (contiguous 16-B loads) instead of two dependent ones.
+     * Filled by glove_plan_build when non-NULL, or later by glove_plan_fill_records for an exact-size
+     * (compacted) plan.  Capacity: cap_chunks * rec_dwords int32 each. */
+    int32_t *r_crec;
+    int32_t *c_crec;
 } glove_plan;
 
 int glove_abi_version(void);
@@ -121,6 +129,9 @@ size_t glove_plan_workspace_bytes(int64_t B, int32_t V);
 int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y,
                      int64_t B, int32_t V, const glove_plan *plan,
                      void *ws, size_t ws_bytes, void *stream);
+
+/* (Re)builds r_crec / c_crec of a plan whose other arrays are complete (both must be non-NULL). */
+int glove_plan_fill_records(const glove_plan *plan, void *stream);
 
 /* ---- step workspace ---------------------------------------------------------------------
  * Holds e[B], per-chunk partial gradient rows and per-block loss partials. */

@@ -50,7 +50,7 @@ def test_struct_layout_matches_the_c_header(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "glove_hip.h"\nint main(void){\n'
                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(glove_tables), sizeof(glove_hyper), '
                    'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
-                   'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, heavy));\n'
+                   'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, c_crec));\n'
                    'printf("%zu %zu\\n", offsetof(glove_tables, R), offsetof(glove_hyper, sides));\n'
                    'return 0;}\n')
     exe = tmp_path / "layout"
@@ -58,7 +58,7 @@ def test_struct_layout_matches_the_c_header(tmp_path):
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     T, H, P = hip_api.GloveTables, hip_api.GloveHyper, hip_api.GlovePlan
     assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
-                   P.host_counts.offset, P.r_to_c.offset, P.heavy.offset, T.R.offset, H.sides.offset]
+                   P.host_counts.offset, P.r_to_c.offset, P.c_crec.offset, T.R.offset, H.sides.offset]
 
 
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):

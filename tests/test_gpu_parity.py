@@ -49,6 +49,28 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(plan.c_uniq_slot.cpu().numpy()[:nu_c + 1], want["c_uniq_slot"])
     np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
+    # per-chunk records {id, n, start, 0 | partner | w | y} (small plans carry them from the build, big ones
+    # get them when compacted): same content as the SoA arrays, padding slots weigh 0
+    cpr = plan.compact(hip.lib)
+    capP = (cap + 7) // 8 * 8
+    rd = 4 + 3 * capP
+    for side, nc, ids, starts, partner, ww, yy in (
+            ("r", nc_r, want["r_chunk_id"], want["r_chunk_start"], want["r_partner"], w[want["perm_r"]], y[want["perm_r"]]),
+            ("c", nc_c, want["c_chunk_id"], want["c_chunk_start"], want["c_partner"],
+             w[want["perm_r"]][want["c_perm"]], y[want["perm_r"]][want["c_perm"]])):
+        for p_ in ([plan, cpr] if plan.r_crec is not None else [cpr]):
+            rec = getattr(p_, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
+            n = np.diff(starts)
+            np.testing.assert_array_equal(rec[:, 0], ids)
+            np.testing.assert_array_equal(rec[:, 1], n)
+            np.testing.assert_array_equal(rec[:, 2], starts[:-1])
+            for j in (0, nc // 2, nc - 1):
+                sl = slice(starts[j], starts[j + 1])
+                np.testing.assert_array_equal(rec[j, 4:4 + n[j]], partner[sl])
+                np.testing.assert_array_equal(rec[j, 4 + capP:4 + capP + n[j]].view(np.float32), ww[sl])
+                np.testing.assert_array_equal(rec[j, 4 + 2 * capP:4 + 2 * capP + n[j]].view(np.float32), yy[sl])
+                assert (rec[j, 4 + capP + n[j]:4 + 2 * capP].view(np.float32) == 0).all()
+    assert (plan.r_crec is not None) == (B <= 4096)
     # compacted copy describes the same index
     cp = plan.compact()
     assert cp.cap_chunks == max(nc_r, nc_c) and cp.cap_uniq == max(nu_r, nu_c)
