@@ -292,6 +292,15 @@ def main():
         kern[name] = sorted(spans)[1]
     if G is not None:
         G.zero_()
+    # attribution of the algorithmic bytes to the two kernels of the sparse step: the pass kernel
+    # owns the nonzero stream and ONE read of every distinct row + bias; the apply kernel owns the accumulator
+    # read and the two writes
+    per_kernel = None
+    if not dense and not adam:
+        attributed = {"passes": 16 * B + 4 * (d + 1) * (u_row + u_col), "apply_adagrad": 12 * (d + 1) * (u_row + u_col)}
+        per_kernel = {k: {"algorithmic_bytes": attributed[k], "avg_us": kern[k],
+                          "achieved_GBps": attributed[k] / (kern[k] * 1e-6) / 1e9,
+                          "frac": attributed[k] / (kern[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in attributed}
     step_us = sum(kern.values())
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
@@ -313,7 +322,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one step = " + " + ".join(kern),
-                         "algorithmic_bytes_per_step": alg, "kernel_us": kern,
+                         "algorithmic_bytes_per_step": alg, "kernel_us": kern, "per_kernel": per_kernel,
                          "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
         }

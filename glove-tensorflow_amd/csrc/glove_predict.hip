@@ -112,15 +112,42 @@ __global__ __launch_bounds__(kBlock) void cosine_kernel(const float *__restrict_
     }
 }
 
-// k rounds of workgroup arg-max under the order (sim desc, index asc); one workgroup per query.
+// order of tf.math.top_k: larger similarity first, ties -> lower index first
+__device__ inline bool topk_before(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
+
+// One pass over the V similarities of a query (one workgroup per query): every thread keeps the best K of
+// its strided share in registers (sorted insertion, static indices), the 256 lists meet in LDS and k rounds
+// of workgroup arg-max pick the result.  O(V) reads per query instead of k * V.
+template <int K>
 __global__ __launch_bounds__(kBlock) void topk_kernel(const float *__restrict__ sims, int32_t V, int32_t k,
                                                       float *__restrict__ out_sim, int32_t *__restrict__ out_idx)
 {
+    __shared__ float c_val[kBlock * K];
+    __shared__ int c_idx[kBlock * K];
     __shared__ float s_val[kBlock / 64];
     __shared__ int s_idx[kBlock / 64];
     __shared__ float prev_val;
     __shared__ int prev_idx;
     const float *row = sims + (size_t)blockIdx.x * V;
+    float val[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { val[j] = -INFINITY; idx[j] = 0x7fffffff; }
+    for (int v = threadIdx.x; v < V; v += kBlock) {
+        const float s = row[v];
+        if (topk_before(s, v, val[K - 1], idx[K - 1])) {
+            val[K - 1] = s; idx[K - 1] = v;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                if (topk_before(val[j], idx[j], val[j - 1], idx[j - 1])) {
+                    const float tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
+                    const int ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) { c_val[threadIdx.x * K + j] = val[j]; c_idx[threadIdx.x * K + j] = idx[j]; }
     if (threadIdx.x == 0) { prev_val = INFINITY; prev_idx = -1; }
     __syncthreads();
     for (int t = 0; t < k; ++t) {
@@ -128,27 +155,28 @@ __global__ __launch_bounds__(kBlock) void topk_kernel(const float *__restrict__ 
         const int pi = prev_idx;
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int v = threadIdx.x; v < V; v += kBlock) {
-            const float s = row[v];
-            const bool after_prev = (s < pv) || (s == pv && v > pi);
-            if (after_prev && (s > best || (s == best && v < bi))) { best = s; bi = v; }
+        // each thread's list is sorted: its first entry behind the previous pick is its best remaining one
+        for (int j = 0; j < K; ++j) {
+            const float s = c_val[threadIdx.x * K + j];
+            const int v = c_idx[threadIdx.x * K + j];
+            if ((s < pv || (s == pv && v > pi)) && topk_before(s, v, best, bi)) { best = s; bi = v; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             const float ob = __shfl_xor(best, m, 64);
             const int oi = __shfl_xor(bi, m, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            if (topk_before(ob, oi, best, bi)) { best = ob; bi = oi; }
         }
         if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = bi; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            float b = s_val[0]; int i = s_idx[0];
+            float bv = s_val[0]; int i = s_idx[0];
             for (int wv = 1; wv < kBlock / 64; ++wv)
-                if (s_val[wv] > b || (s_val[wv] == b && s_idx[wv] < i)) { b = s_val[wv]; i = s_idx[wv]; }
-            if (i == 0x7fffffff) { b = -INFINITY; i = -1; }   // fewer than k candidates
-            out_sim[(size_t)blockIdx.x * k + t] = b;
+                if (topk_before(s_val[wv], s_idx[wv], bv, i)) { bv = s_val[wv]; i = s_idx[wv]; }
+            if (i == 0x7fffffff) { bv = -INFINITY; i = -1; }   // fewer than k candidates
+            out_sim[(size_t)blockIdx.x * k + t] = bv;
             out_idx[(size_t)blockIdx.x * k + t] = i;
-            prev_val = b; prev_idx = (i < 0) ? V : i;
+            prev_val = bv; prev_idx = (i < 0) ? V : i;
         }
         __syncthreads();
     }
@@ -189,7 +217,7 @@ size_t glove_topk_workspace_bytes(int32_t n, int32_t V, int32_t k)
 int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *query_ids, int32_t n, int32_t k,
                           float *sims_out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!R || V <= 0 || d <= 0 || (d % 4) != 0 || n < 0 || n > 65535 * kQT || k <= 0 || k > V) return GLOVE_E_BADARG;
+    if (!R || V <= 0 || d <= 0 || (d % 4) != 0 || n < 0 || n > 65535 * kQT || k <= 0 || k > V || k > 64) return GLOVE_E_BADARG;
     if (n == 0) return 0;
     if (!query_ids || !sims_out || !idx_out || !ws) return GLOVE_E_BADARG;
     if (glove_topk_workspace_bytes(n, V, k) > ws_bytes) return GLOVE_E_WORKSPACE;
@@ -208,7 +236,9 @@ int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *q
                        query_ids, n, inv_norm, sims)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
-    hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
+    if (k <= 8) hipLaunchKernelGGL(topk_kernel<8>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
+    else if (k <= 20) hipLaunchKernelGGL(topk_kernel<20>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
+    else hipLaunchKernelGGL(topk_kernel<64>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
     return (int)hipGetLastError();
 }
 

@@ -273,7 +273,7 @@ def test_eval_metrics(hip):
     assert dt.global_step == 0      # EVAL mode leaves the step alone
 
 
-@pytest.mark.parametrize("V,d,k", [(500, 64, 20), (1000, 300, 5), (64, 8, 64)])
+@pytest.mark.parametrize("V,d,k", [(500, 64, 20), (1000, 300, 5), (64, 8, 64), (100000, 64, 20), (3000, 128, 33)])
 def test_topk_cosine(hip, V, d, k):
     rng = np.random.default_rng(5)
     R = rng.normal(size=(V, d)).astype(np.float32)
