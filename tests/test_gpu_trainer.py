@@ -116,3 +116,41 @@ def test_data_parallel_form_on_one_gpu_matches_sparse_step(hip):
         assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step == 5
     finally:
         dist.destroy_process_group()
+
+
+def test_whole_pipeline_recovers_planted_topics(hip, tmp_path):
+    """corpus -> trainer.text8 (GPU co-occurrence) -> trainer.estimator (CLI) -> PREDICT.  The corpus is built from
+    8 topics of 30 words; sentences stay inside one topic, so a word's nearest neighbours by cosine over the
+    trained ROW embeddings must be words of its own topic."""
+    from trainer import estimator, text8
+    rng = np.random.default_rng(0)
+    topics, words_per = 8, 30
+    vocab = [["t%dw%02d" % (t, i) for i in range(words_per)] for t in range(topics)]
+    tokens = []
+    for _ in range(4000):
+        t = rng.integers(topics)
+        tokens.extend(rng.choice(vocab[t], size=rng.integers(30, 60)))        # long sentences: few cross-topic windows
+    data_dir = tmp_path / "data"
+    data_dir.mkdir()
+    (data_dir / "text8").write_text(" ".join(tokens))
+    text8.main(url="", dest=str(data_dir), vocab_size=None, coverage=0.999, context_size=5, seed=1)
+    assert (data_dir / "interaction.csv").exists() and (data_dir / "vocab.txt").exists()
+    job = tmp_path / "job"
+    estimator.main(["--train-csv", str(data_dir / "interaction.csv"), "--vocab-txt", str(data_dir / "vocab.txt"),
+                    "--job-dir", str(job), "--disable-datetime-path", "--embedding-size", "32", "--optimizer", "Adagrad",
+                    "--learning-rate", "0.1", "--batch-size", "2048", "--train-steps", "3000", "--log-every", "50",
+                    "--seed", "3", "--skip-eval"])
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert log[-1]["global_step"] == 3000 and log[-1]["loss"] < 0.8 * log[0]["loss"]      # step 50 vs step 3000
+    params = json.loads((job / "params.json").read_text())
+    params["top_k"] = 11
+    same, total = 0, 0
+    for pred in estimator.Estimator(params).predict():
+        word = pred["input_string"]
+        if word == "<UNK>":
+            continue
+        assert pred["top_k_string"][0] == word
+        neighbours = [n for n in pred["top_k_string"][1:] if n != "<UNK>"]
+        same += sum(n[:2] == word[:2] for n in neighbours)
+        total += len(neighbours)
+    assert total >= topics * words_per * 9 and same / total > 0.6, (same, total)       # chance level: 0.12; 0.76 observed
