@@ -58,7 +58,7 @@ def test_plan_build_bit_exact(hip, B, V, cap):
             ("r", nc_r, want["r_chunk_id"], want["r_chunk_start"], want["r_partner"], w[want["perm_r"]], y[want["perm_r"]]),
             ("c", nc_c, want["c_chunk_id"], want["c_chunk_start"], want["c_partner"],
              w[want["perm_r"]][want["c_perm"]], y[want["perm_r"]][want["c_perm"]])):
-        for p_ in ([plan, cpr] if plan.r_crec is not None else [cpr]):
+        for p_ in [q_ for q_ in (plan, cpr) if q_.r_crec is not None]:
             rec = getattr(p_, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
             n = np.diff(starts)
             np.testing.assert_array_equal(rec[:, 0], ids)
@@ -71,6 +71,7 @@ def test_plan_build_bit_exact(hip, B, V, cap):
                 np.testing.assert_array_equal(rec[j, 4 + 2 * capP:4 + 2 * capP + n[j]].view(np.float32), yy[sl])
                 assert (rec[j, 4 + capP + n[j]:4 + 2 * capP].view(np.float32) == 0).all()
     assert (plan.r_crec is not None) == (B <= 4096)
+    assert (cpr.r_crec is not None) == (4 * B >= cap * max(nc_r, nc_c))     # only reasonably filled chunks
     # compacted copy describes the same index
     cp = plan.compact()
     assert cp.cap_chunks == max(nc_r, nc_c) and cp.cap_uniq == max(nu_r, nu_c)
