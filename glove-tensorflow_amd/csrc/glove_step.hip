@@ -961,6 +961,18 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
     return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
 }
 
+int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t, const glove_hyper *h,
+                            void *ws, size_t ws_bytes, float *loss_out, void *stream)
+{
+    if (!plans || n < 0) return GLOVE_E_BADARG;
+    for (int32_t i = 0; i < n; ++i) {
+        if (int rc = glove_passes_f32(plans[i], t, h, ws, ws_bytes, stream)) return rc;
+        if (int rc = glove_apply_adagrad_f32(plans[i], t, h, ws, ws_bytes, i == n - 1 ? loss_out : nullptr, stream))
+            return rc;
+    }
+    return 0;
+}
+
 int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                         float *G_flat, float *loss_out, void *stream)
 {

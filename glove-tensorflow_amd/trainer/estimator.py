@@ -103,8 +103,10 @@ class Estimator:
             self.ckpt.save(tables)          # Estimator saves at step 0 too
         t_last, s_last = time.perf_counter(), step
         while step < max_steps:
-            stepper.step(stream.next_plan())
-            step += 1
+            # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
+            burst = min(max_steps, (step // log_every + 1) * log_every) - step
+            stepper.step_many([stream.next_plan() for _ in range(burst)])
+            step += burst
             if step % log_every == 0 or step == max_steps:
                 rec = stepper.read_loss()                      # device sync
                 if not math.isfinite(rec["loss"]):

@@ -40,6 +40,9 @@ class HipBackend:
     def step_sparse_adagrad(self, plan, tables, hyper, loss_out):
         self.hip.step_adagrad(plan, tables, hyper, loss_out)
 
+    def steps_sparse_adagrad(self, plans, tables, hyper, loss_out):
+        self.hip.steps_adagrad(plans, tables, hyper, loss_out)
+
     def local_dense_grad(self, plan, tables, hyper, G):
         self.hip.passes(plan, tables, hyper)
         self.hip.dense_grad(plan, tables, hyper, G)
@@ -90,6 +93,14 @@ class Stepper:
         if self.world > 1:
             self.dist.all_reduce(self.G)          # sum over ranks; the tail carries the loss partials
         self.backend.apply_dense(self.tables, self.hyper, self.G, self.loss_out)
+
+    def step_many(self, plans):
+        """Several consecutive steps; on one GPU with sparse Adagrad they are issued by one C call."""
+        if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
+            self.backend.steps_sparse_adagrad(plans, self.tables, self.hyper, self.loss_out)
+        else:
+            for plan in plans:
+                self.step(plan)
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""

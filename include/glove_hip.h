@@ -178,6 +178,11 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
 /* ---- whole step = session.run(train_op) (estimator.py:49-56) ------------------------------ */
 int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                            void *ws, size_t ws_bytes, float *loss_out, void *stream);
+/* n consecutive Adagrad steps, plans[i] in order, from ONE host call (the launch loop runs in C: a Python
+ * host loop costs more per step than the two kernels of a 1,024-pair step take).  loss_out, if not NULL,
+ * receives the scalars of the LAST step. */
+int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
+                            const glove_hyper *h, void *ws, size_t ws_bytes, float *loss_out, void *stream);
 int glove_step_adam_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
 
