@@ -54,6 +54,12 @@ class Estimator:
         opt = get_optimizer(params["optimizer"], learning_rate=params["learning_rate"])
         self.optimizer_name = opt["class_name"]
         seed = params.get("seed")
+        if self.world > 1 and seed is None:
+            # the ranks cut ONE permutation of the stream into shards: they must agree on it even when the
+            # run is unseeded (the reference's default), so rank 0 draws the seed
+            box = [int(torch.seed() % (1 << 31)) if self.rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=0)
+            seed = self.params["seed"] = box[0]
         self.model = MatrixFactorisation(self.vocab_size, params["embedding_size"], params["l2_reg"],
                                          optimizer=self.optimizer_name, device=self.device,
                                          seed=None if seed is None else seed + 1)
@@ -118,7 +124,12 @@ class Estimator:
                 self._log("train_log.jsonl", rec)
                 logger.info("global_step %d: loss = %.6f (%.1f steps/s)", step, rec["loss"], rate)
                 t_last, s_last = now, step
-            if self.ckpt.due() or step == max_steps:
+            due = self.ckpt.due() or step == max_steps
+            if self.world > 1:               # the eval pass below is collective: rank 0's clock decides for all
+                flag = torch.tensor([1 if due else 0], device=self.device)
+                self.dist.broadcast(flag, src=0)
+                due = bool(flag.item())
+            if due:
                 if self.rank == 0:
                     self.ckpt.save(tables)
                 if not p.get("skip_eval"):
