@@ -18,13 +18,25 @@ namespace glove {
 
 // glove_plan_small.hip: one-workgroup build for batches of at most kSmallPlanMax pairs
 constexpr int kSmallPlanMax = 4096;
-int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st);
 
-__global__ void iota_kernel(int32_t *out, int64_t n)
+// positions 0..n-1, and copies of the ids with anything outside [0, V) mapped to 0 — the id the reference's
+// vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) — so that no later kernel
+// can index outside the tables whatever the caller hands over; counts[5] reports how many were mapped
+__global__ void prepare_ids(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t n, int32_t V,
+                            int32_t *__restrict__ iota, int32_t *__restrict__ row_clean,
+                            int32_t *__restrict__ col_clean, int32_t *__restrict__ n_mapped)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (int32_t)i;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)row[i], c = (uint32_t)col[i];
+        iota[i] = (int32_t)i;
+        row_clean[i] = r < (uint32_t)V ? (int32_t)r : 0;
+        col_clean[i] = c < (uint32_t)V ? (int32_t)c : 0;
+        bad += (r >= (uint32_t)V) + (c >= (uint32_t)V);
+    }
+    if (bad) atomicAdd(n_mapped, bad);
 }
 
 // row side: pull col/w/y through the row-sort permutation
@@ -153,7 +165,7 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 }
 
 struct PlanWs {
-    int32_t *iota, *perm, *keys_sorted, *row_sorted, *run_start;
+    int32_t *iota, *perm, *keys_sorted, *row_sorted, *run_start, *row_clean, *col_clean;
     uint64_t *flags, *scanned;
     void *prim;          // rocPRIM temporary storage
     size_t prim_bytes;
@@ -174,6 +186,8 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.keys_sorted = (int32_t *)take(n * 4);
     p.row_sorted = (int32_t *)take(n * 4);
     p.run_start = (int32_t *)take(n * 4);
+    p.row_clean = (int32_t *)take(n * 4);
+    p.col_clean = (int32_t *)take(n * 4);
     p.flags = (uint64_t *)take(n * 8);
     p.scanned = (uint64_t *)take(n * 8);
     p.prim_bytes = prim_budget(B);
@@ -246,7 +260,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
     if (B <= kSmallPlanMax) {                                                          // launch-bound regime
-        if (int rc = plan_build_small(row, col, w, y, B, plan, st)) return rc;
+        if (int rc = plan_build_small(row, col, w, y, B, V, plan, st)) return rc;
         return plan->r_crec ? launch_fill_records(plan, st) : 0;
     }
     HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
@@ -258,11 +272,14 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     size_t need = 0;
 
     // ---- row side: stable sort (row id, position)
-    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(kBlock), 0, st, pw.iota, B);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, row, pw.row_sorted, pw.iota, pw.perm, (size_t)B, 0, bits, st));
+    hipLaunchKernelGGL(prepare_ids, dim3(nb), dim3(kBlock), 0, st, row, col, B, V, pw.iota, pw.row_clean, pw.col_clean,
+                       plan->counts + 5);
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
+                                      (size_t)B, 0, bits, st));
     if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, row, pw.row_sorted, pw.iota, pw.perm, (size_t)B, 0, bits, st));
-    hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, col, w, y, B, plan->r_partner,
+    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
+                                      (size_t)B, 0, bits, st));
+    hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, pw.col_clean, w, y, B, plan->r_partner,
                        plan->r_w, plan->r_y);
     if (int rc = build_side(pw.row_sorted, B, plan->chunk_cap, pw, plan->r_chunk_id, plan->r_chunk_start,
                             plan->r_uniq_slot, plan->r_uniq_rec, plan->cap_uniq, plan->counts + 0, 0, plan, st))

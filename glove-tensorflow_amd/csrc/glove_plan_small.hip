@@ -126,7 +126,7 @@ __device__ inline void small_side(const int *ids, int B, int cap, int heavy_chun
 
 __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
-    const float *__restrict__ y, int B, int np, glove_plan plan)
+    const float *__restrict__ y, int B, int V, int np, glove_plan plan)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);                 // [np]
@@ -139,20 +139,31 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     int *sc = sb + np;
     __shared__ int wave_tot[16];
     if (threadIdx.x < 8) plan.counts[threadIdx.x] = 0;
+    __syncthreads();
 
-    // ---- row side: stable sort by (row id, position)
-    for (int i = threadIdx.x; i < np; i += kSmallThreads)
-        keys[i] = i < B ? (((uint64_t)(uint32_t)row[i] << kPosBits) | (uint64_t)i) : ~0ull;
+    // ---- row side: stable sort by (row id, position); ids outside [0, V) count as id 0 (see prepare_ids)
+    int mapped = 0;
+    for (int i = threadIdx.x; i < np; i += kSmallThreads) {
+        uint64_t key = ~0ull;
+        if (i < B) {
+            uint32_t r = (uint32_t)row[i];
+            if (r >= (uint32_t)V) { r = 0; ++mapped; }
+            key = ((uint64_t)r << kPosBits) | (uint64_t)i;
+        }
+        keys[i] = key;
+    }
     __syncthreads();
     bitonic_sort(keys, np);
     for (int k = threadIdx.x; k < B; k += kSmallThreads) {
         const int p = (int)(keys[k] & kPosMask);
-        const int c = col[p];
+        int c = col[p];
+        if ((uint32_t)c >= (uint32_t)V) { c = 0; ++mapped; }
         const float wv = w[p], yv = y[p];
         srow[k] = (int)(keys[k] >> kPosBits);
         scol[k] = c; sw[k] = wv; sy[k] = yv;
         plan.r_partner[k] = c; plan.r_w[k] = wv; plan.r_y[k] = yv;
     }
+    if (mapped) atomicAdd(plan.counts + 5, mapped);
     __syncthreads();
     small_side(srow, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 0, sa, sb, sc, wave_tot,
                SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts + 0,
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
 }
 
 // host side: called from glove_plan_build for B <= kSmallPlanMax
-int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st)
 {
     int np = 64;
@@ -190,7 +201,7 @@ int plan_build_small(const int32_t *row, const int32_t *col, const float *w, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(kSmallThreads), smem, st, row, col, w, y, (int)B, np, *plan);
+    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(kSmallThreads), smem, st, row, col, w, y, (int)B, (int)V, np, *plan);
     return (int)hipGetLastError();
 }
 

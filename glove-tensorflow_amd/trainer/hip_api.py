@@ -7,10 +7,13 @@ as the owner of device memory and streams (`tensor.data_ptr()`, `current_stream(
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 from pathlib import Path
 
 import torch
+
+logger = logging.getLogger(__name__)
 
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
@@ -281,7 +284,9 @@ class Plan:
     def compact(self, lib=None) -> "Plan":
         """Exact-size copy (one host sync): used when plans of a static stream stay resident.  With `lib`
         (the loaded C library) the copy also gets its per-chunk records."""
-        nc_r, nu_r, nc_c, nu_c, n_heavy = (int(x) for x in self.counts.tolist()[:5])
+        nc_r, nu_r, nc_c, nu_c, n_heavy, n_mapped = (int(x) for x in self.counts.tolist()[:6])
+        if n_mapped:
+            logger.warning("%d ids outside [0, %d) were treated as id 0 (the unknown token)", n_mapped, self.V)
         out = Plan.__new__(Plan)
         out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)

@@ -83,7 +83,8 @@ typedef struct glove_plan {
     int32_t heavy_chunks;       /* ids with more chunks than this go to the `heavy` list (default 8) */
     int32_t cap_heavy;          /* capacity of `heavy` (>= 2 B / (heavy_chunks * chunk_cap) + 2) */
     int32_t reserved;
-    int32_t *counts;            /* int32[8]: chunks_row, uniq_row, chunks_col, uniq_col, heavy, 0.. */
+    int32_t *counts;            /* int32[8]: chunks_row, uniq_row, chunks_col, uniq_col, heavy,
+                                 * ids outside [0,V) that were mapped to 0, 0, 0 */
     /* host copy of counts for plans whose build has completed (a resident plan of a static
      * stream): saves the kernels one dependent load.  -1 = unknown, read `counts` on the device. */
     int32_t host_counts[8];

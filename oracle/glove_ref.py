@@ -238,16 +238,23 @@ def cosine_topk(R, query_ids, k):
 # --------------------------------------------------------------------------------------
 # Dedup index ("plan") — integer work, bit-exact target for glove_plan_build.
 # --------------------------------------------------------------------------------------
-def build_plan(row, col, chunk_cap, heavy_chunks=8):
+def build_plan(row, col, chunk_cap, heavy_chunks=8, V=None):
     """Reference construction of the per-batch dedup index the HIP library builds on device.
 
     Row side: pairs stably sorted by row id; each run of equal ids is cut into chunks of at
     most `chunk_cap` pairs.  Col side: the ROW-SORTED pairs stably sorted by col id, `c_perm`
     pointing back into row-sorted positions and `r_to_c` its inverse.  See DESIGN.md "Data layout".
+    With `V` given, ids outside [0, V) count as id 0 — what the reference's vocabulary lookup returns for
+    an unknown token (src/models/estimator.py:26-28) — and counts[5] says how many there were.
     """
     row = np.asarray(row, np.int64)
     col = np.asarray(col, np.int64)
     B = len(row)
+    mapped = 0
+    if V is not None:
+        bad_r, bad_c = (row < 0) | (row >= V), (col < 0) | (col >= V)
+        mapped = int(bad_r.sum() + bad_c.sum())
+        row, col = np.where(bad_r, 0, row), np.where(bad_c, 0, col)
 
     def side(keys):
         starts = np.flatnonzero(np.r_[True, keys[1:] != keys[:-1]]) if B else np.zeros(0, np.int64)
@@ -280,7 +287,7 @@ def build_plan(row, col, chunk_cap, heavy_chunks=8):
                 c_perm=perm_c.astype(np.int32), c_partner=s_row[perm_c].astype(np.int32),
                 c_chunk_id=c_chunk_id, c_chunk_start=c_chunk_start, c_uniq_slot=c_uniq_slot,
                 counts=np.asarray([len(r_chunk_id), len(r_uniq_slot) - 1,
-                                   len(c_chunk_id), len(c_uniq_slot) - 1, len(heavy), 0, 0, 0], np.int32))
+                                   len(c_chunk_id), len(c_uniq_slot) - 1, len(heavy), mapped, 0, 0], np.int32))
 
 
 # --------------------------------------------------------------------------------------

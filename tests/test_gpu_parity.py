@@ -22,6 +22,37 @@ def _hyper(hp: ref.Hyper, B):
                       beta1=hp.beta1, beta2=hp.beta2, batch_size=B)
 
 
+@pytest.mark.parametrize("B", [300, 9000])        # one-workgroup builder / rocPRIM builder
+def test_plan_maps_out_of_range_ids_to_zero(hip, B):
+    """Ids outside [0, V) must never reach the tables: both builders treat them as id 0 (the reference's
+    unknown-token id, estimator.py:26-28) and count them in counts[5]."""
+    V = 40
+    row, col, w, y = make_batch(B, B, V)
+    row[::7] = V + 3
+    col[5::11] = -2
+    row[1] = np.iinfo(np.int32).max
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=8)
+    want = ref.build_plan(row, col, 8, V=V)
+    assert want["counts"][5] > 0
+    np.testing.assert_array_equal(plan.counts.cpu().numpy(), want["counts"])
+    nc_r, nu_r, nc_c, nu_c = want["counts"][:4]
+    np.testing.assert_array_equal(plan.r_partner.cpu().numpy()[:B], want["r_partner"])
+    np.testing.assert_array_equal(plan.c_partner.cpu().numpy()[:B], want["c_partner"])
+    np.testing.assert_array_equal(plan.r_chunk_id.cpu().numpy()[:nc_r], want["r_chunk_id"])
+    np.testing.assert_array_equal(plan.c_chunk_id.cpu().numpy()[:nc_c], want["c_chunk_id"])
+    np.testing.assert_array_equal(plan.c_perm.cpu().numpy()[:B], want["c_perm"])
+    # and a step over it stays inside the tables (equals the step on the cleaned batch)
+    from trainer.hip_api import DeviceTables
+    crow = np.where((row < 0) | (row >= V), 0, row).astype(np.int32)
+    ccol = np.where((col < 0) | (col >= V), 0, col).astype(np.int32)
+    out = []
+    for r, c in ((row, col), (crow, ccol)):
+        tables = DeviceTables(V, 16, "Adagrad", hip.device, seed=3)
+        hip.step_adagrad(hip.build_plan(*to_dev(r, c, w, y), V, chunk_cap=8), tables, _hyper(ref.Hyper(), B))
+        out.append(tables.R.cpu().numpy().copy())
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("B,V,cap", [(1, 5, 32), (7, 50, 32), (64, 50, 4), (1024, 300, 32), (5000, 97, 3),
                                      (20000, 2000, 32), (100000, 12000, 16)])
 def test_plan_build_bit_exact(hip, B, V, cap):

@@ -123,3 +123,14 @@ def test_eval_and_topk_reference_behaviour():
     sims, idx = ref.cosine_topk(t.R, np.array([4, 9]), 5)
     assert idx[0, 0] == 4 and idx[1, 0] == 9 and np.allclose(sims[:, 0], 1.0)
     assert (np.diff(sims, axis=1) <= 1e-15).all()
+
+
+def test_plan_treats_out_of_range_ids_as_unknown_token():
+    """estimator.py:26-28: the vocabulary lookup maps anything unknown to id 0."""
+    row = np.array([3, 9, -1, 2, 3], np.int32)
+    col = np.array([0, 1, 2, 77, 4], np.int32)
+    p = ref.build_plan(row, col, 4, V=5)
+    q = ref.build_plan(np.array([3, 0, 0, 2, 3]), np.array([0, 1, 2, 0, 4]), 4)
+    assert p["counts"][5] == 3 and q["counts"][5] == 0
+    for k in ("r_partner", "c_partner", "r_chunk_id", "c_chunk_id", "c_perm", "r_to_c"):
+        np.testing.assert_array_equal(p[k], q[k])
