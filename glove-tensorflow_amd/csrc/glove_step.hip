@@ -653,14 +653,15 @@ __global__ __launch_bounds__(kBlock) void dense_adagrad_kernel(
 }
 
 __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
-    DenseSegs segs, StepConsts k, double beta1, double beta2, const int64_t *__restrict__ step,
+    DenseSegs segs, StepConsts k, float b1, float b2, double ln_beta1, double ln_beta2, const int64_t *__restrict__ step,
     float *__restrict__ scalars, float *__restrict__ tail, float *__restrict__ loss_out, int do_scalars)
 {
     const DenseSeg sg = segs.s[blockIdx.y];
     // t = global_step after rowpass advanced it; lr_t = lr sqrt(1-b2^t)/(1-b1^t)  (Keras legacy Adam)
+    // 1 - beta^t = -expm1(t ln beta): the logs come from the host in fp64, so each wave pays two fp64
+    // multiplies and two expm1f instead of two fp64 pow() (~290 fp64 instructions, a third of this kernel's time)
     const double t = (double)(*step);
-    const float lr_t = (float)((double)k.lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
-    const float b1 = (float)beta1, b2 = (float)beta2;
+    const float lr_t = k.lr * sqrtf(-expm1f((float)(t * ln_beta2))) / -expm1f((float)(t * ln_beta1));
     const int64_t n4 = blockIdx.y < 2 ? sg.n / 4 : 0;
     f4 *W4 = reinterpret_cast<f4 *>(sg.W), *M4 = reinterpret_cast<f4 *>(sg.S1), *V4 = reinterpret_cast<f4 *>(sg.S2),
        *G4 = reinterpret_cast<f4 *>(sg.G);
@@ -947,10 +948,11 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
 {
     DenseSegs segs; float *tail; int nbx, sides;
     if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx, sides)) return rc;
+    if (!(h->beta1 > 0.0 && h->beta1 < 1.0 && h->beta2 > 0.0 && h->beta2 < 1.0)) return GLOVE_E_BADARG;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, h->beta1, h->beta2, t->step,
-                       t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
+    hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, (float)h->beta1, (float)h->beta2,
+                       log(h->beta1), log(h->beta2), t->step, t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
     return (int)hipGetLastError();
 }
 
