@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
     // [2] sum b^2, [3] sum e
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int j = bid + grp * nblk; j < n_chunks; j += nblk * GPB) {
+    for (int j = bid * GPB + grp; j < n_chunks; j += nblk * GPB) {
         int32_t u;
         int s = 0, n;
         const int capP = sd.capP;
@@ -279,10 +279,7 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
 #pragma unroll
                 for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 32, 64);
             }
-            constexpr int ES = (U + LPR - 1) / LPR;          // pairs of this trip whose e a lane keeps
-            float e_mine[ES];
-#pragma unroll
-            for (int x = 0; x < ES; ++x) e_mine[x] = 0.f;
+            float ev[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
                 const float valid = (q0 + a < n) ? 1.0f : 0.f;
@@ -294,13 +291,17 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
                 ed += e * diff;
                 cc_sum += valid * cc[a];
                 bsq += valid * bcv[a] * bcv[a];
-                e_mine[a / LPR] = (lg == (a % LPR)) ? e : e_mine[a / LPR];   // lane a % LPR keeps pair q0+a's e
+                ev[a] = e;
             }
-            if (sd.e_out) {
+            if (sd.e_out) {                                  // glove_rowpass_f32 only: e_i for diagnostics
+                constexpr int ES = (U + LPR - 1) / LPR;      // pairs of this trip whose e a lane stores
 #pragma unroll
                 for (int x = 0; x < ES; ++x) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int a = x * LPR; a < U && a < (x + 1) * LPR; ++a) mine = (lg == a - x * LPR) ? ev[a] : mine;
                     const int q = q0 + lg + x * LPR;
-                    if (lg + x * LPR < U && q < n) sd.e_out[s + q] = e_mine[x];
+                    if (lg + x * LPR < U && q < n) sd.e_out[s + q] = mine;
                 }
             }
         }
@@ -449,7 +450,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
     // the last workgroup of the grid only does the once-per-step scalar work, beside everyone else
     if (blockIdx.x == gridDim.x - 1) return (wk.sides & 2) != 0;
     const int lb = blockIdx.x - wk.heavy_blocks, nlb = gridDim.x - wk.heavy_blocks - 1;
-    for (int q = q_begin + lb + grp * nlb; q < total; q += nlb * GPB) {
+    for (int q = q_begin + lb * GPB + grp; q < total; q += nlb * GPB) {
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
@@ -794,7 +795,7 @@ size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *off
     return (size_t)L.total;
 }
 
-static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row)
+static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row, bool want_e = false)
 {
     PassSide sd;
     sd.partner = row ? p->r_partner : p->c_partner;
@@ -808,7 +809,7 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.other_bias = row ? t->bc : t->br;
     sd.gp = row ? w.gp_r : w.gp_c;
     sd.gb = row ? w.gb_r : w.gb_c;
-    sd.e_out = row ? w.e : nullptr;
+    sd.e_out = row && want_e ? w.e : nullptr;
     sd.n_host = p->host_counts[row ? 0 : 2];
     sd.count_index = row ? 0 : 2;
     sd.crec = row ? p->r_crec : p->c_crec;
@@ -828,7 +829,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     const int nb_side = rowpass_blocks(p, shape.lpr);
     const int row_blocks = (which & 1) ? nb_side : 0;
     const int nb = row_blocks + ((which & 2) ? nb_side : 0);
-    const PassSide rs = pass_side(p, t, w, true), cs = pass_side(p, t, w, false);
+    const PassSide rs = pass_side(p, t, w, true, which == 1), cs = pass_side(p, t, w, false);
     hipStream_t st = (hipStream_t)stream;
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;

@@ -135,7 +135,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
 int glove_plan_fill_records(const glove_plan *plan, void *stream);
 
 /* ---- step workspace ---------------------------------------------------------------------
- * Holds e[B], per-chunk partial gradient rows and per-block loss partials. */
+ * Holds e[B] (written by glove_rowpass_f32 only), per-chunk partial gradient rows and per-block loss partials. */
 size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d);
 
 /* ---- fused forward + gradient passes (model_utils.py:41-54, estimator.py:48-56, autodiff) --
@@ -144,7 +144,8 @@ size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d);
  *   col side: the per-chunk sums  sum_i e_i R[row_i]  /  sum_i e_i
  * The sides are independent (each forms e_i itself): glove_passes_f32 runs both in ONE launch, which
  * is what the step functions use; glove_rowpass_f32 / glove_colpass_f32 run one side each.
- * None of them modifies the tables. */
+ * glove_rowpass_f32 alone also stores e[B] (row-sorted pair order) at the start of the workspace, for
+ * diagnostics and parity tests; the step path never needs it in memory.  None of them modifies the tables. */
 int glove_passes_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                      void *ws, size_t ws_bytes, void *stream);
 int glove_rowpass_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,

@@ -150,7 +150,7 @@ def test_per_pair_error_coefficients(hip):
     dt = tables_from_oracle(t, DeviceTables)
     plan = hip.build_plan(*to_dev(row, col, w, y), V)
     ws = hip.step_workspace(plan, d)
-    hip.rowpass(plan, dt, _hyper(hp, B), ws)
+    hip.rowpass(plan, dt, _hyper(hp, B), ws)       # the standalone row pass is the one that stores e
     torch.cuda.synchronize()
     e_dev = ws[:4 * B].view(torch.float32).cpu().numpy()     # first array of the workspace, row-sorted order
     gr = ref.gradients(t, row, col, w, y, hp)

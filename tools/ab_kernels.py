@@ -19,13 +19,14 @@ def main():
     ap.add_argument("--workload", default="text8_d64")
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--caps", default="32,16")
-    ap.add_argument("--variants", default="0")
+    ap.add_argument("--libs", default="", help="comma-separated builds of libglove_hip.so to compare (default: the shipped one)")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=40)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    hip = GloveHip(dev)
-    set_variant = getattr(hip.lib, "glove_debug_set_variant", None)   # only in diagnostic builds
+    libs = [x for x in args.libs.split(",") if x] or [None]
+    hips = [GloveHip(dev, lib_path=x) if x else GloveHip(dev) for x in libs]
+    hip = hips[0]
     wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], args.batch_size
     nb = min(8, wl["row"].numel() // B)
@@ -36,15 +37,14 @@ def main():
     for cap in [int(c) for c in args.caps.split(",")]:
         plans = [hip.build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
                                 chunk_cap=cap, compact=True) for b in range(nb)]
-        for v in [int(x) for x in args.variants.split(",")]:
+        for v in range(len(hips)):
             configs.append((cap, v, plans))
     ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     res = {(c, v): {"rowpass": [], "colpass": [], "passes": [], "apply": [], "step": []} for c, v, _ in configs}
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for rnd in range(args.rounds + 1):
         for cap, v, plans in configs:
-            if set_variant is not None:
-                set_variant(v)
+            hip = hips[v]
             for name in ("rowpass", "colpass", "passes", "apply", "step"):
                 fn = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws),
                       "passes": lambda p: hip.passes(p, tables, hyper, ws),
@@ -63,7 +63,7 @@ def main():
                     res[(cap, v)][name].append(a.elapsed_time(b) * 1e3 / args.reps)
     print("%s B=%d d=%d  (us per launch incl. launch gaps; median / min over %d rounds)" % (args.workload, B, d, args.rounds))
     for (cap, v), r in res.items():
-        print("cap=%-3d variant=%d  " % (cap, v) + "  ".join(
+        print("cap=%-3d lib=%s  " % (cap, libs[v] or "shipped") + "  ".join(
             "%s %.2f/%.2f" % (k, statistics.median(x), min(x)) for k, x in r.items()))
 
 
