@@ -216,10 +216,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One hipGraph holds a full sweep over the resident batches (nb steps); it is replayed
-    # steps // nb times and the remainder runs eagerly, so exactly `steps` steps are timed.
+    # One hipGraph holds whole sweeps over the resident batches (spg steps); it is replayed
+    # steps // spg times and the remainder runs eagerly, so exactly `steps` steps are timed.
     use_graph = not dense and not args.no_graph
     graph = None
+    spg = nb * ((16 + nb - 1) // nb)          # steps per graph: whole sweeps, at least 16 steps per replay
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -230,15 +231,15 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(nb):
+            for i in range(spg):
                 step(i)
 
     def run(n_steps, first):
         done = 0
         if graph is not None:
-            for _ in range(n_steps // nb):
+            for _ in range(n_steps // spg):
                 graph.replay()
-            done = (n_steps // nb) * nb
+            done = (n_steps // spg) * spg
         for i in range(done, n_steps):
             step(first + i)
 
