@@ -984,4 +984,14 @@ int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_
     return glove_dense_adam_f32(t, h, G_flat, loss_out, stream);
 }
 
+int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t, const glove_hyper *h,
+                         void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream)
+{
+    if (!plans || n < 0) return GLOVE_E_BADARG;
+    for (int32_t i = 0; i < n; ++i)
+        if (int rc = glove_step_adam_f32(plans[i], t, h, ws, ws_bytes, G_flat, i == n - 1 ? loss_out : nullptr, stream))
+            return rc;
+    return 0;
+}
+
 }  // extern "C"

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_fill_records", "glove_step_workspace_bytes",
     "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
-    "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
+    "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
 )
 
@@ -106,6 +106,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_steps_adagrad_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
+        "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
         "glove_topk_cosine_f32": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
@@ -439,6 +440,17 @@ class GloveHip:
         _check(self.lib.glove_step_adam_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
                                             _ptr(ws), ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_step_adam_f32")
+
+    def steps_adam(self, plans, tables, hyper, G_flat, loss_out=None):
+        """len(plans) consecutive Adam steps from one host call."""
+        if not plans:
+            return
+        big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
+        ws = self.step_workspace(big, tables.d)
+        arr = (C.POINTER(GlovePlan) * len(plans))(*[C.pointer(p.struct()) for p in plans])
+        _check(self.lib.glove_steps_adam_f32(arr, len(plans), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
+                                             ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
+               "glove_steps_adam_f32")
 
     # ---- eval / predict
     def eval_sums(self, row, col, w, y, tables, sums=None) -> torch.Tensor:

@@ -43,6 +43,9 @@ class HipBackend:
     def steps_sparse_adagrad(self, plans, tables, hyper, loss_out):
         self.hip.steps_adagrad(plans, tables, hyper, loss_out)
 
+    def steps_dense_adam(self, plans, tables, hyper, G, loss_out):
+        self.hip.steps_adam(plans, tables, hyper, G, loss_out)
+
     def local_dense_grad(self, plan, tables, hyper, G):
         self.hip.passes(plan, tables, hyper)
         self.hip.dense_grad(plan, tables, hyper, G)
@@ -95,9 +98,11 @@ class Stepper:
         self.backend.apply_dense(self.tables, self.hyper, self.G, self.loss_out)
 
     def step_many(self, plans):
-        """Several consecutive steps; on one GPU with sparse Adagrad they are issued by one C call."""
+        """Several consecutive steps; on one GPU they are issued by one C call."""
         if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
             self.backend.steps_sparse_adagrad(plans, self.tables, self.hyper, self.loss_out)
+        elif (self.world == 1 and self.tables.optimizer == "Adam" and hasattr(self.backend, "steps_dense_adam")):
+            self.backend.steps_dense_adam(plans, self.tables, self.hyper, self.G, self.loss_out)
         else:
             for plan in plans:
                 self.step(plan)

@@ -187,6 +187,10 @@ int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glo
                             const glove_hyper *h, void *ws, size_t ws_bytes, float *loss_out, void *stream);
 int glove_step_adam_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
+/* n consecutive Keras-legacy Adam steps from one host call; G_flat is left zeroed after every step. */
+int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
+                         const glove_hyper *h, void *ws, size_t ws_bytes, float *G_flat, float *loss_out,
+                         void *stream);
 
 /* ---- EVAL mode of model_fn: RegressionHead metrics over a batch (estimator.py:48-56) -------
  * Accumulates into sums_out (device double[4]): sum w (p-y)^2, sum w, sum w p, sum w y. */
