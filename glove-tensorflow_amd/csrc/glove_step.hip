@@ -705,6 +705,7 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
+    if (t->d_model < 0 || t->d_model > t->d) return GLOVE_E_BADARG;
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     return 0;
 }
@@ -743,14 +744,15 @@ static IdWork id_work(const glove_plan *p)
 static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
 {
     StepConsts k;
-    k.kappa = 2.0f * h->reg_mult * h->l2_reg / (float)t->d * h->inv_batch;
+    const float dm = (float)(t->d_model > 0 ? t->d_model : t->d);      // the reference's embedding size
+    k.kappa = 2.0f * h->reg_mult * h->l2_reg / dm * h->inv_batch;
     k.kappa_b = 2.0f * h->reg_mult * h->l2_reg * h->inv_batch;
     k.lr = h->learning_rate;
     k.eps = h->epsilon;
     k.l2 = h->l2_reg;
     k.m = h->reg_mult;
     k.inv_batch = h->inv_batch;
-    k.inv_d = 1.0f / (float)t->d;
+    k.inv_d = 1.0f / dm;
     return k;
 }
 
@@ -916,7 +918,8 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
 static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_flat, bool adam, DenseSegs &segs,
                         float *&tail, int &nbx, int &sides)
 {
-    if (!t || !h || !G_flat || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    if (!t || !h || !G_flat || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0 || t->d_model < 0 || t->d_model > t->d)
+        return GLOVE_E_BADARG;
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
     if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
     if (adam && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;

@@ -44,7 +44,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 
 
 class GloveTables(C.Structure):
-    _fields_ = [("V", C.c_int32), ("d", C.c_int32), ("V_row", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("V", C.c_int32), ("d", C.c_int32), ("V_row", C.c_int32), ("d_model", C.c_int32),
                 ("R", _fp), ("C", _fp), ("br", _fp), ("bc", _fp),
                 ("s1_R", _fp), ("s1_C", _fp), ("s1_br", _fp), ("s1_bc", _fp),
                 ("s2_R", _fp), ("s2_C", _fp), ("s2_br", _fp), ("s2_bc", _fp),
@@ -150,13 +150,17 @@ class DeviceTables:
 
     def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None,
                  V_row: int | None = None):
-        """`V_row` < V: this process holds only a shard of the row table (row ids handed to the kernels
+        """`d`: --embedding-size, any positive int.  Rows are stored 16-byte aligned: `self.d` is the row
+        stride (d rounded up to a multiple of 4, what the kernels and workspace queries take), `self.d_model`
+        the reference's embedding size; the padding columns are zero and stay zero (glove_tables.d_model).
+        `V_row` < V: this process holds only a shard of the row table (row ids handed to the kernels
         are then local indices into the shard); the col table always has V rows."""
-        if d % 4 != 0:
-            raise ValueError("embedding size must be a multiple of 4 (16-byte rows), got %d" % d)
+        if d <= 0:
+            raise ValueError("embedding size must be positive, got %d" % d)
         if optimizer not in ("Adagrad", "Adam"):
             raise ValueError("optimizer must be 'Adagrad' or 'Adam' (Keras names), got %r" % (optimizer,))
-        self.V, self.d, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
+        self.V, self.d_model, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
+        self.d = (int(d) + 3) // 4 * 4
         self.V_row = int(V if V_row is None else V_row)
         if not 0 < self.V_row <= self.V:
             raise ValueError("V_row must be in (0, V]")
@@ -169,7 +173,12 @@ class DeviceTables:
         def uni(*shape):  # Keras Embedding default: U(-0.05, 0.05)
             return ((torch.rand(*shape, generator=gen, dtype=torch.float32) - 0.5) * 0.1).to(self.device)
 
-        self.R, self.C = uni(self.V_row, d), uni(V, d)
+        def table(rows):
+            t = torch.zeros(rows, self.d, dtype=torch.float32, device=self.device)
+            t[:, :self.d_model] = uni(rows, self.d_model)
+            return t
+
+        self.R, self.C = table(self.V_row), table(V)
         self.br, self.bc = uni(self.V_row), uni(V)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -189,6 +198,7 @@ class DeviceTables:
         if self._struct is None:
             s = GloveTables()
             s.V, s.d, s.V_row = self.V, self.d, (0 if self.V_row == self.V else self.V_row)
+            s.d_model = 0 if self.d_model == self.d else self.d_model
             for n in self.NAMES:
                 setattr(s, n, _ptr(getattr(self, n)))
                 setattr(s, "s1_" + n, _ptr(self.s1[n]))
@@ -197,28 +207,41 @@ class DeviceTables:
             self._struct = s
         return self._struct
 
-    # ---- (de)serialisation used by the checkpoint code and the tests
+    def embeddings(self, name: str) -> torch.Tensor:
+        """R or C without the alignment padding: [rows, d_model] (a view)."""
+        return getattr(self, name)[:, :self.d_model]
+
+    # ---- (de)serialisation used by the checkpoint code and the tests: logical shapes [rows, d_model]
+    def _logical(self, x):
+        return (x[:, :self.d_model] if x.dim() == 2 else x).cpu()
+
+    def _store(self, dst, src):
+        if dst.dim() == 2:
+            dst[:, :self.d_model].copy_(src)
+        else:
+            dst.copy_(src)
+
     def state_dict(self) -> dict:
-        out = {"V": self.V, "d": self.d, "V_row": self.V_row, "optimizer": self.optimizer,
+        out = {"V": self.V, "d": self.d_model, "V_row": self.V_row, "optimizer": self.optimizer,
                "scalars": self.scalars.cpu(), "global_step": self.step.cpu()}
         for n in self.NAMES:
-            out[n] = getattr(self, n).cpu()
-            out["slot1_" + n] = self.s1[n].cpu()
+            out[n] = self._logical(getattr(self, n))
+            out["slot1_" + n] = self._logical(self.s1[n])
             if n in self.s2:
-                out["slot2_" + n] = self.s2[n].cpu()
+                out["slot2_" + n] = self._logical(self.s2[n])
         return out
 
     def load_state_dict(self, sd: dict):
-        if (sd["V"], sd["d"], sd["optimizer"], sd.get("V_row", sd["V"])) != (self.V, self.d, self.optimizer, self.V_row):
+        if (sd["V"], sd["d"], sd["optimizer"], sd.get("V_row", sd["V"])) != (self.V, self.d_model, self.optimizer, self.V_row):
             raise ValueError("checkpoint is for V=%s d=%s %s, model is V=%d d=%d %s" % (
-                sd["V"], sd["d"], sd["optimizer"], self.V, self.d, self.optimizer))
+                sd["V"], sd["d"], sd["optimizer"], self.V, self.d_model, self.optimizer))
         self.scalars.copy_(sd["scalars"])
         self.step.copy_(sd["global_step"])
         for n in self.NAMES:
-            getattr(self, n).copy_(sd[n])
-            self.s1[n].copy_(sd["slot1_" + n])
+            self._store(getattr(self, n), sd[n])
+            self._store(self.s1[n], sd["slot1_" + n])
             if n in self.s2:
-                self.s2[n].copy_(sd["slot2_" + n])
+                self._store(self.s2[n], sd["slot2_" + n])
 
     @property
     def global_bias(self) -> float:

@@ -28,8 +28,8 @@ class MatrixFactorisation:
 def get_named_variables(model: MatrixFactorisation) -> dict:
     """Reference model_utils.py:66-78 (the tensors, not Keras layers)."""
     t = model.tables
-    return {"global_bias": t.scalars[0], "row_biases": t.br, "row_embeddings": t.R, "col_biases": t.bc,
-            "col_embeddings": t.C}
+    return {"global_bias": t.scalars[0], "row_biases": t.br, "row_embeddings": t.embeddings("R"), "col_biases": t.bc,
+            "col_embeddings": t.embeddings("C")}
 
 
 def get_predictions(hip, model: MatrixFactorisation, input_ids: torch.Tensor, id_string_table: list, top_k=TOP_K):
@@ -42,7 +42,7 @@ def get_predictions(hip, model: MatrixFactorisation, input_ids: torch.Tensor, id
     lookup = lambda i: id_string_table[i] if 0 <= i < len(id_string_table) else "<UNK>"
     return {
         "input_string": [lookup(i) for i in ids.tolist()],
-        "input_embedding": R[ids.long()].cpu(),
+        "input_embedding": model.tables.embeddings("R")[ids.long()].cpu(),
         "top_k_similarity": sims.cpu(),
         "top_k_string": [[lookup(i) for i in r] for r in idx.tolist()],
     }

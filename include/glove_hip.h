@@ -35,11 +35,14 @@ extern "C" {
  * slot2 = v (reference src/models/train_utils.py:13-16 picks the Keras optimizer by name). */
 typedef struct glove_tables {
     int32_t V;                  /* vocab size = lines of vocab.txt (reference estimator.py:31) */
-    int32_t d;                  /* embedding size (--embedding-size) */
+    int32_t d;                  /* floats per table row: --embedding-size rounded up to a multiple of 4 (16-B rows) */
     int32_t V_row;              /* rows of R / br held by this process; 0 = V.  Smaller than V when the
                                  * row table is sharded over ranks (BASELINE config 5): row ids in the
                                  * plans are then LOCAL indices into the shard */
-    int32_t reserved;
+    int32_t d_model;            /* --embedding-size itself, 0 = d.  The activity-L2 coefficient is l2/d_model
+                                 * (model_utils.py:8); columns d_model..d-1 of R, C and their slots are padding:
+                                 * they must start at zero (Adagrad accumulator: any value) and every kernel
+                                 * keeps them exactly zero, so dots, norms and gradients ignore them */
     float *R, *C;               /* row_embedding / col_embedding [V,d] (model_utils.py:31-34) */
     float *br, *bc;             /* row_bias / col_bias [V]         (model_utils.py:32-36) */
     float *s1_R, *s1_C, *s1_br, *s1_bc;   /* slot 1, same shapes */

@@ -36,13 +36,17 @@ def tables_from_oracle(t: "ref.Tables", DeviceTables, device="cuda:0"):
     """Device tables holding exactly the (fp32-rounded) oracle state."""
     dt = DeviceTables(t.V, t.d, t.optimizer, device=device, seed=0)
     f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(device)
+    dm = dt.d_model                    # device rows are padded to a multiple of 4 floats; the padding stays zero
+
+    def put(dst, a):
+        (dst[:, :dm] if dst.dim() == 2 else dst).copy_(f(a))
     for n in ("R", "C", "br", "bc"):
-        getattr(dt, n).copy_(f(getattr(t, n)))
+        put(getattr(dt, n), getattr(t, n))
         if t.optimizer == "Adagrad":
-            dt.s1[n].copy_(f(getattr(t, "A_" + n)))
+            put(dt.s1[n], getattr(t, "A_" + n))
         else:
-            dt.s1[n].copy_(f(getattr(t, "M_" + n)))
-            dt.s2[n].copy_(f(getattr(t, "V_" + n)))
+            put(dt.s1[n], getattr(t, "M_" + n))
+            put(dt.s2[n], getattr(t, "V_" + n))
     sc = np.zeros(8, np.float32)
     sc[0] = t.g
     if t.optimizer == "Adagrad":
@@ -62,13 +66,15 @@ def oracle_tables(V, d, optimizer, seed=1):
 
 
 def assert_tables_close(dt, t, rtol=1e-5, atol=1e-6):
+    dm = dt.d_model
+    got = lambda x: (x[:, :dm] if x.dim() == 2 else x).cpu().numpy()
     for n in ("R", "C", "br", "bc"):
-        np.testing.assert_allclose(getattr(dt, n).cpu().numpy(), getattr(t, n), rtol=rtol, atol=atol, err_msg=n)
+        np.testing.assert_allclose(got(getattr(dt, n)), getattr(t, n), rtol=rtol, atol=atol, err_msg=n)
         slot = "A_" if t.optimizer == "Adagrad" else "M_"
-        np.testing.assert_allclose(dt.s1[n].cpu().numpy(), getattr(t, slot + n), rtol=rtol, atol=atol,
-                                   err_msg=slot + n)
+        np.testing.assert_allclose(got(dt.s1[n]), getattr(t, slot + n), rtol=rtol, atol=atol, err_msg=slot + n)
         if t.optimizer == "Adam":
-            np.testing.assert_allclose(dt.s2[n].cpu().numpy(), getattr(t, "V_" + n), rtol=rtol, atol=1e-9,
-                                       err_msg="V_" + n)
+            np.testing.assert_allclose(got(dt.s2[n]), getattr(t, "V_" + n), rtol=rtol, atol=1e-9, err_msg="V_" + n)
+        if getattr(dt, n).dim() == 2 and dt.d > dm:      # alignment padding must stay exactly zero
+            assert float(getattr(dt, n)[:, dm:].abs().max()) == 0.0, n + " padding moved"
     np.testing.assert_allclose(dt.scalars[0].item(), t.g, rtol=rtol, atol=atol, err_msg="global_bias")
     assert dt.global_step == t.step

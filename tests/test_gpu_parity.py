@@ -121,6 +121,8 @@ STEP_CASES = [
     (7, 50, 8, 32), (64, 50, 64, 4), (1024, 300, 64, 32), (1024, 50, 128, 32), (1024, 120, 300, 32),
     (3000, 40, 16, 2), (4096, 500, 256, 8), (2048, 64, 512, 32), (2048, 64, 1024, 32), (512, 64, 768, 16),
     (20000, 2000, 64, 32), (1024, 12000, 64, 32), (777, 33, 96, 5), (900, 70, 384, 7),
+    # embedding sizes that are not a multiple of 4: rows are padded to 16 B, the reference's d enters l2/d
+    (1024, 300, 50, 32), (513, 40, 2, 8), (2048, 90, 150, 16), (700, 60, 301, 32), (640, 77, 1, 4),
 ]
 
 
@@ -183,7 +185,8 @@ def test_trajectory(hip, optimizer, B, V, d):
         assert float(G.abs().max()) == 0.0     # the dense apply leaves the gradient buffer zeroed
 
 
-@pytest.mark.parametrize("B,V,d,cap", [(7, 50, 8, 32), (1024, 300, 64, 32), (1024, 120, 300, 32), (5000, 60, 64, 4)])
+@pytest.mark.parametrize("B,V,d,cap", [(7, 50, 8, 32), (1024, 300, 64, 32), (1024, 120, 300, 32), (5000, 60, 64, 4),
+                                       (1024, 200, 50, 32), (300, 31, 3, 8)])
 def test_adam_single_step_dense_decay(hip, B, V, d, cap):
     """Keras-legacy Adam: every row moves, also untouched ones."""
     from trainer.hip_api import DeviceTables
@@ -210,7 +213,7 @@ def test_adam_single_step_dense_decay(hip, B, V, d, cap):
         assert (dt.R[untouched] != before[untouched]).any()
 
 
-@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2)])
+@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2), (3000, 150, 50, 16)])
 def test_dense_path_equals_sparse_path_bitwise(hip, B, V, d, cap):
     """dense_grad + dense_adagrad (the data-parallel form) == sparse apply, bit for bit: both sum
     the same partials in the same order and G = 0 is an exact no-op for Adagrad."""
@@ -328,11 +331,15 @@ def test_topk_cosine(hip, V, d, k):
 def test_argument_errors_are_reported_not_swallowed(hip):
     from trainer.hip_api import DeviceTables, GloveHipError
     with pytest.raises(ValueError):
-        DeviceTables(10, 6, "Adagrad")
+        DeviceTables(10, 0, "Adagrad")
     with pytest.raises(ValueError):
         DeviceTables(10, 8, "SGD")
     row, col, w, y = make_batch(1, 64, 10)
     dt = DeviceTables(10, 8, "Adagrad", seed=0)
+    bad = DeviceTables(10, 8, "Adagrad", seed=0)
+    bad.struct().d_model = 9                       # more model columns than the row stride holds
+    with pytest.raises(GloveHipError, match="BADARG"):
+        hip.step_adagrad(hip.build_plan(*to_dev(row, col, w, y), 10), bad, _hyper(ref.Hyper(), 64))
     plan = hip.build_plan(*to_dev(row, col, w, y), 10)
     tiny = torch.empty(16, dtype=torch.uint8, device="cuda:0")
     with pytest.raises(GloveHipError, match="WORKSPACE"):

@@ -19,8 +19,8 @@ def test_cli_train_resume_export(hip, tmp_path):
     csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
     job = tmp_path / "job"
     argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
-            "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
-            "--train-steps", "60", "--log-every", "20", "--seed", "7"]
+            "--embedding-size", "50", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+            "--train-steps", "60", "--log-every", "20", "--seed", "7"]      # 50: not a multiple of 4 (padded rows)
     estimator.main(argv)
     assert (job / "params.json").exists() and (job / vocab.name).exists()
     assert (job / "checkpoint").read_text().startswith('model_checkpoint_path: "model.ckpt-60"')
@@ -42,7 +42,7 @@ def test_cli_train_resume_export(hip, tmp_path):
     emb = json.loads(out.read_text())
     tokens = vocab.read_text().split("\n")
     assert set(emb) == set(tokens) - {"<UNK>"} and "nan" in emb
-    assert emb["the"]["item_id"] == "the" and len(emb["the"]["item_embedding"]) == 16
+    assert emb["the"]["item_id"] == "the" and len(emb["the"]["item_embedding"]) == 50
     # predictions: the query token is its own nearest neighbour (reference README.md:284)
     params = json.loads((job / "params.json").read_text())
     first = next(iter(estimator.Estimator(params).predict()))
