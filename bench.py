@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="control-flow rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
+                         "collectives go through gloo; its numbers mean nothing")
     return ap.parse_args()
 
 
@@ -131,6 +134,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -142,7 +147,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:      # --force-dense on a single GPU without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from trainer import synthetic
     from trainer.hip_api import DeviceTables, GloveHip, make_hyper
@@ -162,6 +170,12 @@ def main():
     nb = min(max(1, nnz // B), args.max_batches)
     if nnz < B:
         raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))
+    if dist is not None and world > 1:
+        # every rank's shard has its own nonzero count: agree on the number of resident batches, so that all
+        # ranks issue the same number of collectives in every loop below
+        agreed = torch.tensor([nb], dtype=torch.int64, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        nb = int(agreed.item())
 
     # ---- load time (untimed): resident batches + their dedup index
     batches, plans = [], []
