@@ -2,6 +2,7 @@
 gates of SURVEY.md §8d (same batches + same init for 1,024 steps at bs = 1,024: 100-step-smoothed
 loss within 1 % of the CPU restatement, top-20 neighbour overlap >= 0.9 on probe tokens)."""
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -154,3 +155,50 @@ def test_whole_pipeline_recovers_planted_topics(hip, tmp_path):
         same += sum(n[:2] == word[:2] for n in neighbours)
         total += len(neighbours)
     assert total >= topics * words_per * 9 and same / total > 0.6, (same, total)       # chance level: 0.12; 0.76 observed
+
+
+def _two_rank_trainer(rank, port, argv, out_dir):
+    """One rank of `python -m trainer.estimator` under a launcher, both ranks on the box's one GPU: the HIP
+    kernels are the product's, only the transport of the collectives is gloo instead of RCCL."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = Path(__file__).resolve().parent
+    for p in (here.parent, here):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+    from trainer import estimator
+    from trainer.config_utils import parse_args
+    from trainer.stepper import HipBackend
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    box = [parse_args(argv) if rank == 0 else None]          # as trainer.estimator.main: rank 0 decides job_dir
+    dist.broadcast_object_list(box, src=0)
+    params = box[0]
+    est = estimator.Estimator(params, backend=HipBackend("cuda:0"), dist=dist, device="cuda:0")
+    est.train(params["train_steps"])
+    t = est.model.tables
+    torch.save({"R": t.R.cpu(), "C": t.C.cpu(), "br": t.br.cpu(), "bc": t.bc.cpu(), "g": t.global_bias,
+                "step": t.global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
+    """The multi-rank host loop end to end (sharded stream, agreed seed, dense-gradient all-reduce, rank-0
+    checkpoints, collective eval): replicas stay bit-identical, the loss falls, only rank 0 writes."""
+    import torch.multiprocessing as mp
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+            "--train-steps", "60", "--log-every", "20"]                # unseeded: rank 0 draws the seed for both
+    mp.spawn(_two_rank_trainer, args=(29700 + os.getpid() % 200, argv, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(a[n], b[n]), n
+    assert a["g"] == b["g"] and a["step"] == b["step"] == 60
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert [r["global_step"] for r in log] == [20, 40, 60] and log[-1]["loss"] < log[0]["loss"]
+    assert (job / "model.ckpt-60.pt").exists()
+    ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+    assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
