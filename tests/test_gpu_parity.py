@@ -114,6 +114,14 @@ def test_plan_empty_batch(hip):
     f = torch.empty(0, dtype=torch.float32, device="cuda:0")
     plan = hip.build_plan(e, e, f, f, 10)
     assert plan.counts.tolist() == [0] * 8
+    # a step over it launches, moves no row and advances global_step (the reference never feeds one:
+    # its training input repeats forever in full batches, data_utils.py:12-21)
+    from trainer.hip_api import DeviceTables
+    dt = DeviceTables(10, 8, "Adagrad", seed=0)
+    before = dt.R.clone()
+    loss_out = torch.ones(4, device="cuda:0")
+    hip.step_adagrad(plan, dt, _hyper(ref.Hyper(), 1), loss_out)
+    assert torch.equal(dt.R, before) and dt.global_step == 1 and loss_out[:3].tolist() == [0.0, 0.0, 0.0]
 
 
 # (B, V, d, chunk_cap): d covers every (lanes-per-row, float4-per-lane) kernel shape
