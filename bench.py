@@ -277,7 +277,12 @@ def main():
     kern = {}
     reps = max(nb, min(200, args.steps))
     calls = {"passes": lambda p: hip.passes(p, tables, hyper, ws)}      # row side + col side, one launch
-    if adam:
+    adam_fused = adam and 2 * B <= V_row + V          # glove_step_adam_f32's own rule (include/glove_hip.h)
+    if adam_fused:
+        # passes (+ id marks) and ONE fused apply/decay kernel; the second kernel has no entry point of its own,
+        # so it is timed as the whole step minus the passes
+        calls["step_adam"] = lambda p: hip.step_adam(p, tables, hyper, G, loss_out, ws)
+    elif adam:
         calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
         calls["dense_adam"] = lambda p: hip.dense_adam(tables, hyper, G, loss_out)
     elif not dense:
@@ -315,6 +320,8 @@ def main():
             torch.cuda.synchronize()
             spans.append(a.elapsed_time(b) * 1e3 / reps)
         kern[name] = sorted(spans)[1]
+    if adam_fused:
+        kern["adam_fused"] = kern.pop("step_adam") - kern["passes"]
     if G is not None:
         G.zero_()
     # attribution of the algorithmic bytes to the two kernels of the sparse step: the pass kernel

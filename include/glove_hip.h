@@ -188,6 +188,10 @@ int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const 
  * receives the scalars of the LAST step. */
 int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
                             const glove_hyper *h, void *ws, size_t ws_bytes, float *loss_out, void *stream);
+/* One Keras-legacy Adam step.  G_flat (glove_dense_grad_floats floats, all zero on entry) is scratch and is all zero
+ * again on return.  A batch of at most (V_row + V) / 2 pairs takes two launches: the passes also mark the batch's
+ * ids (in G_flat's bias segments), then one kernel applies the marked ids and gives every other row the G = 0
+ * update; larger batches run passes + glove_dense_grad_f32 + glove_dense_adam_f32.  Same result bit for bit. */
 int glove_step_adam_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
 /* n consecutive Keras-legacy Adam steps from one host call; G_flat is left zeroed after every step. */

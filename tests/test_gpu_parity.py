@@ -248,6 +248,45 @@ def test_dense_path_equals_sparse_path_bitwise(hip, B, V, d, cap):
     assert float(G.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,V,d,cap", [(200, 1000, 64, 32), (1024, 3000, 50, 16), (64, 500, 300, 32), (300, 5000, 8, 2),
+                                       (400, 2000, 128, 2)])
+def test_adam_fused_step_equals_the_dense_form_bitwise(hip, B, V, d, cap):
+    """glove_step_adam_f32 on a batch that touches a minority of the rows (passes that mark the ids + ONE kernel
+    that applies them and decays every other row) == passes + dense_grad + dense_adam, bit for bit; the
+    gradient buffer is all zero again afterwards; both within tolerance of the oracle."""
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B + d, B, V)
+    row[::3] = 3                                   # one id far over the heavy threshold at small caps
+    assert 2 * B <= 2 * V
+    hp = ref.Hyper(learning_rate=0.001)
+    t = oracle_tables(V, d, "Adam")
+    rng = np.random.default_rng(5)
+    for n in ("R", "C", "br", "bc"):
+        setattr(t, "M_" + n, rng.normal(0, 1e-3, getattr(t, n).shape).astype(np.float32).astype(np.float64))
+        setattr(t, "V_" + n, (rng.uniform(0, 1e-5, getattr(t, n).shape)).astype(np.float32).astype(np.float64))
+    t.step = 17
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    h = _hyper(hp, B)
+    Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    for _ in range(2):                             # twice: the marks of step 1 must be gone in step 2
+        hip.step_adam(plan, a, h, Ga, la)
+        hip.passes(plan, b, h)
+        hip.dense_grad(plan, b, h, Gb)
+        hip.dense_adam(b, h, Gb, lb)
+        assert float(Ga.abs().max()) == 0.0
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+        assert torch.equal(a.s1[n], b.s1[n]) and torch.equal(a.s2[n], b.s2[n]), "slots " + n
+    assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step == 19
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-6)
+    ref.train_step(t, row, col, w, y, hp)
+    loss, L, reg = ref.train_step(t, row, col, w, y, hp)
+    np.testing.assert_allclose(la.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
+    assert_tables_close(a, t, PARAM_RTOL, PARAM_ATOL)
+
+
 def test_step_is_bitwise_repeatable(hip):
     from trainer.hip_api import DeviceTables
     B, V, d = 20000, 500, 64
