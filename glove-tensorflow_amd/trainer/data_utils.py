@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 logger = logging.getLogger(__name__)
+CSV_SLAB_ROWS = 4_000_000
 
 
 def file_lines(fname) -> int:
@@ -83,12 +84,14 @@ def load_interaction_csv(file_pattern, vocab_txt, row_name="row_token", col_name
     table = get_string_id_table(vocab_txt)
     parts = []
     for p in paths:
-        df = pd.read_csv(p, usecols=columns, dtype={row_name: str, col_name: str, weight_name: np.float32,
-                                                    target_name: np.float32},
-                         keep_default_na=False, na_filter=False)
-        row = df[row_name].map(table).fillna(0).to_numpy(np.int32)   # OOV -> 0
-        col = df[col_name].map(table).fillna(0).to_numpy(np.int32)
-        parts.append((row, col, df[weight_name].to_numpy(np.float32), df[target_name].to_numpy(np.float32)))
+        # read in slabs: the token columns of a 200 M-row file (BASELINE config 4) do not fit in host memory as
+        # Python strings, the 16 B/row binary COO does
+        for df in pd.read_csv(p, usecols=columns, dtype={row_name: str, col_name: str, weight_name: np.float32,
+                                                         target_name: np.float32},
+                              keep_default_na=False, na_filter=False, chunksize=CSV_SLAB_ROWS):
+            row = df[row_name].map(table).fillna(0).to_numpy(np.int32)   # OOV -> 0
+            col = df[col_name].map(table).fillna(0).to_numpy(np.int32)
+            parts.append((row, col, df[weight_name].to_numpy(np.float32), df[target_name].to_numpy(np.float32)))
     out = {k: np.concatenate([p[i] for p in parts]) for i, k in enumerate(("row", "col", "w", "y"))}
     if cache:
         np.savez(cache, **out)

@@ -72,3 +72,13 @@ def test_csv_loader_reproduces_reference_ids(tag, tmp_path):
     # second call is served from the binary COO cache
     again = load_interaction_csv(str(csv), str(vocab), cache_dir=str(tmp_path))
     assert list(tmp_path.glob("interaction-*.coo.npz")) and (again["row"] == coo["row"]).all()
+    # the file is read in slabs (bounded host memory for 10^8-row files): slab boundaries change nothing
+    from trainer import data_utils
+    monkey = data_utils.CSV_SLAB_ROWS
+    try:
+        data_utils.CSV_SLAB_ROWS = 97
+        slabs = load_interaction_csv(str(csv), str(vocab))
+    finally:
+        data_utils.CSV_SLAB_ROWS = monkey
+    for k in ("row", "col", "w", "y"):
+        np.testing.assert_array_equal(slabs[k], coo[k])
