@@ -67,69 +67,208 @@ __global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t 
     }
 }
 
-// seg_start_in[k] = k where a new id starts, else 0 (max-scan turns it into "start of my run")
-__global__ void mark_runs(const int32_t *__restrict__ keys, int64_t n, int32_t *__restrict__ run_start)
+// ---- chunk / id numbering of BOTH sides in two launches --------------------------------------------------
+// A side's structure follows from its sorted keys alone: position k opens a new id where keys[k] != keys[k-1], and
+// a new chunk where it opens an id or lies a multiple of chunk_cap behind the start of its run.  Numbering those
+// flags needs prefix sums over the whole batch; instead of two device-wide scans per side (eight launches with the
+// marking kernels around them) the batch is cut into tiles of kTile positions, one workgroup each:
+//   side_tiles  counts the flags of every tile.  The only thing a tile needs from outside is where the run that
+//               crosses its left edge started: one binary search over the sorted keys by one thread;
+//   side_emit   adds up the counts of the tiles to its left (a block reduction over at most B / kTile pairs),
+//               recomputes its flags, numbers them with one block scan and writes chunk_id / chunk_start /
+//               uniq_slot; the last tile also writes the totals and the closing entries.
+// blockIdx.y selects the side.  Bit-exact against oracle/glove_ref.py:build_plan like the scans it replaces.
+__device__ inline int wave_sum_int(int v)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        run_start[i] = (i == 0 || keys[i] != keys[i - 1]) ? (int32_t)i : 0;
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
+    return v;
 }
 
-// flags packed as (is_unique << 32) | is_chunk so that one 64-bit sum-scan numbers both
-__global__ void mark_chunks(const int32_t *__restrict__ keys, const int32_t *__restrict__ run_start, int64_t n,
-                            int32_t chunk_cap, uint64_t *__restrict__ flags)
+constexpr int kTileThreads = 256;
+constexpr int kTilePer = 8;                               // consecutive positions per thread
+constexpr int kTile = kTileThreads * kTilePer;
+
+struct SideKeys { const int32_t *keys[2]; };
+struct SideOut {
+    int32_t *chunk_id[2], *chunk_start[2], *uniq_slot[2];
+    int32_t *counts;                                      // plan counts: [0],[1] row side, [2],[3] col side
+};
+
+// flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
+// Leaves the (tile-local) inclusive thread prefix of both counts in lds_u / lds_c for the caller's use.
+__device__ inline void tile_flags(const int32_t *__restrict__ keys, int64_t B, int64_t begin, int32_t chunk_cap,
+                                  int64_t first_run_start, unsigned (&flag)[kTilePer], int &nu, int &nc, int64_t *lds_rs)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const bool uniq = (i == 0 || keys[i] != keys[i - 1]);
-        const bool chunk = uniq || ((i - run_start[i]) % chunk_cap == 0);
-        flags[i] = ((uint64_t)uniq << 32) | (uint64_t)chunk;
+    // start of the run each of my positions belongs to: max-scan of "k where an id opens", seeded from the left
+    const int64_t k0 = begin + (int64_t)threadIdx.x * kTilePer;
+    int32_t key[kTilePer + 1];
+    key[0] = (k0 > 0 && k0 <= B) ? keys[k0 - 1] : -1;
+#pragma unroll
+    for (int i = 0; i < kTilePer; ++i) key[i + 1] = (k0 + i < B) ? keys[k0 + i] : -1;
+    int64_t my_last_start = -1;                            // last id opening among my positions
+#pragma unroll
+    for (int i = 0; i < kTilePer; ++i) {
+        const int64_t k = k0 + i;
+        if (k < B && (k == 0 || key[i + 1] != key[i])) my_last_start = k;
+    }
+    // exclusive max-scan of my_last_start over the threads of the workgroup (wave shuffles, then the 4 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t incl = my_last_start;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int64_t o = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl = o > incl ? o : incl;
+    }
+    if (lane == 63) lds_rs[wave] = incl;
+    __syncthreads();
+    int64_t carry = first_run_start;
+    for (int wv = 0; wv < wave; ++wv) carry = lds_rs[wv] > carry ? lds_rs[wv] : carry;
+    int64_t prev = __shfl_up(incl, 1, 64);
+    if (lane == 0) prev = -1;
+    int64_t run_start = prev > carry ? prev : carry;       // run that is open when my first position begins
+    __syncthreads();
+    nu = nc = 0;
+#pragma unroll
+    for (int i = 0; i < kTilePer; ++i) {
+        const int64_t k = k0 + i;
+        flag[i] = 0;
+        if (k >= B) continue;
+        const bool uniq = (k == 0 || key[i + 1] != key[i]);
+        if (uniq) run_start = k;
+        const bool chunk = uniq || ((int)(k - run_start) % chunk_cap == 0);
+        flag[i] = (chunk ? 1u : 0u) | (uniq ? 2u : 0u);
+        nu += uniq;
+        nc += chunk;
     }
 }
 
-__global__ void emit_side(const int32_t *__restrict__ keys, const uint64_t *__restrict__ flags,
-                          const uint64_t *__restrict__ scanned, int64_t n, int32_t *__restrict__ chunk_id,
-                          int32_t *__restrict__ chunk_start, int32_t *__restrict__ uniq_slot,
-                          int32_t *__restrict__ counts /* [0]=chunks [1]=uniq */)
+// start of the run that position `pos` lies in: first index in [0, pos] holding keys[pos] (keys sorted ascending)
+__device__ inline int64_t run_start_of(const int32_t *__restrict__ keys, int64_t pos)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t f = flags[i], sc = scanned[i];
-        const int32_t ci = (int32_t)(sc & 0xffffffffu) - 1;
-        const int32_t ui = (int32_t)(sc >> 32) - 1;
-        if (f & 1u) { chunk_id[ci] = keys[i]; chunk_start[ci] = (int32_t)i; }
-        if (f >> 32) uniq_slot[ui] = ci;
-        if (i == n - 1) {
-            chunk_start[ci + 1] = (int32_t)n;
-            uniq_slot[ui + 1] = ci + 1;
-            counts[0] = ci + 1;
-            counts[1] = ui + 1;
+    const int32_t key = keys[pos];
+    int64_t lo = 0, hi = pos;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
+                                                           int64_t *__restrict__ tile_rs, int2 *__restrict__ tile_sums)
+{
+    __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
+    __shared__ int red[2][kTileThreads / 64];
+    const int side = blockIdx.y, t = blockIdx.x;
+    const int32_t *keys = sk.keys[side];
+    const int64_t begin = (int64_t)t * kTile;
+    if (threadIdx.x == 0) lds_rs[kTileThreads / 64] = begin > 0 ? run_start_of(keys, begin) : 0;
+    __syncthreads();
+    const int64_t frs = lds_rs[kTileThreads / 64];
+    unsigned flag[kTilePer];
+    int nu, nc;
+    tile_flags(keys, B, begin, chunk_cap, frs, flag, nu, nc, lds_rs);
+    nu = wave_sum_int(nu);
+    nc = wave_sum_int(nc);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nu; red[1][threadIdx.x >> 6] = nc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int su = 0, sc = 0;
+        for (int wv = 0; wv < kTileThreads / 64; ++wv) { su += red[0][wv]; sc += red[1][wv]; }
+        tile_sums[(size_t)side * ntiles + t] = make_int2(su, sc);
+        tile_rs[(size_t)side * ntiles + t] = frs;
+    }
+}
+
+__global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
+                                                          const int64_t *__restrict__ tile_rs,
+                                                          const int2 *__restrict__ tile_sums, SideOut out)
+{
+    __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
+    __shared__ int red[2][kTileThreads / 64];
+    __shared__ int wave_tot[2][kTileThreads / 64];
+    const int side = blockIdx.y, t = blockIdx.x;
+    const int32_t *keys = sk.keys[side];
+    const int64_t begin = (int64_t)t * kTile;
+    // ids / chunks opened by the tiles to my left
+    int pu = 0, pc = 0;
+    for (int i = threadIdx.x; i < t; i += kTileThreads) {
+        const int2 v = tile_sums[(size_t)side * ntiles + i];
+        pu += v.x;
+        pc += v.y;
+    }
+    pu = wave_sum_int(pu);
+    pc = wave_sum_int(pc);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pu; red[1][threadIdx.x >> 6] = pc; }
+    __syncthreads();
+    int base_u = 0, base_c = 0;
+    for (int wv = 0; wv < kTileThreads / 64; ++wv) { base_u += red[0][wv]; base_c += red[1][wv]; }
+    unsigned flag[kTilePer];
+    int nu, nc;
+    tile_flags(keys, B, begin, chunk_cap, tile_rs[(size_t)side * ntiles + t], flag, nu, nc, lds_rs);
+    // exclusive prefix of (nu, nc) over the threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int iu = nu, ic = nc;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int ou = __shfl_up(iu, dlt, 64), oc = __shfl_up(ic, dlt, 64);
+        if (lane >= dlt) { iu += ou; ic += oc; }
+    }
+    if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = ic; }
+    __syncthreads();
+    int ui = base_u + iu - nu, ci = base_c + ic - nc;      // numbers of my first id / chunk opening
+    for (int wv = 0; wv < wave; ++wv) { ui += wave_tot[0][wv]; ci += wave_tot[1][wv]; }
+    const int64_t k0 = begin + (int64_t)threadIdx.x * kTilePer;
+    int32_t *chunk_id = out.chunk_id[side], *chunk_start = out.chunk_start[side], *uniq_slot = out.uniq_slot[side];
+#pragma unroll
+    for (int i = 0; i < kTilePer; ++i) {
+        const int64_t k = k0 + i;
+        if (flag[i] & 2u) uniq_slot[ui++] = ci;
+        if (flag[i] & 1u) { chunk_id[ci] = keys[k]; chunk_start[ci] = (int32_t)k; ++ci; }   // keys[k]: L1-hot, read by tile_flags
+        if (k == B - 1) {                                  // closing entries and totals
+            chunk_start[ci] = (int32_t)B;
+            uniq_slot[ui] = ci;
+            out.counts[2 * side] = ci;
+            out.counts[2 * side + 1] = ui;
         }
     }
 }
 
-// {id, first chunk, chunks, pairs} per distinct id, from the arrays emit_side wrote
+// {id, first chunk, chunks, pairs} per distinct id, from the arrays side_emit wrote (blockIdx.y = side);
 // also appends the ids with more than heavy_chunks chunks to the plan's heavy list (any order)
-__global__ void emit_uniq_rec(const int32_t *__restrict__ counts, const int32_t *__restrict__ chunk_id,
-                              const int32_t *__restrict__ chunk_start, const int32_t *__restrict__ uniq_slot,
-                              int32_t *__restrict__ rec, int side, int heavy_chunks, int cap_heavy,
+struct UniqRecArgs {
+    const int32_t *chunk_id[2], *chunk_start[2], *uniq_slot[2];
+    int32_t *rec[2];
+};
+__global__ void emit_uniq_rec(const int32_t *__restrict__ counts, UniqRecArgs a, int heavy_chunks, int cap_heavy,
                               int32_t *__restrict__ heavy, int32_t *__restrict__ n_heavy)
 {
-    const int nu = counts[1];
+    const int side = blockIdx.y;
+    const int nu = counts[2 * side + 1];
+    const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *uniq_slot = a.uniq_slot[side];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nu; q += gridDim.x * blockDim.x) {
-        const int a = uniq_slot[q], b = uniq_slot[q + 1];
-        reinterpret_cast<int4 *>(rec)[q] = make_int4(chunk_id[a], a, b - a, chunk_start[b] - chunk_start[a]);
-        if (b - a > heavy_chunks) {
+        const int x = uniq_slot[q], y = uniq_slot[q + 1];
+        reinterpret_cast<int4 *>(a.rec[side])[q] = make_int4(chunk_id[x], x, y - x, chunk_start[y] - chunk_start[x]);
+        if (y - x > heavy_chunks) {
             const int slot = atomicAdd(n_heavy, 1);
             if (slot < cap_heavy) heavy[slot] = (side << 30) | q;
         }
     }
 }
 
-// per-chunk records: one thread per (chunk, float4 of the record)
-__global__ void fill_records(const int32_t *__restrict__ counts, int count_index, const int32_t *__restrict__ chunk_id,
-                             const int32_t *__restrict__ chunk_start, const int32_t *__restrict__ partner,
-                             const float *__restrict__ w, const float *__restrict__ y, int capP,
-                             int32_t *__restrict__ crec)
+// per-chunk records of both sides (blockIdx.y = side): one thread per (chunk, float4 of the record)
+struct RecordArgs {
+    const int32_t *chunk_id[2], *chunk_start[2], *partner[2];
+    const float *w[2], *y[2];
+    int32_t *crec[2];
+};
+__global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP)
 {
-    const int n_chunks = counts[count_index];
+    const int side = blockIdx.y;
+    const int n_chunks = counts[2 * side];
+    const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *partner = a.partner[side];
+    const float *w = a.w[side], *y = a.y[side];
     const int rq = 1 + 3 * capP / 4;                       // float4 per record
     const int64_t total = (int64_t)n_chunks * rq;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -148,7 +287,7 @@ __global__ void fill_records(const int32_t *__restrict__ counts, int count_index
             }
             v = make_int4(o[0], o[1], o[2], o[3]);
         }
-        reinterpret_cast<int4 *>(crec)[i] = v;
+        reinterpret_cast<int4 *>(a.crec[side])[i] = v;
     }
 }
 
@@ -156,17 +295,19 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 {
     const int capP = (plan->chunk_cap + 7) & ~7;      // a trip of the pass kernel reads up to 8 slots from q0
     const int64_t work = (int64_t)plan->cap_chunks * (1 + 3 * capP / 4);
-    const int nb = blocks_for(work, kBlock);
-    hipLaunchKernelGGL(fill_records, dim3(nb), dim3(kBlock), 0, st, plan->counts, 0, plan->r_chunk_id, plan->r_chunk_start,
-                       plan->r_partner, plan->r_w, plan->r_y, capP, plan->r_crec);
-    hipLaunchKernelGGL(fill_records, dim3(nb), dim3(kBlock), 0, st, plan->counts, 2, plan->c_chunk_id, plan->c_chunk_start,
-                       plan->c_partner, plan->c_w, plan->c_y, capP, plan->c_crec);
+    const RecordArgs a = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+                          {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
+                          {plan->r_crec, plan->c_crec}};
+    hipLaunchKernelGGL(fill_records, dim3(blocks_for(work, kBlock), 2), dim3(kBlock), 0, st,
+                       (const int32_t *)plan->counts, a, capP);
     return (int)hipGetLastError();
 }
 
 struct PlanWs {
-    int32_t *iota, *perm, *keys_sorted, *row_sorted, *run_start, *row_clean, *col_clean;
-    uint64_t *flags, *scanned;
+    int32_t *iota, *perm, *keys_sorted, *row_sorted, *row_clean, *col_clean;
+    int64_t *tile_rs;    // [2][ntiles] start of the run that crosses a tile's left edge
+    int2 *tile_sums;     // [2][ntiles] (ids, chunks) opened inside a tile
+    int ntiles;
     void *prim;          // rocPRIM temporary storage
     size_t prim_bytes;
     size_t bytes;
@@ -185,11 +326,11 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.perm = (int32_t *)take(n * 4);
     p.keys_sorted = (int32_t *)take(n * 4);
     p.row_sorted = (int32_t *)take(n * 4);
-    p.run_start = (int32_t *)take(n * 4);
     p.row_clean = (int32_t *)take(n * 4);
     p.col_clean = (int32_t *)take(n * 4);
-    p.flags = (uint64_t *)take(n * 8);
-    p.scanned = (uint64_t *)take(n * 8);
+    p.ntiles = (int)((n + kTile - 1) / kTile);
+    p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
+    p.tile_sums = (int2 *)take((size_t)2 * p.ntiles * 8);
     p.prim_bytes = prim_budget(B);
     p.prim = take(p.prim_bytes);
     p.bytes = off;
@@ -204,28 +345,6 @@ static int ceil_log2(int32_t v)
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
-
-static int build_side(const int32_t *keys_sorted, int64_t B, int32_t chunk_cap, const PlanWs &w, int32_t *chunk_id,
-                      int32_t *chunk_start, int32_t *uniq_slot, int32_t *uniq_rec, int32_t cap_uniq, int32_t *counts,
-                      int side, const glove_plan *plan, hipStream_t st)
-{
-    const int nb = blocks_for(B, kBlock);
-    hipLaunchKernelGGL(mark_runs, dim3(nb), dim3(kBlock), 0, st, keys_sorted, B, w.run_start);
-    size_t need = 0;
-    HIP_TRY(rocprim::inclusive_scan(nullptr, need, w.run_start, w.run_start, (size_t)B, rocprim::maximum<int32_t>(), st));
-    if (need > w.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::inclusive_scan(w.prim, need, w.run_start, w.run_start, (size_t)B, rocprim::maximum<int32_t>(), st));
-    hipLaunchKernelGGL(mark_chunks, dim3(nb), dim3(kBlock), 0, st, keys_sorted, w.run_start, B, chunk_cap, w.flags);
-    HIP_TRY(rocprim::inclusive_scan(nullptr, need, w.flags, w.scanned, (size_t)B, rocprim::plus<uint64_t>(), st));
-    if (need > w.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::inclusive_scan(w.prim, need, w.flags, w.scanned, (size_t)B, rocprim::plus<uint64_t>(), st));
-    hipLaunchKernelGGL(emit_side, dim3(nb), dim3(kBlock), 0, st, keys_sorted, w.flags, w.scanned, B, chunk_id,
-                       chunk_start, uniq_slot, counts);
-    hipLaunchKernelGGL(emit_uniq_rec, dim3(blocks_for(cap_uniq, kBlock)), dim3(kBlock), 0, st, counts, chunk_id,
-                       chunk_start, uniq_slot, uniq_rec, side, plan->heavy_chunks, plan->cap_heavy, plan->heavy,
-                       plan->counts + 4);
-    return (int)hipGetLastError();
-}
 
 }  // namespace glove
 
@@ -281,9 +400,6 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                                       (size_t)B, 0, bits, st));
     hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, pw.col_clean, w, y, B, plan->r_partner,
                        plan->r_w, plan->r_y);
-    if (int rc = build_side(pw.row_sorted, B, plan->chunk_cap, pw, plan->r_chunk_id, plan->r_chunk_start,
-                            plan->r_uniq_slot, plan->r_uniq_rec, plan->cap_uniq, plan->counts + 0, 0, plan, st))
-        return rc;
 
     // ---- col side: stable sort of the row-sorted pairs by col id
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
@@ -293,9 +409,20 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                                       plan->c_perm, (size_t)B, 0, bits, st));
     hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, plan->r_w, plan->r_y, B,
                        plan->c_partner, plan->r_to_c, plan->c_w, plan->c_y);
-    if (int rc = build_side(pw.keys_sorted, B, plan->chunk_cap, pw, plan->c_chunk_id, plan->c_chunk_start,
-                            plan->c_uniq_slot, plan->c_uniq_rec, plan->cap_uniq, plan->counts + 2, 1, plan, st))
-        return rc;
+
+    // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
+    const SideKeys sk = {{pw.row_sorted, pw.keys_sorted}};
+    const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+                        {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts};
+    hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
+                       pw.tile_rs, pw.tile_sums);
+    hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
+                       (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
+    const UniqRecArgs ua = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+                            {plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_uniq_rec, plan->c_uniq_rec}};
+    hipLaunchKernelGGL(emit_uniq_rec, dim3(blocks_for(plan->cap_uniq, kBlock), 2), dim3(kBlock), 0, st,
+                       (const int32_t *)plan->counts, ua, plan->heavy_chunks, plan->cap_heavy, plan->heavy,
+                       plan->counts + 4);
     if (plan->r_crec) return launch_fill_records(plan, st);
     return (int)hipGetLastError();
 }

@@ -54,7 +54,11 @@ def test_plan_maps_out_of_range_ids_to_zero(hip, B):
 
 
 @pytest.mark.parametrize("B,V,cap", [(1, 5, 32), (7, 50, 32), (64, 50, 4), (1024, 300, 32), (5000, 97, 3),
-                                     (20000, 2000, 32), (100000, 12000, 16)])
+                                     (20000, 2000, 32), (100000, 12000, 16),
+                                     # the tiled builder (B > 4096, tiles of 2048 positions): exact tile multiples,
+                                     # one position past, runs that span many tiles, one id only, chunks of one pair
+                                     (4097, 300, 32), (6144, 50, 16), (8193, 3, 32), (10000, 1, 7), (30000, 40000, 1),
+                                     (65536, 7, 5), (300000, 1000, 32)])
 def test_plan_build_bit_exact(hip, B, V, cap):
     row, col, w, y = make_batch(B + V, B, V)
     drow, dcol, dw, dy = to_dev(row, col, w, y)
