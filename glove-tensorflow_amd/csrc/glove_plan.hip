@@ -143,14 +143,30 @@ __device__ inline void tile_flags(const int32_t *__restrict__ keys, int64_t B, i
     }
 }
 
-// start of the run that position `pos` lies in: first index in [0, pos] holding keys[pos] (keys sorted ascending)
+// start of the run that position `pos` lies in: first index in [0, pos] holding keys[pos] (keys sorted ascending).
+// Called by one whole wave: a 64-ary search, three dependent rounds of loads for any batch below 2^18 positions
+// (a one-thread binary search cost this kernel 17 round trips, most of its run time).
 __device__ inline int64_t run_start_of(const int32_t *__restrict__ keys, int64_t pos)
 {
+    const int lane = threadIdx.x & 63;
     const int32_t key = keys[pos];
-    int64_t lo = 0, hi = pos;
+    int64_t lo = 0, hi = pos;                              // answer in [lo, hi]; keys[hi] >= key throughout
     while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        // 64 probes spread over the undecided positions lo .. hi-1
+        const int64_t n = hi - lo, step = (n + 63) / 64;
+        int64_t q = lo + step * lane;
+        if (q > hi - 1) q = hi - 1;
+        const bool ge = keys[q] >= key;
+        const unsigned long long m = __ballot(ge);
+        if (m == 0) {                                      // every probe is below: the answer lies behind the last one
+            lo = __shfl(q, 63, 64) + 1;
+            continue;
+        }
+        const int first = __ffsll((long long)m) - 1;       // first probe at or above the key
+        const int64_t q_first = __shfl(q, first, 64);
+        const int64_t q_before = __shfl(q, first > 0 ? first - 1 : 0, 64);
+        lo = first == 0 ? lo : q_before + 1;               // first == 0: the probe at lo itself holds it
+        hi = first == 0 ? lo : q_first;
     }
     return lo;
 }
@@ -163,7 +179,10 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
     const int side = blockIdx.y, t = blockIdx.x;
     const int32_t *keys = sk.keys[side];
     const int64_t begin = (int64_t)t * kTile;
-    if (threadIdx.x == 0) lds_rs[kTileThreads / 64] = begin > 0 ? run_start_of(keys, begin) : 0;
+    if (threadIdx.x < 64) {                                // wave 0 searches together
+        const int64_t r = begin > 0 ? run_start_of(keys, begin) : 0;
+        if (threadIdx.x == 0) lds_rs[kTileThreads / 64] = r;
+    }
     __syncthreads();
     const int64_t frs = lds_rs[kTileThreads / 64];
     unsigned flag[kTilePer];
