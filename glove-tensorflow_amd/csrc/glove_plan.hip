@@ -5,13 +5,12 @@
 // of every step (reached from reference src/models/train_utils.py:13-16).  The
 // sums themselves happen in glove_step.hip; this file only orders the pairs.
 //
-// Integer work: stable LSD radix sorts (rocPRIM device primitives) + two scans per side.  The
-// result is bit-exact against oracle/glove_ref.py:build_plan.
+// Integer work: two stable sorts (rocPRIM device primitives) + two tile kernels that number the chunks and
+// ids of both sides.  The result is bit-exact against oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
 
 namespace glove {

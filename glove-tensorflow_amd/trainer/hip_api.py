@@ -27,8 +27,8 @@ HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whol
 def auto_chunk_cap(B: int, V: int) -> int:
     """Chunk length used when the caller does not choose one.  Short chunks shorten the dependent
     chain of the gather passes (fewer partner-row round trips per chunk) and win while a batch holds
-    few pairs per id; long chunks mean fewer partial rows and win for dense batches (measured with
-    tools/ab_kernels.py: B = 131072, V = 10000: 16 -> 27.1 us/step vs 32 -> 29.3; B = 1048576: 91.8 vs 68.1)."""
+    few pairs per id; long chunks mean fewer partial rows and win for dense batches (bench.py --chunk-cap,
+    V = 10000: B = 131072: 8 / 16 / 24 / 32 -> 22.4 / 21.2 / 22.3 / 23.3 us per step; B = 1048576: 16 -> 59.4, 32 -> 53.8)."""
     return 16 if B <= 20 * V else 32
 
 # every symbol include/glove_hip.h declares
