@@ -34,12 +34,12 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const int32_t *__restrict_
                                                       int64_t B, const float *__restrict__ R,
                                                       const float *__restrict__ C, const float *__restrict__ br,
                                                       const float *__restrict__ bc, const float *__restrict__ scalars,
-                                                      int d4, double *__restrict__ sums)
+                                                      int d4, double *__restrict__ sums, int head)
 {
     constexpr int GPB = kBlock / LPR;
     const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const float g = scalars[0];
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     for (int64_t i = (int64_t)blockIdx.x * GPB + grp; i < B; i += (int64_t)gridDim.x * GPB) {
         const int32_t u = row[i], v = col[i];
         f4 r[NV], c[NV];
@@ -49,14 +49,22 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const int32_t *__restrict_
 #pragma unroll
         for (int k = 0; k < NV; ++k) dp += dot4(r[k], c[k]);
         const float p = group_sum<LPR>(dp) + br[u] + bc[v] + g;
-        if (lg == 0) {
+        if (lg == 0 && head == GLOVE_HEAD_REGRESSION) {
             const double wi = w[i], yi = y[i], diff = (double)p - yi;
             a0 += wi * diff * diff; a1 += wi; a2 += wi * (double)p; a3 += wi * yi;
+        } else if (lg == 0) {
+            // w = positive weight (label 1), y = negative weight (label 0); sigmoid cross-entropy of one logit
+            const double pos = w[i], neg = y[i], x = p;
+            const double lse = log1p(exp(-fabs(x))), sg = 1.0 / (1.0 + exp(-x));
+            a0 += pos * (fmax(-x, 0.0) + lse); a1 += pos; a2 += neg * (fmax(x, 0.0) + lse); a3 += neg;
+            a4 += pos * sg; a5 += neg * sg;
         }
     }
     a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2); a3 = wave_sum_f64(a3);
+    if (head != GLOVE_HEAD_REGRESSION) { a4 = wave_sum_f64(a4); a5 = wave_sum_f64(a5); }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&sums[0], a0); atomicAdd(&sums[1], a1); atomicAdd(&sums[2], a2); atomicAdd(&sums[3], a3);
+        if (head != GLOVE_HEAD_REGRESSION) { atomicAdd(&sums[4], a4); atomicAdd(&sums[5], a5); }
     }
 }
 
@@ -188,8 +196,23 @@ using namespace glove;
 
 extern "C" {
 
+static int launch_eval(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+                       const glove_tables *t, double *sums_out, void *stream, int head);
+
 int glove_eval_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
                    const glove_tables *t, double *sums_out, void *stream)
+{
+    return launch_eval(row, col, w, y, B, t, sums_out, stream, GLOVE_HEAD_REGRESSION);
+}
+
+int glove_eval_logistic_f32(const int32_t *row, const int32_t *col, const float *pos, const float *neg, int64_t B,
+                            const glove_tables *t, double *sums_out, void *stream)
+{
+    return launch_eval(row, col, pos, neg, B, t, sums_out, stream, GLOVE_HEAD_LOGISTIC);
+}
+
+static int launch_eval(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+                       const glove_tables *t, double *sums_out, void *stream, int head)
 {
     if (!t || !sums_out || B < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars) return GLOVE_E_BADARG;
@@ -201,7 +224,7 @@ int glove_eval_f32(const int32_t *row, const int32_t *col, const float *w, const
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                           \
     hipLaunchKernelGGL((eval_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, row, col, w, y, B, t->R, t->C, \
-                       t->br, t->bc, t->scalars, d4, sums_out)
+                       t->br, t->bc, t->scalars, d4, sums_out, head)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();

@@ -174,7 +174,7 @@ template <int LPR, int NV, bool FULL, bool REC>
 __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
-    float *__restrict__ blockpart)
+    float *__restrict__ blockpart, int head, float neg_factor)
 {
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
@@ -300,12 +300,25 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
 #pragma unroll
             for (int a = 0; a < U; ++a) {
                 const float valid = (q0 + a < n) ? 1.0f : 0.f;
-                const float diff = (dp[a] + bg) - yq[a];
-                const float e = w2[a] * diff;                       // 0 on tail slots
+                float e;
+                if (head == GLOVE_HEAD_REGRESSION) {                 // uniform branch
+                    const float diff = (dp[a] + bg) - yq[a];
+                    e = w2[a] * diff;                               // 0 on tail slots
+                    ed += e * diff;
+                } else {
+                    // pos / neg logistic heads on one logit: dL/dp = (pos (s - 1) + nf neg s) / B, s = sigmoid(p);
+                    // `ed` collects 2/B times the pair's loss so that the common rescaling below applies
+                    const float p = dp[a] + bg;
+                    const float en = expf(-fabsf(p));               // in (0, 1]: no overflow either way
+                    const float s = (p >= 0.f ? 1.0f : en) / (1.0f + en);
+                    const float lse = log1pf(en);                   // softplus(x) = max(x, 0) + log1p(exp(-|x|))
+                    const float wn = 2.0f * inv_batch * neg_factor * valid * yq[a];
+                    e = 0.5f * (w2[a] * (s - 1.0f) + wn * s);
+                    ed += w2[a] * (fmaxf(-p, 0.f) + lse) + wn * (fmaxf(p, 0.f) + lse);
+                }
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
                 se += e;
-                ed += e * diff;
                 cc_sum += valid * cc[a];
                 bsq += valid * bcv[a] * bcv[a];
                 ev[a] = e;
@@ -857,6 +870,7 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
     if (t->d_model < 0 || t->d_model > t->d) return GLOVE_E_BADARG;
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
+    if (h->head != GLOVE_HEAD_REGRESSION && h->head != GLOVE_HEAD_LOGISTIC) return GLOVE_E_BADARG;
     return 0;
 }
 
@@ -986,7 +1000,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     rs.mark = mark_rows;
     cs.mark = mark_cols;
     hipStream_t st = (hipStream_t)stream;
-#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart
+#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;
 #define CALL(LPR, NV)                                                                                          \
     if (LPR * NV == d4 && rec) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \

@@ -71,6 +71,7 @@ class Estimator:
                                       params.get("keep_checkpoint_max", 5))
         self.ckpt.restore(self.model.tables)
         self._stream = None
+        self.logistic = params.get("head", "regression") == "logistic"
 
     # ---- input_fn
     def stream(self) -> NonzeroStream:
@@ -103,6 +104,8 @@ class Estimator:
         stream = self.stream()
         hyper_kwargs = dict(l2_reg=p["l2_reg"], reg_mult=p.get("reg_multiplicity", 2.0),
                             learning_rate=p["learning_rate"])
+        if self.logistic:       # logistic_matrix_factorisation.py:50-54: the stream's (w, y) are (pos, neg) weights
+            hyper_kwargs.update(head=1, neg_factor=p.get("neg_factor", 1.0))
         stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
         log_every = max(1, int(p.get("log_every", 100)))
         if self.rank == 0 and self.ckpt.latest() is None:
@@ -142,16 +145,27 @@ class Estimator:
         RegressionHead metrics: average_loss = sum w l / sum w, loss = mean over batches of the
         batch-mean weighted loss, prediction/mean, label/mean."""
         tables, stream = self.model.tables, self.stream()
-        sums = torch.zeros(4, dtype=torch.float64, device=self.device)
-        n_batches = 0
+        sums = torch.zeros(6 if self.logistic else 4, dtype=torch.float64, device=self.device)
         for row, col, w, y in stream.eval_batches():
-            self.backend.eval_sums(row, col, w, y, tables, sums)
-            n_batches += 1
+            if self.logistic:
+                self.backend.eval_sums_logistic(row, col, w, y, tables, sums)
+            else:
+                self.backend.eval_sums(row, col, w, y, tables, sums)
         if self.world > 1:
             self.dist.all_reduce(sums)
         s = sums.tolist()
-        rec = {"global_step": tables.global_step, "average_loss": s[0] / s[1],
-               "loss": s[0] / (stream.nnz * self.world) , "prediction/mean": s[2] / s[1], "label/mean": s[3] / s[1]}
+        n = stream.nnz * self.world
+        if self.logistic:
+            # BinaryClassHead metrics of the two heads ("pos": label 1, "neg": label 0) and MultiHead's merged loss
+            nf = self.params.get("neg_factor", 1.0)
+            rec = {"global_step": tables.global_step, "loss": (s[0] + nf * s[2]) / n,
+                   "average_loss/pos": s[0] / max(s[1], 1e-300), "average_loss/neg": s[2] / max(s[3], 1e-300),
+                   "prediction/mean/pos": s[4] / max(s[1], 1e-300), "prediction/mean/neg": s[5] / max(s[3], 1e-300),
+                   "label/mean/pos": 1.0, "label/mean/neg": 0.0}
+            rec["average_loss"] = rec["average_loss/pos"] + nf * rec["average_loss/neg"]
+        else:
+            rec = {"global_step": tables.global_step, "average_loss": s[0] / s[1], "loss": s[0] / n,
+                   "prediction/mean": s[2] / s[1], "label/mean": s[3] / s[1]}
         self._log(os.path.join("eval", "eval_log.jsonl"), rec)
         logger.info("eval at global_step %d: average_loss = %.6f", rec["global_step"], rec["average_loss"])
         return rec
@@ -175,10 +189,14 @@ def estimator_predict(params):
     return Estimator(params).predict()
 
 
-def main(argv=None):
+def main(argv=None, adapt_params=None):
+    """`adapt_params(params)`: hook for the sibling entry points that share this loop
+    (trainer.logistic_matrix_factorisation)."""
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(name)s: %(message)s")
     world, rank, _ = _dist_env()
     params = parse_args(argv) if rank == 0 or world == 1 else None
+    if params is not None and adapt_params is not None:
+        adapt_params(params)
     if world > 1:
         # every rank must agree on the (time-stamped) job_dir: rank 0 decides
         import torch.distributed as dist

@@ -18,7 +18,8 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 1
+GLOVE_ABI_VERSION = 2
+HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 DEFAULT_CHUNK_CAP = 32
 RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
@@ -36,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_fill_records", "glove_step_workspace_bytes",
     "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
-    "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
+    "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
 )
 
@@ -54,7 +55,8 @@ class GloveTables(C.Structure):
 class GloveHyper(C.Structure):
     _fields_ = [("beta1", C.c_double), ("beta2", C.c_double),
                 ("l2_reg", C.c_float), ("reg_mult", C.c_float), ("learning_rate", C.c_float),
-                ("epsilon", C.c_float), ("inv_batch", C.c_float), ("sides", C.c_int32)]
+                ("epsilon", C.c_float), ("inv_batch", C.c_float), ("sides", C.c_int32),
+                ("head", C.c_int32), ("neg_factor", C.c_float), ("reserved", C.c_int32)]
 
 
 class GlovePlan(C.Structure):
@@ -108,6 +110,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
+        "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
         "glove_topk_cosine_f32": (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
         "glove_cooc_workspace_bytes": (sz, [i64, i32]),
@@ -345,10 +348,11 @@ class Plan:
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
-               batch_size=None, inv_batch=None, sides=0) -> GloveHyper:
-    """`sides`: 0/3 both sides, 1 row side only, 2 col side only (see glove_hyper in the header)."""
+               batch_size=None, inv_batch=None, sides=0, head=HEAD_REGRESSION, neg_factor=1.0) -> GloveHyper:
+    """`sides`: 0/3 both sides, 1 row side only, 2 col side only; `head`: HEAD_REGRESSION (GloVe) or
+    HEAD_LOGISTIC (pos/neg logistic matrix factorisation, with `neg_factor`) — see glove_hyper in the header."""
     h = GloveHyper()
-    h.sides = sides
+    h.sides, h.head, h.neg_factor = sides, head, neg_factor
     h.beta1, h.beta2 = beta1, beta2
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
     h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
@@ -482,6 +486,15 @@ class GloveHip:
             sums = torch.zeros(4, dtype=torch.float64, device=tables.device)
         _check(self.lib.glove_eval_f32(_ptr(row), _ptr(col), _ptr(w), _ptr(y), int(row.numel()),
                                        C.byref(tables.struct()), _ptr(sums), _stream()), "glove_eval_f32")
+        return sums
+
+    def eval_sums_logistic(self, row, col, pos, neg, tables, sums=None) -> torch.Tensor:
+        _require_cuda(row, col, pos, neg)
+        if sums is None:
+            sums = torch.zeros(6, dtype=torch.float64, device=tables.device)
+        _check(self.lib.glove_eval_logistic_f32(_ptr(row), _ptr(col), _ptr(pos), _ptr(neg), int(row.numel()),
+                                                C.byref(tables.struct()), _ptr(sums), _stream()),
+               "glove_eval_logistic_f32")
         return sums
 
     def topk_cosine(self, R: torch.Tensor, query_ids: torch.Tensor, k: int):

@@ -73,6 +73,10 @@ class HipBackend:
     def eval_sums(self, row, col, w, y, tables, sums):
         return self.hip.eval_sums(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), tables, sums)
 
+    def eval_sums_logistic(self, row, col, pos, neg, tables, sums):
+        return self.hip.eval_sums_logistic(row.contiguous(), col.contiguous(), pos.contiguous(), neg.contiguous(),
+                                           tables, sums)
+
     def topk_cosine(self, R, query_ids, k):
         return self.hip.topk_cosine(R, query_ids, k)
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 1
+#define GLOVE_ABI_VERSION 2
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -67,7 +67,21 @@ typedef struct glove_hyper {
      * 0 or 3 = both, 1 = row side (R, br) only, 2 = col side (C, bc) only.  The once-per-step scalar work
      * (global bias, loss, clearing the tail) goes with the col side. */
     int32_t sides;
+    /* loss head (the model, its regulariser and both optimizers are shared):
+     *   GLOVE_HEAD_REGRESSION  RegressionHead(weight_column) of the GloVe estimator (estimator.py:48-56):
+     *                          plan.w = glove_weight, plan.y = glove_value, loss_i = w (p - y)^2
+     *   GLOVE_HEAD_LOGISTIC    MultiHead([BinaryClassHead(pos), BinaryClassHead(neg)], [1, neg_factor]) of
+     *                          logistic_matrix_factorisation.py:50-54: plan.w = positive weight (`value`),
+     *                          plan.y = negative weight (`neg_weight`), both heads see the same logit,
+     *                          loss_i = w softplus(-p) + neg_factor y softplus(p)
+     * both summed over the batch and divided by the batch size. */
+    int32_t head;
+    float neg_factor;           /* --neg-factor; read by the logistic head only */
+    int32_t reserved;
 } glove_hyper;
+
+#define GLOVE_HEAD_REGRESSION 0
+#define GLOVE_HEAD_LOGISTIC 1
 
 /*
  * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,
@@ -203,6 +217,11 @@ int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_
  * Accumulates into sums_out (device double[4]): sum w (p-y)^2, sum w, sum w p, sum w y. */
 int glove_eval_f32(const int32_t *row, const int32_t *col, const float *w, const float *y,
                    int64_t B, const glove_tables *t, double *sums_out, void *stream);
+/* The same pass for GLOVE_HEAD_LOGISTIC (BinaryClassHead metrics of the two heads,
+ * logistic_matrix_factorisation.py:50-54).  sums_out is device double[6]: sum pos xent(p, 1), sum pos,
+ * sum neg xent(p, 0), sum neg, sum pos sigmoid(p), sum neg sigmoid(p). */
+int glove_eval_logistic_f32(const int32_t *row, const int32_t *col, const float *pos, const float *neg,
+                            int64_t B, const glove_tables *t, double *sums_out, void *stream);
 
 /* ---- PREDICT mode: cosine_similarity + tf.math.top_k (model_utils.py:81-110, utils.py:12-19) --
  * For n query ids: sims/idx [n,k] sorted descending over all V ROW embeddings.

@@ -57,6 +57,11 @@ class Hyper:
     epsilon: float = KERAS_EPSILON
     beta1: float = ADAM_BETA1
     beta2: float = ADAM_BETA2
+    # loss head: 0 = RegressionHead(weight_column) of the GloVe estimator (estimator.py:48-56);
+    # 1 = MultiHead([BinaryClassHead(pos), BinaryClassHead(neg)], [1, neg_factor]) of
+    # logistic_matrix_factorisation.py:50-54 (then w = positive weight, y = negative weight)
+    head: int = 0
+    neg_factor: float = 1.0
 
 
 class Tables:
@@ -105,8 +110,34 @@ def forward(t: Tables, row, col):
     return (r * c).sum(-1) + t.br[row] + t.bc[col] + t.g
 
 
+def _softplus(x):
+    """log(1 + e^x) without overflow: the form of tf.nn.sigmoid_cross_entropy_with_logits."""
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def head_loss_and_error(p, w, y, hp: Hyper, ib):
+    """Per-pair loss of the head (already divided by the batch size) and e_i = d(sum of them)/d p_i.
+
+    head 0 (estimator.py:48-51, SUM_OVER_BATCH_SIZE):  l_i = w_i (p_i - y_i)^2 / B
+    head 1 (logistic_matrix_factorisation.py:48-54): both BinaryClassHeads see the same logit p, labels 1 (pos)
+        and 0 (neg), weights w = features[pos_name], y = features[neg_name]; sigmoid cross-entropy
+        SUM_OVER_BATCH_SIZE per head, MultiHead sums the heads with weights [1, neg_factor]:
+        l_i = (w_i softplus(-p_i) + neg_factor y_i softplus(p_i)) / B
+    """
+    dt = p.dtype.type
+    w, y = w.astype(dt), y.astype(dt)
+    if hp.head == 0:
+        diff = p - y
+        return w * diff * diff * ib, dt(2.0) * w * diff * ib
+    if hp.head != 1:
+        raise ValueError("unknown head %r" % (hp.head,))
+    nf = dt(hp.neg_factor)
+    s = dt(1.0) / (dt(1.0) + np.exp(-p))
+    return (w * _softplus(-p) + nf * y * _softplus(p)) * ib, (w * (s - dt(1.0)) + nf * y * s) * ib
+
+
 def loss_terms(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
-    """(weighted_mse L, Reg) with the reference's reductions.
+    """(head loss L, Reg, per-pair e) with the reference's reductions.
 
     L   = sum_i w_i (p_i - y_i)^2 / B                     (estimator.py:48-51, SUM_OVER_BATCH_SIZE)
     Reg = l2/(d B) sum_i(|r_i|^2+|c_i|^2) + l2/B sum_i(br_i^2+bc_i^2) + l2 g^2
@@ -118,12 +149,12 @@ def loss_terms(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
     ib = dt(1.0 / B) if inv_batch is None else dt(inv_batch)
     r, c = t.R[row], t.C[col]
     p = (r * c).sum(-1) + t.br[row] + t.bc[col] + t.g
-    diff = p - y.astype(dt)
-    L = (w.astype(dt) * diff * diff).sum() * ib
+    per_pair, e = head_loss_and_error(p, w, y, hp, ib)
+    L = per_pair.sum()
     lam = dt(hp.l2_reg)
     reg = lam / dt(t.d) * ib * ((r * r).sum() + (c * c).sum()) \
         + lam * ib * ((t.br[row] ** 2).sum() + (t.bc[col] ** 2).sum())
-    return L, reg, diff
+    return L, reg, e
 
 
 def gradients(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
@@ -138,8 +169,7 @@ def gradients(t: Tables, row, col, w, y, hp: Hyper, inv_batch=None):
     B = len(row)
     ib = dt(1.0 / B) if inv_batch is None else dt(inv_batch)
     lam, m, d = dt(hp.l2_reg), dt(hp.reg_mult), dt(t.d)
-    L, reg, diff = loss_terms(t, row, col, w, y, hp, inv_batch)
-    e = dt(2.0) * w.astype(dt) * diff * ib
+    L, reg, e = loss_terms(t, row, col, w, y, hp, inv_batch)
     kappa = dt(2.0) * m * lam / d * ib
     kappa_b = dt(2.0) * m * lam * ib
     r, c = t.R[row], t.C[col]

@@ -19,7 +19,7 @@ PARAM_RTOL, PARAM_ATOL = 1e-5, 1e-6
 def _hyper(hp: ref.Hyper, B):
     from trainer.hip_api import make_hyper
     return make_hyper(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=hp.learning_rate, epsilon=hp.epsilon,
-                      beta1=hp.beta1, beta2=hp.beta2, batch_size=B)
+                      beta1=hp.beta1, beta2=hp.beta2, batch_size=B, head=hp.head, neg_factor=hp.neg_factor)
 
 
 @pytest.mark.parametrize("B", [300, 9000])        # one-workgroup builder / rocPRIM builder
@@ -289,6 +289,43 @@ def test_adam_fused_step_equals_the_dense_form_bitwise(hip, B, V, d, cap):
     loss, L, reg = ref.train_step(t, row, col, w, y, hp)
     np.testing.assert_allclose(la.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
     assert_tables_close(a, t, PARAM_RTOL, PARAM_ATOL)
+
+
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (3000, 40, 16, 2), (512, 2000, 50, 16), (2048, 64, 300, 8)])
+def test_logistic_head_single_step(hip, optimizer, B, V, d, cap):
+    """The pos / neg logistic heads of logistic_matrix_factorisation.py:48-54 as an epilogue of the same kernels:
+    w = positive weight, y = negative weight (non-negative), logits from large negative to large positive."""
+    from trainer.hip_api import DeviceTables
+    row, col, pos, neg = make_batch(B + 7 * d, B, V)
+    neg = (np.abs(neg) * 0.5).astype(np.float32)
+    hp = ref.Hyper(learning_rate=0.05 if optimizer == "Adagrad" else 0.001, head=1, neg_factor=0.8)
+    t = oracle_tables(V, d, optimizer)
+    t.R *= 30.0                                     # spread the logits: both softplus branches, saturated sigmoids
+    t.g = t.dtype(0.3)
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(row, col, pos, neg), V, chunk_cap=cap)
+    loss_out = torch.zeros(4, device="cuda:0")
+    if optimizer == "Adagrad":
+        # the e_i of the head, then the step; the dense (data-parallel) form must agree bit for bit
+        ws = hip.step_workspace(plan, dt.d)
+        hip.rowpass(plan, dt, _hyper(hp, B), ws)
+        e_dev = ws[:4 * B].view(torch.float32).cpu().numpy().copy()
+        dt.step.fill_(t.step)
+        gr = ref.gradients(t, row, col, pos, neg, hp)
+        np.testing.assert_allclose(e_dev, gr["e"][ref.build_plan(row, col, cap)["perm_r"]], rtol=1e-5, atol=1e-7)
+        twin = tables_from_oracle(t, DeviceTables)
+        G = hip.dense_grad_buffer(twin)
+        hip.passes(plan, twin, _hyper(hp, B))
+        hip.dense_grad(plan, twin, _hyper(hp, B), G)
+        hip.dense_adagrad(twin, _hyper(hp, B), G)
+        hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+        assert torch.equal(dt.R, twin.R) and torch.equal(dt.bc, twin.bc) and torch.equal(dt.scalars, twin.scalars)
+    else:
+        hip.step_adam(plan, dt, _hyper(hp, B), hip.dense_grad_buffer(dt), loss_out)
+    loss, L, reg = ref.train_step(t, row, col, pos, neg, hp)
+    np.testing.assert_allclose(loss_out.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
+    assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
 
 
 def test_step_is_bitwise_repeatable(hip):

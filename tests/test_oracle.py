@@ -12,11 +12,28 @@ def _total_loss(t, row, col, w, y, hp):
     return L + hp.reg_mult * (reg + hp.l2_reg * t.g * t.g)
 
 
-@pytest.mark.parametrize("m", [1.0, 2.0])
-def test_gradients_match_finite_differences(m):
+def test_logistic_head_is_the_weighted_sigmoid_cross_entropy_of_both_labels():
+    """logistic_matrix_factorisation.py:48-54 with the TF definition z = label, x = logit:
+    max(x, 0) - x z + log(1 + exp(-|x|)), weighted by pos (z = 1) and neg_factor * neg (z = 0), divided by B."""
+    p = np.array([-30.0, -2.0, 0.0, 0.7, 25.0])
+    pos, neg = np.array([1.0, 0.5, 2.0, 0.0, 3.0]), np.array([0.2, 4.0, 1.0, 2.0, 0.0])
+    hp = ref.Hyper(head=1, neg_factor=1.7)
+    xent = lambda x, z: np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))
+    want = (pos * xent(p, 1.0) + 1.7 * neg * xent(p, 0.0)) / len(p)
+    got, e = ref.head_loss_and_error(p, pos, neg, hp, 1.0 / len(p))
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    eps = 1e-6
+    num = (ref.head_loss_and_error(p + eps, pos, neg, hp, 0.2)[0] - ref.head_loss_and_error(p - eps, pos, neg, hp, 0.2)[0]) / (2 * eps)
+    np.testing.assert_allclose(e, num, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("m,head", [(1.0, 0), (2.0, 0), (2.0, 1)])
+def test_gradients_match_finite_differences(m, head):
     B, V, d = 40, 9, 8
     row, col, w, y = make_batch(0, B, V)
-    hp = ref.Hyper(reg_mult=m, l2_reg=0.3)
+    if head == 1:
+        y = np.abs(y) * 0.3                      # negative weights are weights: non-negative
+    hp = ref.Hyper(reg_mult=m, l2_reg=0.3, head=head, neg_factor=0.6)
     t = ref.Tables(V, d, "Adagrad", dtype=np.float64, seed=2)
     t.g = np.float64(0.2)
     gr = ref.gradients(t, row, col, w, y, hp)
