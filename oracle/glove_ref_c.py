@@ -63,6 +63,8 @@ class CPort:
         self.out = np.zeros(3, np.float32)
 
     def step(self, row, col, w, y, hp, inv_batch=None):
+        if getattr(hp, "head", 0) != 0:
+            raise NotImplementedError("the scalar C port restates the GloVe (regression) head only")
         B = len(row)
         h = HyperC(hp.l2_reg, hp.reg_mult, hp.learning_rate, hp.epsilon, hp.beta1, hp.beta2,
                    (1.0 / B) if inv_batch is None else inv_batch)
