@@ -1,110 +1,112 @@
-"""Command line -> params dict -> job_dir initialisation.
+"""Command line -> `params` dict -> job directory.
 
-Mirrors reference src/models/config_utils.py:20-186: the same 19 flags with the same defaults,
-the `-%Y%m%d-%H%M%S` job_dir suffix, the vocab.txt copy into job_dir, the derived
-`input_fn_args` / `dataset_args` / `serving_input_fn_args` dicts and `params.json`.
-Flags after the "MI355X path" comment are additions of this build (all optional).
+Interface kept from the reference (src/models/config_utils.py:20-186): the 19 flag names and their defaults,
+the `-YYYYmmdd-HHMMSS` suffix on --job-dir unless --disable-datetime-path, the copy of vocab.txt into the job
+directory, and `params.json` with the derived `input_fn_args` / `dataset_args` / `serving_input_fn_args` blocks
+that `trainer.export_embeddings` and a resumed run read back.  The flags are declared once in `FLAGS`; the last
+group exists only in this build.
 """
+from __future__ import annotations
+
+import argparse
 import json
 import logging
-import os
 import shutil
 import sys
-from argparse import ArgumentParser
-from datetime import datetime
+import time
+from pathlib import Path
+from typing import NamedTuple
 
-from trainer.config import (
-    BATCH_SIZE, COL_NAME, EMBEDDING_SIZE, JOB_DIR, L2_REG, LEARNING_RATE, NEG_FACTOR, NEG_NAME, OPTIMIZER, POS_NAME,
-    ROW_NAME, STEPS_PER_EPOCH, TARGET_NAME, TOP_K, TRAIN_CSV, TRAIN_STEPS, VOCAB_TXT, WEIGHT_NAME,
-)
+from trainer import config
 
 logger = logging.getLogger(__name__)
 
 
-def get_function_args(params):
-    row_name, col_name = params["row_name"], params["col_name"]
-    target_name, weight_name = params["target_name"], params["weight_name"]
-    input_fn_args = {
-        "file_pattern": params["train_csv"],
-        "batch_size": params["batch_size"],
-        "select_columns": [row_name, col_name, weight_name, target_name],
-        "target_names": [target_name],
-    }
-    dataset_args = {
-        "row_col_names": [row_name, col_name],
-        "vocab_txt": params["vocab_txt"],
-        **input_fn_args,
-        "weight_names": [weight_name],
-    }
-    serving_input_fn_args = {"string_features": [row_name, col_name]}
-    return {"input_fn_args": input_fn_args, "dataset_args": dataset_args,
-            "serving_input_fn_args": serving_input_fn_args}
+class Flag(NamedTuple):
+    name: str                 # "--train-csv" without the dashes
+    kind: type | None         # None: boolean switch
+    default: object
+    text: str
 
 
-def save_params(params, params_json="params.json"):
-    with open(os.path.join(params["job_dir"], params_json), "w") as f:
-        json.dump(params, f, indent=2)
+FLAGS = (
+    # ---- inputs
+    Flag("train-csv", str, config.TRAIN_CSV, "interaction CSV (co-occurrence nonzeros) to train and evaluate on"),
+    Flag("vocab-txt", str, config.VOCAB_TXT, "vocabulary, one token per line; the line number is the id"),
+    Flag("row-name", str, config.ROW_NAME, "CSV column holding the row token"),
+    Flag("col-name", str, config.COL_NAME, "CSV column holding the column token"),
+    Flag("target-name", str, config.TARGET_NAME, "CSV column regressed on (GloVe: log co-occurrence)"),
+    Flag("weight-name", str, config.WEIGHT_NAME, "CSV column weighting the squared error"),
+    Flag("pos-name", str, config.POS_NAME, "CSV column weighting the positive label (logistic heads)"),
+    Flag("neg-name", str, config.NEG_NAME, "CSV column weighting the negative label (logistic heads)"),
+    # ---- outputs
+    Flag("job-dir", str, config.JOB_DIR, "where params.json, vocab.txt, checkpoints and logs go"),
+    Flag("disable-datetime-path", None, False, "use --job-dir as given instead of appending -YYYYmmdd-HHMMSS"),
+    # ---- model / optimisation
+    Flag("embedding-size", int, config.EMBEDDING_SIZE, "columns of the row and column embedding tables"),
+    Flag("l2-reg", float, config.L2_REG, "activity-L2 coefficient"),
+    Flag("neg-factor", float, config.NEG_FACTOR, "weight of the negative head's loss (logistic heads)"),
+    Flag("optimizer", str, config.OPTIMIZER, "Keras optimizer name: Adagrad or Adam"),
+    Flag("learning-rate", float, config.LEARNING_RATE, "optimizer step size"),
+    Flag("batch-size", int, config.BATCH_SIZE, "nonzeros per step and rank"),
+    Flag("train-steps", int, config.TRAIN_STEPS, "absolute global_step to stop at"),
+    Flag("steps-per-epoch", int, config.STEPS_PER_EPOCH, "accepted for compatibility; checkpoints are timed"),
+    Flag("top-k", int, config.TOP_K, "neighbours returned per query token in PREDICT mode"),
+    # ---- this build only
+    Flag("reg-multiplicity", float, 2.0, "how often the regulariser list enters the loss: 2 under the pinned "
+                                         "Keras 2.11 (`get_losses_for` returns all losses twice), 1 under TF 2.1"),
+    Flag("seed", int, None, "seed of the parameter init and the stream permutation (the reference is unseeded)"),
+    Flag("chunk-cap", int, 0, "nonzeros per dedup-index chunk; 0 picks it from batch and vocabulary size"),
+    Flag("log-every", int, 100, "steps between two lines of train_log.jsonl"),
+    Flag("save-checkpoints-secs", float, 300.0, "seconds between checkpoints (each followed by an eval pass)"),
+    Flag("keep-checkpoint-max", int, 5, "checkpoints kept in the job directory"),
+    Flag("skip-eval", None, False, "checkpoint without the eval pass"),
+)
 
 
-def init_params(params, write=True):
-    # job_dir
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for flag in FLAGS:
+        if flag.kind is None:
+            parser.add_argument("--" + flag.name, action="store_true", help=flag.text)
+        else:
+            parser.add_argument("--" + flag.name, type=flag.kind, default=flag.default, help=flag.text)
+    return parser
+
+
+def derived_blocks(params: dict) -> dict:
+    """The three argument blocks the reference stores in params.json (config_utils.py:25-45): which CSV columns
+    the input pipeline selects, what the dataset needs on top, and the string features of the serving signature."""
+    tokens = [params["row_name"], params["col_name"]]
+    reader = {"file_pattern": params["train_csv"], "batch_size": params["batch_size"],
+              "select_columns": tokens + [params["weight_name"], params["target_name"]],
+              "target_names": [params["target_name"]]}
+    dataset = dict(row_col_names=tokens, vocab_txt=params["vocab_txt"], **reader, weight_names=[params["weight_name"]])
+    return {"input_fn_args": reader, "dataset_args": dataset, "serving_input_fn_args": {"string_features": tokens}}
+
+
+def save_params(params: dict, name: str = "params.json") -> None:
+    Path(params["job_dir"], name).write_text(json.dumps(params, indent=2))
+
+
+def init_params(params: dict, write: bool = True) -> dict:
+    """Stamps the job directory, puts the vocabulary next to the checkpoints and records everything."""
     if not params["disable_datetime_path"]:
-        params["job_dir"] = "{job_dir}-{datetime:%Y%m%d-%H%M%S}".format(job_dir=params["job_dir"],
-                                                                      datetime=datetime.now())
+        params["job_dir"] = params["job_dir"] + time.strftime("-%Y%m%d-%H%M%S")
+    job_dir, vocab = Path(params["job_dir"]), Path(params["vocab_txt"])
+    inside = job_dir / vocab.name
     if write:
-        os.makedirs(params["job_dir"], exist_ok=True)
-    # vocab_txt
-    output_vocab_txt = os.path.join(params["job_dir"], os.path.basename(params["vocab_txt"]))
-    if write and os.path.abspath(params["vocab_txt"]) != os.path.abspath(output_vocab_txt):
-        shutil.copyfile(params["vocab_txt"], output_vocab_txt)
-    params["vocab_txt"] = output_vocab_txt
-    params.update(get_function_args(params))
+        job_dir.mkdir(parents=True, exist_ok=True)
+        if vocab.resolve() != inside.resolve():
+            shutil.copyfile(vocab, inside)
+    params["vocab_txt"] = str(inside)            # resumed runs and the exporter read the copy
+    params.update(derived_blocks(params))
     if write:
         save_params(params)
     return params
 
 
-def build_parser():
-    parser = ArgumentParser()
-    d = " (default: %(default)s)"
-    parser.add_argument("--train-csv", default=TRAIN_CSV, help="path to the training csv data" + d)
-    parser.add_argument("--vocab-txt", default=VOCAB_TXT, help="path to the vocab txt" + d)
-    parser.add_argument("--row-name", default=ROW_NAME, help="row id name" + d)
-    parser.add_argument("--col-name", default=COL_NAME, help="column id name" + d)
-    parser.add_argument("--target-name", default=TARGET_NAME, help="target name" + d)
-    parser.add_argument("--weight-name", default=WEIGHT_NAME, help="weight name" + d)
-    parser.add_argument("--pos-name", default=POS_NAME, help="positive name" + d)
-    parser.add_argument("--neg-name", default=NEG_NAME, help="negative name" + d)
-    parser.add_argument("--job-dir", default=JOB_DIR, help="job directory" + d)
-    parser.add_argument("--disable-datetime-path", action="store_true",
-                        help="flag whether to disable appending datetime in job_dir path" + d)
-    parser.add_argument("--embedding-size", type=int, default=EMBEDDING_SIZE, help="embedding size" + d)
-    parser.add_argument("--l2-reg", type=float, default=L2_REG, help="scale of l2 regularisation" + d)
-    parser.add_argument("--neg-factor", type=float, default=NEG_FACTOR, help="negative loss factor" + d)
-    parser.add_argument("--optimizer", default=OPTIMIZER, help="name of optimzer" + d)
-    parser.add_argument("--learning-rate", type=float, default=LEARNING_RATE, help="learning rate" + d)
-    parser.add_argument("--batch-size", type=int, default=BATCH_SIZE, help="batch size" + d)
-    parser.add_argument("--train-steps", type=int, default=TRAIN_STEPS, help="number of training steps" + d)
-    parser.add_argument("--steps-per-epoch", type=int, default=STEPS_PER_EPOCH,
-                        help="number of steps per checkpoint" + d)
-    parser.add_argument("--top-k", type=int, default=TOP_K, help="number of similar items" + d)
-    # ---- MI355X path (not in the reference)
-    parser.add_argument("--reg-multiplicity", type=float, default=2.0,
-                        help="times the activity-L2 list enters the loss: 2 = keras>=2.4 `get_losses_for` "
-                             "behaviour of the pinned TF 2.11, 1 = TF 2.1" + d)
-    parser.add_argument("--seed", type=int, default=None, help="seed of the init and of the batch shuffle "
-                        "(the reference is unseeded)" + d)
-    parser.add_argument("--chunk-cap", type=int, default=0, help="max nonzeros per dedup-index chunk, 0 = choose from batch size / vocab size" + d)
-    parser.add_argument("--log-every", type=int, default=100, help="steps between loss log lines" + d)
-    parser.add_argument("--save-checkpoints-secs", type=float, default=300.0, help="checkpoint cadence" + d)
-    parser.add_argument("--keep-checkpoint-max", type=int, default=5, help="checkpoints kept" + d)
-    parser.add_argument("--skip-eval", action="store_true", help="do not run the eval pass at checkpoints" + d)
-    return parser
-
-
-def parse_args(argv=None):
-    parser = build_parser()
-    args = parser.parse_args(argv)
-    logger.info("call: %s.", " ".join(sys.argv))
-    logger.info("ArgumentParser: %s.", args.__dict__)
-    return init_params(dict(args.__dict__))
+def parse_args(argv=None) -> dict:
+    namespace = build_parser().parse_args(argv)
+    logger.info("command line: %s", " ".join(sys.argv if argv is None else argv))
+    return init_params(vars(namespace).copy())

@@ -1,46 +1,49 @@
-"""`python -m trainer.export_embeddings --job-dir J` (reference src/models/export_embeddings.py):
-load J/params.json, restore the latest checkpoint, run PREDICT over the vocabulary and write
-{token: {"item_id", "item_embedding"}} skipping "<UNK>" (export_embeddings.py:13-26,39)."""
+"""`python -m trainer.export_embeddings --job-dir J [--embeddings-json F]`
+
+Reads J/params.json, restores the newest checkpoint and writes the row embeddings as JSON
+`{token: {"item_id": token, "item_embedding": [...]}}`, leaving out "<UNK>" — the file the reference's exporter
+produces from its PREDICT pass (reference src/models/export_embeddings.py:13-39).
+"""
+from __future__ import annotations
+
+import argparse
 import json
 import logging
-import os
-from argparse import ArgumentParser
+from pathlib import Path
 
-from trainer.config import EMBEDDINGS_JSON, JOB_DIR
+from trainer import config
 
 logger = logging.getLogger(__name__)
+SKIPPED_TOKEN = "<UNK>"
 
 
-def format_predictions(predictions):
-    embeddings = {}
-    for instance in predictions:
-        item_id = instance["input_string"]
-        if isinstance(item_id, bytes):
-            item_id = item_id.decode()
-        if item_id != "<UNK>":
-            embeddings[item_id] = {"item_id": item_id, "item_embedding": instance["input_embedding"].tolist()}
-    logger.info("embedding dict size: %s.", len(embeddings))
-    return embeddings
+def format_predictions(predictions) -> dict:
+    """PREDICT-mode records (`input_string`, `input_embedding`, ...) -> the exported mapping."""
+    table = {}
+    for record in predictions:
+        token = record["input_string"]
+        token = token.decode() if isinstance(token, bytes) else token
+        if token == SKIPPED_TOKEN:
+            continue
+        table[token] = {"item_id": token, "item_embedding": [float(x) for x in record["input_embedding"]]}
+    logger.info("%d embeddings exported", len(table))
+    return table
 
 
-def main(job_dir=JOB_DIR, embeddings_json=EMBEDDINGS_JSON, **kwargs):
+def main(job_dir=config.JOB_DIR, embeddings_json=config.EMBEDDINGS_JSON, **_):
     from trainer.estimator import estimator_predict
-    with open(os.path.join(job_dir, "params.json")) as f:
-        params = json.load(f)
-    embeddings = format_predictions(estimator_predict(params))
-    os.makedirs(os.path.dirname(os.path.abspath(embeddings_json)), exist_ok=True)
-    with open(embeddings_json, "w") as f:
-        json.dump(embeddings, f)
+    params = json.loads(Path(job_dir, "params.json").read_text())
+    target = Path(embeddings_json)
+    target.parent.mkdir(parents=True, exist_ok=True)
+    target.write_text(json.dumps(format_predictions(estimator_predict(params))))
 
 
 if __name__ == "__main__":
     logging.basicConfig(level=logging.INFO)
-    parser = ArgumentParser()
-    parser.add_argument("--job-dir", default=JOB_DIR, help="job directory (default: %(default)s)")
-    parser.add_argument("--embeddings-json", default=EMBEDDINGS_JSON,
-                        help="path to the embeddings json (default: %(default)s)")
-    args = parser.parse_args()
+    cli = argparse.ArgumentParser(description=__doc__.splitlines()[0], formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    cli.add_argument("--job-dir", default=config.JOB_DIR, help="job directory of a finished or running training")
+    cli.add_argument("--embeddings-json", default=config.EMBEDDINGS_JSON, help="file to write")
     try:
-        main(**args.__dict__)
+        main(**vars(cli.parse_args()))
     except KeyboardInterrupt:
         pass

@@ -17,10 +17,25 @@ def test_defaults_match_reference_app_ini():
     assert (config.EMBEDDING_SIZE, config.L2_REG, config.OPTIMIZER, config.LEARNING_RATE, config.BATCH_SIZE,
             config.TOP_K) == (64, 0.01, "Adam", 0.001, 1024, 20)
     assert config.TRAIN_STEPS == 1024                      # [dev] override (app.ini:49-50)
-    assert config.read_config(environment="prod").getint("TRAIN_STEPS") == 65536
+    assert config.load_settings(environment="prod")["TRAIN_STEPS"] == 65536
     assert (config.ROW_NAME, config.COL_NAME, config.TARGET_NAME, config.WEIGHT_NAME) == (
         "row_token", "col_token", "glove_value", "glove_weight")
     assert config.TRAIN_CSV == "data/interaction.csv" and config.JOB_DIR == "checkpoints/estimator"
+
+
+def test_a_users_app_ini_overrides_the_built_in_defaults(tmp_path):
+    """The reference's configuration file (configs/app.ini, sections picked by $ENVIRONMENT) still works."""
+    from trainer import config
+    ini = tmp_path / "app.ini"
+    ini.write_text("[DEFAULT]\nCHECKPOINTS_DIR = ckpt\nMODEL_NAME = mf\nJOB_DIR = %(CHECKPOINTS_DIR)s/%(MODEL_NAME)s-x\n"
+                   "BATCH_SIZE = 4096\nDATA_DIR = corpus\n[dev]\nTRAIN_STEPS = 77\n[prod]\nOPTIMIZER = Adagrad\n")
+    dev = config.load_settings("dev", ini)
+    assert (dev["BATCH_SIZE"], dev["TRAIN_STEPS"], dev["JOB_DIR"], dev["OPTIMIZER"]) == (4096, 77, "ckpt/mf-x", "Adam")
+    assert dev["TRAIN_CSV"] == "corpus/interaction.csv" and dev["EMBEDDINGS_JSON"] == "ckpt/embeddings.json"
+    prod = config.load_settings("prod", ini)
+    assert prod["OPTIMIZER"] == "Adagrad" and prod["TRAIN_STEPS"] == 65536
+    with pytest.raises(KeyError):
+        config.load_settings("staging", ini)
 
 
 def test_cli_flags_are_the_reference_flags():
