@@ -223,3 +223,20 @@ def test_logistic_matrix_factorisation_cli(hip, tmp_path):
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()][-1]
     assert ev["global_step"] == 80 and 0.0 < ev["prediction/mean/neg"] < 1.0 and ev["average_loss/pos"] > 0
     np.testing.assert_allclose(ev["average_loss"], ev["average_loss/pos"] + 0.5 * ev["average_loss/neg"], rtol=1e-12)
+
+
+def test_non_finite_loss_stops_training(hip, tmp_path):
+    """The Estimator's NanTensorHook: a non-finite loss ends the run with an error instead of training on
+    (reference: tf.estimator's default hooks under train_and_evaluate, estimator.py:95)."""
+    import pandas as pd
+    from trainer import estimator
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    df = pd.read_csv(csv, keep_default_na=False, na_filter=False)
+    df.loc[5, "glove_value"] = float("inf")
+    bad = tmp_path / "interaction.csv"
+    df.to_csv(bad, index=False)
+    argv = ["--train-csv", str(bad), "--vocab-txt", str(vocab), "--job-dir", str(tmp_path / "job"),
+            "--disable-datetime-path", "--embedding-size", "8", "--optimizer", "Adagrad", "--batch-size", "64",
+            "--train-steps", "200", "--log-every", "10", "--seed", "1"]
+    with pytest.raises(FloatingPointError, match="global_step"):
+        estimator.main(argv)
