@@ -86,36 +86,69 @@ __global__ __launch_bounds__(kBlock) void inv_norm_kernel(const float *__restric
     }
 }
 
-constexpr int kQT = 4;   // queries per workgroup row in the similarity kernel
+// sims[q, v] = (R[qid[q]] . R[v]) inv_norm[qid[q]] inv_norm[v]: the one GEMM-shaped piece of the path
+// (tf.matmul of the l2-normalised query rows with all rows, utils.py:12-19), on the matrix cores in exact f32:
+// v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so the numerics are those of a scalar loop.
+// Workgroup = 128 queries x 128 vocabulary rows, four waves of 2 x 2 MFMA tiles (64 accumulator VGPRs); the
+// operands go through LDS in slabs of 32 columns (row stride 33 floats: a tile column is read conflict-free).
+// One call reads R once per 128 queries instead of once per 4.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kSimTile = 128, kSimK = 32;
 
-template <int LPR, int NV>
-__global__ __launch_bounds__(kBlock) void cosine_kernel(const float *__restrict__ R, int32_t V, int d4,
-                                                        const int32_t *__restrict__ qid, int32_t n,
-                                                        const float *__restrict__ inv_norm,
-                                                        float *__restrict__ sims /* [n,V] */)
+__global__ __launch_bounds__(kBlock) void cosine_mfma_kernel(const float *__restrict__ R, int32_t V, int32_t d,
+                                                             const int32_t *__restrict__ qid, int32_t n,
+                                                             const float *__restrict__ inv_norm,
+                                                             float *__restrict__ sims /* [n,V] */)
 {
-    constexpr int GPB = kBlock / LPR;
-    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
-    const int q0 = blockIdx.y * kQT;
-    f4 q[kQT][NV];
-    float qi[kQT];
+    __shared__ float Qs[kSimTile][kSimK + 1];
+    __shared__ float Rs[kSimTile][kSimK + 1];
+    const int v0 = blockIdx.x * kSimTile, q0 = blockIdx.y * kSimTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;               // this wave's 64 x 64 quadrant of the tile
+    const int r32 = lane & 31, kh = lane >> 5;             // operand maps: A[i = lane & 31][k = lane >> 5], B likewise
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < kQT; ++a) {
-        const int32_t id = qid[(q0 + a < n) ? q0 + a : q0];
-        load_row_p<LPR, NV>(q[a], R, id, d4, lg);
-        qi[a] = inv_norm[id];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    for (int k0 = 0; k0 < d; k0 += kSimK) {
+        // stage 128 rows x 32 columns of each operand: 8 threads x 16 B per row, zero beyond n / V / d
+        for (int i = threadIdx.x; i < kSimTile * (kSimK / 4); i += kBlock) {
+            const int row = i / (kSimK / 4), c = (i % (kSimK / 4)) * 4;
+            const bool kin = k0 + c < d;                   // d is a multiple of 4
+            f4 qv = f4{0.f, 0.f, 0.f, 0.f}, rv = qv;
+            if (kin && q0 + row < n) qv = *reinterpret_cast<const f4 *>(R + (size_t)qid[q0 + row] * d + k0 + c);
+            if (kin && v0 + row < V) rv = *reinterpret_cast<const f4 *>(R + (size_t)(v0 + row) * d + k0 + c);
+            Qs[row][c] = qv.x; Qs[row][c + 1] = qv.y; Qs[row][c + 2] = qv.z; Qs[row][c + 3] = qv.w;
+            Rs[row][c] = rv.x; Rs[row][c + 1] = rv.y; Rs[row][c + 2] = rv.z; Rs[row][c + 3] = rv.w;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kSimK; kk += 2) {
+            const float a0 = Qs[wm * 64 + r32][kk + kh], a1 = Qs[wm * 64 + 32 + r32][kk + kh];
+            const float b0 = Rs[wn * 64 + r32][kk + kh], b1 = Rs[wn * 64 + 32 + r32][kk + kh];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
     }
-    for (int v = blockIdx.x * GPB + grp; v < V; v += gridDim.x * GPB) {
-        f4 r[NV];
-        load_row_p<LPR, NV>(r, R, v, d4, lg);
-        const float iv = inv_norm[v];
+    // C/D map: column (vocabulary row) = lane & 31, row (query) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int a = 0; a < kQT; ++a) {
-            float dp = 0.f;
+    for (int b = 0; b < 2; ++b) {
+        const int v = v0 + wn * 64 + b * 32 + r32;
+        const float iv = v < V ? inv_norm[v] : 0.f;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) dp += dot4(q[a][k], r[k]);
-            dp = group_sum<LPR>(dp);
-            if (lg == 0 && q0 + a < n) sims[(size_t)(q0 + a) * V + v] = dp * qi[a] * iv;
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int q = q0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                if (q < n && v < V) sims[(size_t)q * V + v] = acc[a][b][reg] * inv_norm[qid[q]] * iv;
+            }
         }
     }
 }
@@ -123,51 +156,45 @@ __global__ __launch_bounds__(kBlock) void cosine_kernel(const float *__restrict_
 // order of tf.math.top_k: larger similarity first, ties -> lower index first
 __device__ inline bool topk_before(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
 
-// One pass over the V similarities of a query (one workgroup per query): every thread keeps the best K of
-// its strided share in registers (sorted insertion, static indices), the 256 lists meet in LDS and k rounds
-// of workgroup arg-max pick the result.  O(V) reads per query instead of k * V.
-template <int K>
-__global__ __launch_bounds__(kBlock) void topk_kernel(const float *__restrict__ sims, int32_t V, int32_t k,
-                                                      float *__restrict__ out_sim, int32_t *__restrict__ out_idx)
+// Top-k of a query's candidates by selection.  Workgroup = (query, segment of kTopkSeg candidates): every thread
+// holds kTopkPer of them in registers and the workgroup runs k rounds of arg-max "behind the previous pick" in the
+// order of tf.math.top_k — 16 compares per thread and round, one barrier per round, nothing sorted and no memory
+// traffic after the first load.  A vocabulary larger than one segment is reduced in stages: each launch turns
+// `len` candidates per query into ceil(len / kTopkSeg) * k winners (values + vocabulary ids) until one segment is
+// left.  (A per-thread sorted list of the best k, the first form of this kernel, cost ~2,300 instructions per
+// inserted element and took 9 ms per 256 queries at V = 400 k; this takes 0.1 ms.)
+constexpr int kTopkPer = 16;
+constexpr int kTopkSeg = kBlock * kTopkPer;
+
+__global__ __launch_bounds__(kBlock) void topk_select_kernel(const float *__restrict__ vals,
+                                                             const int32_t *__restrict__ ids, int64_t row_stride,
+                                                             int32_t len, int32_t k, float *__restrict__ out_val,
+                                                             int32_t *__restrict__ out_idx)
 {
-    __shared__ float c_val[kBlock * K];
-    __shared__ int c_idx[kBlock * K];
-    __shared__ float s_val[kBlock / 64];
-    __shared__ int s_idx[kBlock / 64];
-    __shared__ float prev_val;
-    __shared__ int prev_idx;
-    const float *row = sims + (size_t)blockIdx.x * V;
-    float val[K];
-    int idx[K];
+    __shared__ float s_val[2][kBlock / 64];
+    __shared__ int s_idx[2][kBlock / 64];
+    const float *row = vals + (size_t)blockIdx.x * row_stride;
+    const int32_t *row_ids = ids ? ids + (size_t)blockIdx.x * row_stride : nullptr;
+    const size_t out_row = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * k;
+    float sv[kTopkPer];
+    int id[kTopkPer];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { val[j] = -INFINITY; idx[j] = 0x7fffffff; }
-    for (int v = threadIdx.x; v < V; v += kBlock) {
-        const float s = row[v];
-        if (topk_before(s, v, val[K - 1], idx[K - 1])) {
-            val[K - 1] = s; idx[K - 1] = v;
-#pragma unroll
-            for (int j = K - 1; j > 0; --j) {
-                if (topk_before(val[j], idx[j], val[j - 1], idx[j - 1])) {
-                    const float tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
-                    const int ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti;
-                }
-            }
-        }
+    for (int e = 0; e < kTopkPer; ++e) {
+        const int p = blockIdx.y * kTopkSeg + e * kBlock + threadIdx.x;
+        const bool in = p < len;
+        const int v = in ? (row_ids ? row_ids[p] : p) : -1;
+        sv[e] = (in && v >= 0) ? row[p] : -INFINITY;       // v < 0: an empty slot of a short earlier segment
+        id[e] = v >= 0 ? v : 0x7fffffff;
     }
-#pragma unroll
-    for (int j = 0; j < K; ++j) { c_val[threadIdx.x * K + j] = val[j]; c_idx[threadIdx.x * K + j] = idx[j]; }
-    if (threadIdx.x == 0) { prev_val = INFINITY; prev_idx = -1; }
-    __syncthreads();
+    float pv = INFINITY;                                    // previous pick: everything is "behind" the start
+    int pi = -1;
     for (int t = 0; t < k; ++t) {
-        const float pv = prev_val;
-        const int pi = prev_idx;
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        // each thread's list is sorted: its first entry behind the previous pick is its best remaining one
-        for (int j = 0; j < K; ++j) {
-            const float s = c_val[threadIdx.x * K + j];
-            const int v = c_idx[threadIdx.x * K + j];
-            if ((s < pv || (s == pv && v > pi)) && topk_before(s, v, best, bi)) { best = s; bi = v; }
+#pragma unroll
+        for (int e = 0; e < kTopkPer; ++e) {
+            const bool behind = sv[e] < pv || (sv[e] == pv && id[e] > pi);
+            if (behind && topk_before(sv[e], id[e], best, bi)) { best = sv[e]; bi = id[e]; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -175,18 +202,21 @@ __global__ __launch_bounds__(kBlock) void topk_kernel(const float *__restrict__ 
             const int oi = __shfl_xor(bi, m, 64);
             if (topk_before(ob, oi, best, bi)) { best = ob; bi = oi; }
         }
-        if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = bi; }
+        const int buf = t & 1;                              // double-buffered: one barrier per round
+        if ((threadIdx.x & 63) == 0) { s_val[buf][threadIdx.x >> 6] = best; s_idx[buf][threadIdx.x >> 6] = bi; }
         __syncthreads();
+        best = s_val[buf][0];
+        bi = s_idx[buf][0];
+#pragma unroll
+        for (int wv = 1; wv < kBlock / 64; ++wv)
+            if (topk_before(s_val[buf][wv], s_idx[buf][wv], best, bi)) { best = s_val[buf][wv]; bi = s_idx[buf][wv]; }
+        const bool none = bi == 0x7fffffff;                 // fewer than k candidates in this segment
         if (threadIdx.x == 0) {
-            float bv = s_val[0]; int i = s_idx[0];
-            for (int wv = 1; wv < kBlock / 64; ++wv)
-                if (topk_before(s_val[wv], s_idx[wv], bv, i)) { bv = s_val[wv]; i = s_idx[wv]; }
-            if (i == 0x7fffffff) { bv = -INFINITY; i = -1; }   // fewer than k candidates
-            out_sim[(size_t)blockIdx.x * k + t] = bv;
-            out_idx[(size_t)blockIdx.x * k + t] = i;
-            prev_val = bv; prev_idx = (i < 0) ? V : i;
+            out_val[out_row + t] = none ? -INFINITY : best;
+            out_idx[out_row + t] = none ? -1 : bi;
         }
-        __syncthreads();
+        pv = none ? -INFINITY : best;
+        pi = bi;
     }
 }
 
@@ -230,17 +260,21 @@ static int launch_eval(const int32_t *row, const int32_t *col, const float *w, c
     return (int)hipGetLastError();
 }
 
+// winners the first top-k stage leaves per query (the later stages only shrink)
+static size_t topk_stage_items(int32_t V, int32_t k) { return (size_t)((V + kTopkSeg - 1) / kTopkSeg) * (size_t)k; }
+
 size_t glove_topk_workspace_bytes(int32_t n, int32_t V, int32_t k)
 {
-    (void)k;
-    if (n < 0 || V <= 0) return 0;
-    return align_up((size_t)V * sizeof(float), 256) + align_up((size_t)n * V * sizeof(float), 256);
+    if (n < 0 || V <= 0 || k < 0) return 0;
+    const size_t cand = (size_t)n * topk_stage_items(V, k);                     // two ping-pong buffers of winners
+    return align_up((size_t)V * sizeof(float), 256) + align_up((size_t)n * V * sizeof(float), 256) +
+           2 * (align_up(cand * sizeof(float), 256) + align_up(cand * sizeof(int32_t), 256));
 }
 
 int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *query_ids, int32_t n, int32_t k,
                           float *sims_out, int32_t *idx_out, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!R || V <= 0 || d <= 0 || (d % 4) != 0 || n < 0 || n > 65535 * kQT || k <= 0 || k > V || k > 64) return GLOVE_E_BADARG;
+    if (!R || V <= 0 || d <= 0 || (d % 4) != 0 || n < 0 || n > 65535 * kSimTile || k <= 0 || k > V || k > 1024) return GLOVE_E_BADARG;
     if (n == 0) return 0;
     if (!query_ids || !sims_out || !idx_out || !ws) return GLOVE_E_BADARG;
     if (glove_topk_workspace_bytes(n, V, k) > ws_bytes) return GLOVE_E_WORKSPACE;
@@ -249,19 +283,39 @@ int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *q
     const int d4 = d / 4;
     const RowShape shape = pick_row_shape(d4);
     if (shape.lpr == 0) return GLOVE_E_BADARG;
-    const int gpb = kBlock / shape.lpr;
-    const int nbv = blocks_for(V, gpb);
-    const int nbx = nbv > 256 ? 256 : nbv;
+    const int nbv = blocks_for(V, kBlock / shape.lpr);
     hipStream_t st = (hipStream_t)stream;
-#define CALL(LPR, NV)                                                                                             \
-    hipLaunchKernelGGL((inv_norm_kernel<LPR, NV>), dim3(nbv), dim3(kBlock), 0, st, R, V, d4, inv_norm);           \
-    hipLaunchKernelGGL((cosine_kernel<LPR, NV>), dim3(nbx, (n + kQT - 1) / kQT), dim3(kBlock), 0, st, R, V, d4, \
-                       query_ids, n, inv_norm, sims)
+#define CALL(LPR, NV) hipLaunchKernelGGL((inv_norm_kernel<LPR, NV>), dim3(nbv), dim3(kBlock), 0, st, R, V, d4, inv_norm)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
-    if (k <= 8) hipLaunchKernelGGL(topk_kernel<8>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
-    else if (k <= 20) hipLaunchKernelGGL(topk_kernel<20>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
-    else hipLaunchKernelGGL(topk_kernel<64>, dim3(n), dim3(kBlock), 0, st, sims, V, k, sims_out, idx_out);
+    hipLaunchKernelGGL(cosine_mfma_kernel, dim3((V + kSimTile - 1) / kSimTile, (n + kSimTile - 1) / kSimTile), dim3(kBlock),
+                       0, st, R, V, d, query_ids, n, inv_norm, sims);
+    // reduce in stages until one segment holds a query's candidates; the last stage writes the outputs
+    const size_t cand = (size_t)n * topk_stage_items(V, k);
+    char *pp = (char *)sims + align_up((size_t)n * V * sizeof(float), 256);
+    float *cv[2];
+    int32_t *ci[2];
+    for (int b = 0; b < 2; ++b) {
+        cv[b] = (float *)pp;
+        pp += align_up(cand * sizeof(float), 256);
+        ci[b] = (int32_t *)pp;
+        pp += align_up(cand * sizeof(int32_t), 256);
+    }
+    const float *src_v = sims;
+    const int32_t *src_i = nullptr;
+    int64_t stride = V;
+    int32_t len = V;
+    for (int stage = 0;; ++stage) {
+        const int nseg = (len + kTopkSeg - 1) / kTopkSeg;
+        const bool last = nseg == 1;
+        float *dv = last ? sims_out : cv[stage & 1];
+        int32_t *di = last ? idx_out : ci[stage & 1];
+        hipLaunchKernelGGL(topk_select_kernel, dim3(n, nseg), dim3(kBlock), 0, st, src_v, src_i, stride, len, k, dv, di);
+        if (last) break;
+        src_v = dv;
+        src_i = di;
+        stride = len = nseg * k;
+    }
     return (int)hipGetLastError();
 }
 

@@ -224,7 +224,9 @@ int glove_eval_logistic_f32(const int32_t *row, const int32_t *col, const float 
                             int64_t B, const glove_tables *t, double *sums_out, void *stream);
 
 /* ---- PREDICT mode: cosine_similarity + tf.math.top_k (model_utils.py:81-110, utils.py:12-19) --
- * For n query ids: sims/idx [n,k] sorted descending over all V ROW embeddings.
+ * For n query ids: sims/idx [n,k] sorted descending (ties: lower id first) over all V ROW embeddings; d = row
+ * stride in floats (multiple of 4), 1 <= k <= min(V, 1024).  The similarity matrix is the one GEMM of the path and
+ * runs on the matrix cores in exact f32 (v_mfma_f32_32x32x2_f32); the top-k is a staged selection.
  * ws: glove_topk_workspace_bytes. */
 size_t glove_topk_workspace_bytes(int32_t n, int32_t V, int32_t k);
 int glove_topk_cosine_f32(const float *R, int32_t V, int32_t d, const int32_t *query_ids, int32_t n,

@@ -416,6 +416,20 @@ def test_topk_cosine(hip, V, d, k):
     assert got_i[0, 0] == 0 and got_i[1, 0] == 3 and got_i[2, 0] == 3   # self first; tie -> index 3 before 7
 
 
+def test_topk_cosine_many_queries_and_segments(hip):
+    """More queries than one 128-row MFMA tile, a vocabulary cut into several top-k segments, ragged edges."""
+    V, d, k, n = 40003, 52, 20, 301
+    rng = np.random.default_rng(9)
+    R = rng.normal(size=(V, d)).astype(np.float32)
+    q = rng.integers(0, V, n).astype(np.int32)
+    sims, idx = hip.topk_cosine(*to_dev(R, q), k)
+    want_s, want_i = ref.cosine_topk(R.astype(np.float64), q, k)
+    np.testing.assert_allclose(sims.cpu().numpy(), want_s, rtol=1e-5, atol=1e-6)
+    got_i = idx.cpu().numpy()
+    assert (got_i[:, 0] == q).all()                      # every token is its own nearest neighbour
+    assert (got_i == want_i).mean() > 0.999              # continuous data: ties only by rounding
+
+
 def test_argument_errors_are_reported_not_swallowed(hip):
     from trainer.hip_api import DeviceTables, GloveHipError
     with pytest.raises(ValueError):
