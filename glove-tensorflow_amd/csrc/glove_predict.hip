@@ -102,7 +102,9 @@ __global__ __launch_bounds__(kBlock) void cosine_mfma_kernel(const float *__rest
 {
     __shared__ float Qs[kSimTile][kSimK + 1];
     __shared__ float Rs[kSimTile][kSimK + 1];
+    __shared__ float q_inv[kSimTile];                      // inverse norms of this tile's queries, for the epilogue
     const int v0 = blockIdx.x * kSimTile, q0 = blockIdx.y * kSimTile;
+    if (threadIdx.x < kSimTile) q_inv[threadIdx.x] = q0 + threadIdx.x < n ? inv_norm[qid[q0 + threadIdx.x]] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;               // this wave's 64 x 64 quadrant of the tile
     const int r32 = lane & 31, kh = lane >> 5;             // operand maps: A[i = lane & 31][k = lane >> 5], B likewise
@@ -114,18 +116,32 @@ __global__ __launch_bounds__(kBlock) void cosine_mfma_kernel(const float *__rest
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    for (int k0 = 0; k0 < d; k0 += kSimK) {
-        // stage 128 rows x 32 columns of each operand: 8 threads x 16 B per row, zero beyond n / V / d
-        for (int i = threadIdx.x; i < kSimTile * (kSimK / 4); i += kBlock) {
+    // a slab = 128 rows x 32 columns of each operand: 8 threads x 16 B per row, zero beyond n / V / d.  The next
+    // slab's global loads are issued before the MFMAs of the current one and land in LDS after them.
+    constexpr int kPer = kSimTile * (kSimK / 4) / kBlock;  // float4 per thread, operand and slab
+    f4 qn[kPer], rn[kPer];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) {
+            const int i = threadIdx.x + x * kBlock;
             const int row = i / (kSimK / 4), c = (i % (kSimK / 4)) * 4;
             const bool kin = k0 + c < d;                   // d is a multiple of 4
-            f4 qv = f4{0.f, 0.f, 0.f, 0.f}, rv = qv;
-            if (kin && q0 + row < n) qv = *reinterpret_cast<const f4 *>(R + (size_t)qid[q0 + row] * d + k0 + c);
-            if (kin && v0 + row < V) rv = *reinterpret_cast<const f4 *>(R + (size_t)(v0 + row) * d + k0 + c);
-            Qs[row][c] = qv.x; Qs[row][c + 1] = qv.y; Qs[row][c + 2] = qv.z; Qs[row][c + 3] = qv.w;
-            Rs[row][c] = rv.x; Rs[row][c + 1] = rv.y; Rs[row][c + 2] = rv.z; Rs[row][c + 3] = rv.w;
+            qn[x] = rn[x] = f4{0.f, 0.f, 0.f, 0.f};
+            if (kin && q0 + row < n) qn[x] = *reinterpret_cast<const f4 *>(R + (size_t)qid[q0 + row] * d + k0 + c);
+            if (kin && v0 + row < V) rn[x] = *reinterpret_cast<const f4 *>(R + (size_t)(v0 + row) * d + k0 + c);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += kSimK) {
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) {
+            const int i = threadIdx.x + x * kBlock;
+            const int row = i / (kSimK / 4), c = (i % (kSimK / 4)) * 4;
+            Qs[row][c] = qn[x].x; Qs[row][c + 1] = qn[x].y; Qs[row][c + 2] = qn[x].z; Qs[row][c + 3] = qn[x].w;
+            Rs[row][c] = rn[x].x; Rs[row][c + 1] = rn[x].y; Rs[row][c + 2] = rn[x].z; Rs[row][c + 3] = rn[x].w;
         }
         __syncthreads();
+        if (k0 + kSimK < d) fetch(k0 + kSimK);
 #pragma unroll 4
         for (int kk = 0; kk < kSimK; kk += 2) {
             const float a0 = Qs[wm * 64 + r32][kk + kh], a1 = Qs[wm * 64 + 32 + r32][kk + kh];
@@ -146,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void cosine_mfma_kernel(const float *__rest
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int q = q0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                if (q < n && v < V) sims[(size_t)q * V + v] = acc[a][b][reg] * inv_norm[qid[q]] * iv;
+                const int ql = wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh, q = q0 + ql;
+                if (q < n && v < V) sims[(size_t)q * V + v] = acc[a][b][reg] * q_inv[ql] * iv;
             }
         }
     }
