@@ -1123,7 +1123,7 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, (float)h->beta1, (float)h->beta2,
-                       log(h->beta1), log(h->beta2), t->step, t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
+                       log((double)(float)h->beta1), log((double)(float)h->beta2), t->step, t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -1173,7 +1173,7 @@ static int step_adam_fused(const glove_plan *p, const glove_tables *t, const glo
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                          \
     hipLaunchKernelGGL((adam_fused_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
-                       t->s2_br, t->s2_bc, d4, k, (float)h->beta1, (float)h->beta2, log(h->beta1), log(h->beta2),  \
+                       t->s2_br, t->s2_bc, d4, k, (float)h->beta1, (float)h->beta2, log((double)(float)h->beta1), log((double)(float)h->beta2),  \
                        t->step, t->scalars, w.blockpart, nb_row, mark_rows, mark_cols, (int)Vr, (int)t->V,     \
                        apply_blocks, loss_out)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);

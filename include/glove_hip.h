@@ -56,8 +56,8 @@ typedef struct glove_tables {
 } glove_tables;
 
 typedef struct glove_hyper {
-    double beta1, beta2;        /* Adam 0.9 / 0.999 (double: the bias correction 1-beta2^t
-                                 * loses 1e-5 relative accuracy if beta2 is rounded to fp32) */
+    double beta1, beta2;        /* Adam 0.9 / 0.999.  Used rounded to fp32 everywhere, as Keras casts its
+                                 * hyper-parameters to the variable dtype (1 - float(0.999) is 1.3e-5 off 0.001) */
     float l2_reg;               /* --l2-reg  (activity L2, model_utils.py:8,38) */
     float reg_mult;             /* m: times the regulariser list is counted (estimator.py:55) */
     float learning_rate;        /* --learning-rate */

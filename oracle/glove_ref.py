@@ -210,7 +210,7 @@ def _adam_dense_decay(W, M, Vv, G, lr_t, b1, b2, eps):
 def apply_update(t: Tables, gr, hp: Hyper):
     """Optimizer update of the five variables from summed gradients `gr`; step += 1."""
     dt = t.dtype
-    lr, eps = dt(hp.learning_rate), dt(hp.epsilon)
+    lr, eps = dt(np.float32(hp.learning_rate)), dt(np.float32(hp.epsilon))     # cast to the variable dtype, as Keras does
     dg = gr["sum_e"] + gr["dg_reg"]
     if t.optimizer == "Adagrad":
         _adagrad(t.R, t.A_R, gr["G_R"], gr["touched_r"], lr, eps)
@@ -220,9 +220,11 @@ def apply_update(t: Tables, gr, hp: Hyper):
         t.A_g = t.A_g + dg * dg
         t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
     else:
-        b1, b2 = dt(hp.beta1), dt(hp.beta2)
+        # Keras casts the hyper-parameters to the variable dtype before use (OptimizerV2._get_hyper(name, var_dtype)):
+        # beta_2 = float32(0.999) = 0.99900001287..., so 1 - beta_2 is 1.3e-5 (relative) away from 0.001
+        b1, b2 = dt(np.float32(hp.beta1)), dt(np.float32(hp.beta2))
         tt = t.step + 1
-        lr_t = dt(hp.learning_rate * math.sqrt(1.0 - hp.beta2 ** tt) / (1.0 - hp.beta1 ** tt))
+        lr_t = dt(float(lr) * math.sqrt(1.0 - float(b2) ** tt) / (1.0 - float(b1) ** tt))
         _adam_dense_decay(t.R, t.M_R, t.V_R, gr["G_R"], lr_t, b1, b2, eps)
         _adam_dense_decay(t.C, t.M_C, t.V_C, gr["G_C"], lr_t, b1, b2, eps)
         _adam_dense_decay(t.br, t.M_br, t.V_br, gr["G_br"], lr_t, b1, b2, eps)

@@ -64,8 +64,9 @@ class OracleBackend:
     def apply_sparse(self, plan, tables, hyper):
         t, gr, hp = tables.t, self._gr, hyper["hp"]
         assert hyper["sides"] == 1 and t.optimizer == "Adagrad"
-        ref._adagrad(t.R, t.A_R, gr["G_R"], gr["touched_r"], hp.learning_rate, hp.epsilon)
-        ref._adagrad(t.br, t.A_br, gr["G_br"], gr["touched_r"], hp.learning_rate, hp.epsilon)
+        lr, eps = t.dtype(np.float32(hp.learning_rate)), t.dtype(np.float32(hp.epsilon))     # as ref.apply_update
+        ref._adagrad(t.R, t.A_R, gr["G_R"], gr["touched_r"], lr, eps)
+        ref._adagrad(t.br, t.A_br, gr["G_br"], gr["touched_r"], lr, eps)
 
     def apply_dense(self, tables, hyper, G, loss_out):
         t, hp, sides = tables.t, hyper["hp"], hyper["sides"]

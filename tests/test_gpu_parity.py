@@ -328,6 +328,51 @@ def test_logistic_head_single_step(hip, optimizer, B, V, d, cap):
     assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
 
 
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    V = int(rng.choice([1, 2, 7, 60, 333, 2000, 30000]))
+    B = int(rng.choice([1, 5, 63, 64, 65, 700, 4096, 4097, 9000]))
+    d = int(rng.choice([1, 4, 6, 8, 20, 50, 64, 100, 128, 200, 300, 520]))
+    cap = int(rng.choice([1, 2, 5, 8, 16, 31, 32]))
+    skew = float(rng.choice([0.0, 1.0, 1.6]))          # 0: uniform ids, else Zipf exponent (heavy duplicates)
+    if skew:
+        ranks = np.arange(1, V + 1, dtype=np.float64) ** -skew
+        pdf = ranks / ranks.sum()
+        row, col = rng.choice(V, B, p=pdf).astype(np.int32), rng.choice(V, B, p=pdf).astype(np.int32)
+    else:
+        row, col = rng.integers(0, V, B).astype(np.int32), rng.integers(0, V, B).astype(np.int32)
+    w = rng.uniform(0, 1, B).astype(np.float32)
+    w[rng.uniform(size=B) < 0.1] = 0.0                  # some pairs weigh nothing
+    y = rng.normal(0, 2, B).astype(np.float32)
+    return dict(V=V, B=B, d=d, cap=cap, row=row, col=col, w=w, y=y, optimizer=str(rng.choice(["Adagrad", "Adam"])),
+                head=int(rng.integers(0, 2)), nf=float(rng.uniform(0.2, 2.0)), steps=int(rng.integers(1, 4)))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_step_parity(hip, seed):
+    """Seeded random shapes through the whole step: vocabularies from 1 id up, batches around the builder and tile
+    boundaries, every kernel shape incl. padded embedding sizes, uniform and Zipf ids, zero weights, both
+    optimizers and both heads, one to three consecutive steps on the same batch."""
+    from trainer.hip_api import DeviceTables
+    c = _random_case(1000 + seed)
+    y = np.abs(c["y"]).astype(np.float32) if c["head"] else c["y"]
+    hp = ref.Hyper(learning_rate=0.05 if c["optimizer"] == "Adagrad" else 0.001, head=c["head"], neg_factor=c["nf"])
+    t = oracle_tables(c["V"], c["d"], c["optimizer"], seed=seed)
+    dt = tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(c["row"], c["col"], c["w"], y), c["V"], chunk_cap=c["cap"])
+    G = hip.dense_grad_buffer(dt) if c["optimizer"] == "Adam" else None
+    loss_out = torch.zeros(4, device="cuda:0")
+    for _ in range(c["steps"]):
+        if G is None:
+            hip.step_adagrad(plan, dt, _hyper(hp, c["B"]), loss_out)
+        else:
+            hip.step_adam(plan, dt, _hyper(hp, c["B"]), G, loss_out)
+        loss, L, reg = ref.train_step(t, c["row"], c["col"], c["w"], y, hp)
+    info = {k: c[k] for k in ("V", "B", "d", "cap", "optimizer", "head", "steps")}
+    np.testing.assert_allclose(loss_out.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL, atol=1e-7, err_msg=str(info))
+    assert_tables_close(dt, t, PARAM_RTOL * c["steps"], PARAM_ATOL * c["steps"])
+
+
 def test_step_is_bitwise_repeatable(hip):
     from trainer.hip_api import DeviceTables
     B, V, d = 20000, 500, 64
