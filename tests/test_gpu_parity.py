@@ -115,6 +115,40 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(cp.r_chunk_start.cpu().numpy()[:nc_r + 1], want["r_chunk_start"])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GLOVE_FUZZ_CASES", "40"))))
+def test_randomized_plan_is_bit_exact(hip, seed):
+    """Seeded random batches through both index builders (one workgroup / tiled): every array of the plan equals
+    the oracle's, for uniform and Zipf ids, any chunk cap, with and without ids outside the vocabulary."""
+    rng = np.random.default_rng(7000 + seed)
+    V = int(rng.choice([1, 3, 50, 1000, 20000, 300000]))
+    B = int(rng.choice([1, 2, 100, 4095, 4096, 4097, 6143, 6144, 6145, 20000, 70000]))
+    cap = int(rng.integers(1, 33))
+    if rng.uniform() < 0.5:
+        pdf = np.arange(1, V + 1, dtype=np.float64) ** -1.2
+        row, col = (rng.choice(V, B, p=pdf / pdf.sum()).astype(np.int32) for _ in range(2))
+    else:
+        row, col = (rng.integers(0, V, B).astype(np.int32) for _ in range(2))
+    if rng.uniform() < 0.3:
+        row[rng.integers(0, B, max(1, B // 50))] = V + int(rng.integers(0, 5))
+        col[rng.integers(0, B, max(1, B // 70))] = -1 - int(rng.integers(0, 5))
+    w, y = rng.uniform(size=B).astype(np.float32), rng.normal(size=B).astype(np.float32)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    want = ref.build_plan(row, col, cap, V=V)
+    counts = plan.counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, want["counts"], err_msg=str((V, B, cap)))
+    nc_r, nu_r, nc_c, nu_c, n_heavy = counts[:5]
+    got = lambda name, n: getattr(plan, name).cpu().numpy()[:n]
+    for name, n in (("r_partner", B), ("c_partner", B), ("c_perm", B), ("r_to_c", B), ("r_chunk_id", nc_r),
+                    ("c_chunk_id", nc_c), ("r_chunk_start", nc_r + 1), ("c_chunk_start", nc_c + 1),
+                    ("r_uniq_slot", nu_r + 1), ("c_uniq_slot", nu_c + 1)):
+        np.testing.assert_array_equal(got(name, n), want[name], err_msg="%s %s" % (name, (V, B, cap)))
+    np.testing.assert_array_equal(got("r_uniq_rec", 4 * nu_r).reshape(-1, 4), want["r_uniq_rec"])
+    np.testing.assert_array_equal(got("c_uniq_rec", 4 * nu_c).reshape(-1, 4), want["c_uniq_rec"])
+    np.testing.assert_array_equal(np.sort(got("heavy", n_heavy)), want["heavy"])
+    np.testing.assert_array_equal(got("r_w", B), w[want["perm_r"]])
+    np.testing.assert_array_equal(got("c_y", B), y[want["perm_r"]][want["c_perm"]])
+
+
 def test_plan_empty_batch(hip):
     e = torch.empty(0, dtype=torch.int32, device="cuda:0")
     f = torch.empty(0, dtype=torch.float32, device="cuda:0")
