@@ -347,6 +347,8 @@ def main():
             "config": {"workload": args.workload, "V": V, "d": d, "optimizer": args.optimizer,
                        "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz,
                        "resident_batches": nb, "chunk_cap": cap,
+                       **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
+                          if args.rehearse_on_one_gpu else {}),
                        "index": "rebuilt every step" if args.dynamic else "static, built at load",
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "parallelism": ("row-sharded x%d + col all-reduce" % world if args.row_sharded else
