@@ -71,6 +71,7 @@ class Estimator:
                                       params.get("keep_checkpoint_max", 5))
         self.ckpt.restore(self.model.tables)
         self._stream = None
+        self._events = {}
         self.logistic = params.get("head", "regression") == "logistic"
 
     # ---- input_fn
@@ -86,12 +87,22 @@ class Estimator:
         return self._stream
 
     def _log(self, name, record):
+        """One line of <job_dir>/<name> (JSON) plus the same scalars as a TensorBoard event in that directory,
+        where the reference's Estimator leaves its summaries (job_dir for training, job_dir/eval for eval)."""
         if self.rank != 0:
             return
         path = os.path.join(self.params["job_dir"], name)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
             f.write(json.dumps(record) + "\n")
+        logdir = os.path.dirname(path)
+        if logdir not in self._events:
+            from trainer.event_writer import EventWriter
+            self._events[logdir] = EventWriter(logdir)
+        scalars = {k: v for k, v in record.items() if k != "global_step" and isinstance(v, (int, float))}
+        if "steps_per_sec" in scalars:
+            scalars["global_step/sec"] = scalars.pop("steps_per_sec")          # the Estimator's tag
+        self._events[logdir].scalars(record["global_step"], scalars)
 
     # ---- TRAIN
     def train(self, max_steps: int):

@@ -31,6 +31,13 @@ def test_cli_train_resume_export(hip, tmp_path):
     assert all(np.isfinite(r["loss"]) for r in log) and log[-1]["loss"] < log[0]["loss"]
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
     assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
+    # the same scalars as TensorBoard event files, where the reference's Estimator leaves them
+    from trainer.event_writer import read_events
+    (train_events,), (eval_events,) = list(job.glob("events.out.tfevents.*")), list((job / "eval").glob("events.out.tfevents.*"))
+    recs = [(step, sc) for _, step, sc in read_events(train_events) if sc]
+    assert [step for step, _ in recs] == [20, 40, 60]
+    assert abs(recs[-1][1]["loss"] - log[-1]["loss"]) < 1e-6 * abs(log[-1]["loss"]) and "global_step/sec" in recs[0][1]
+    assert "mf/global_bias" in recs[0][1] and [sc["average_loss"] > 0 for _, _, sc in read_events(eval_events) if sc]
     # resume: max_steps is absolute
     estimator.main(argv[:-6] + ["--train-steps", "100", "--log-every", "20", "--seed", "7"])
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]

@@ -120,3 +120,33 @@ def test_synthetic_workloads_are_well_formed():
     r2, c2, w2, y2 = synthetic.zipf_sampled(1000, 20000, seed=1)
     assert (r2 != c2).all() and int(r2.max()) < 1000 and torch.isfinite(y2).all()
     assert np.bincount(r2.numpy(), minlength=1000)[0] > np.bincount(r2.numpy(), minlength=1000)[500]
+
+
+def test_event_files_are_valid_tfrecords_of_event_protos(tmp_path):
+    """trainer.event_writer against its known answers: the CRC-32C check value, and protobuf's own decoder
+    reading the hand-encoded Event / Summary messages."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from trainer.event_writer import EventWriter, crc32c, encode_event, read_events
+    assert crc32c(b"123456789") == 0xE3069283                       # the standard CRC-32C (Castagnoli) check value
+    fdp = descriptor_pb2.FileDescriptorProto(name="ev.proto", package="t", syntax="proto3")
+    val = fdp.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=9, label=1)
+    val.field.add(name="simple_value", number=2, type=2, label=1)
+    fdp.message_type.add(name="Summary").field.add(name="value", number=1, type=11, label=3, type_name=".t.Value")
+    ev = fdp.message_type.add(name="Event")
+    ev.field.add(name="wall_time", number=1, type=1, label=1)
+    ev.field.add(name="step", number=2, type=3, label=1)
+    ev.field.add(name="file_version", number=3, type=9, label=1)
+    ev.field.add(name="summary", number=5, type=11, label=1, type_name=".t.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fdp)
+    msg = message_factory.GetMessageClass(pool.FindMessageTypeByName("t.Event"))()
+    msg.ParseFromString(encode_event(12.5, 1 << 40, {"loss": 0.125, "mf/global_bias": -2.0}))
+    assert (msg.wall_time, msg.step) == (12.5, 1 << 40)
+    assert [(v.tag, v.simple_value) for v in msg.summary.value] == [("loss", 0.125), ("mf/global_bias", -2.0)]
+    msg.ParseFromString(encode_event(1.0, file_version="brain.Event:2"))
+    assert msg.file_version == "brain.Event:2"
+    w = EventWriter(tmp_path)
+    w.scalars(100, {"loss": 0.5, "note": "text is skipped"})
+    w.scalars(200, {"loss": 0.25})
+    assert [(s, sc) for _, s, sc in read_events(w.path)] == [(0, {}), (100, {"loss": 0.5}), (200, {"loss": 0.25})]
