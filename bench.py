@@ -50,6 +50,9 @@ def parse():
                     help="Adam = Keras-legacy dense-decay Adam (config 1 of BASELINE.json), single GPU only")
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
+    ap.add_argument("--build-ahead", type=int, default=1,
+                    help="with --dynamic: index builds in flight (each on its own stream and staging plan), the way an "
+                         "input pipeline prefetches batches; 1 = build and step strictly alternate on one stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -205,6 +208,37 @@ def main():
         G_col_half = G[hip.grad_layout(tables)["G_C"]:]
 
     staging = hip.build_plan(*batches[0], V, chunk_cap=cap) if args.dynamic else None   # refilled every step
+    ahead = max(1, args.build_ahead) if args.dynamic else 1
+    if ahead > 1:
+        # a ring of staging plans, scratch buffers and streams: the index of batch i is built on stream i % ahead
+        # while earlier steps run; it may start once step i - ahead, the previous reader of its staging plan, is done
+        ring = [staging] + [hip.build_plan(*batches[0], V, chunk_cap=cap) for _ in range(ahead - 1)]
+        ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev) for _ in range(ahead)]
+        ring_streams = [torch.cuda.Stream() for _ in range(ahead)]
+
+    def sweep_pipelined(n_steps):
+        """n_steps dynamic steps with `ahead` index builds in flight (call inside a graph capture or eagerly)."""
+        main = torch.cuda.current_stream()
+        built, stepped = [None] * n_steps, [None] * n_steps
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def launch_build(i):
+            st = ring_streams[i % ahead]
+            st.wait_event(stepped[i - ahead] if i >= ahead else start)
+            with torch.cuda.stream(st):
+                hip.build_plan(*batches[i % nb], V, chunk_cap=cap, into=ring[i % ahead], ws=ring_ws[i % ahead])
+                built[i] = torch.cuda.Event()
+                built[i].record(st)
+        for i in range(min(ahead, n_steps)):
+            launch_build(i)
+        for i in range(n_steps):
+            main.wait_event(built[i])
+            hip.step_adagrad(ring[i % ahead], tables, hyper, loss_out, ws)
+            stepped[i] = torch.cuda.Event()
+            stepped[i].record(main)
+            if i + ahead < n_steps:
+                launch_build(i + ahead)
 
     def step(i):
         bt = batches[i % nb]
@@ -235,6 +269,8 @@ def main():
     use_graph = not dense and not args.no_graph
     graph = None
     spg = nb * ((16 + nb - 1) // nb)          # steps per graph: whole sweeps, at least 16 steps per replay
+    if args.dynamic and args.build_ahead > 1:
+        spg = nb * ((96 + nb - 1) // nb)      # the build pipeline fills and drains once per replay: longer graphs
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -245,8 +281,11 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(spg):
-                step(i)
+            if ahead > 1:
+                sweep_pipelined(spg)
+            else:
+                for i in range(spg):
+                    step(i)
 
     def run(n_steps, first):
         done = 0
@@ -349,7 +388,8 @@ def main():
                        "resident_batches": nb, "chunk_cap": cap,
                        **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
                           if args.rehearse_on_one_gpu else {}),
-                       "index": "rebuilt every step" if args.dynamic else "static, built at load",
+                       "index": ("rebuilt every step, %d builds in flight" % ahead if ahead > 1 else
+                                 "rebuilt every step") if args.dynamic else "static, built at load",
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "parallelism": ("row-sharded x%d + col all-reduce" % world if args.row_sharded else
                                        "dp%d dense-grad all-reduce" % world if dense else "single GPU")},

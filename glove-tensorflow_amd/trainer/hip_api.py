@@ -381,10 +381,11 @@ class GloveHip:
 
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
-                   into: Plan | None = None) -> Plan:
+                   into: Plan | None = None, ws: torch.Tensor | None = None) -> Plan:
         """Builds the dedup index of one batch on the device.  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
-        allocations per step this way."""
+        allocations per step this way.  `ws`: scratch of glove_plan_workspace_bytes(B, V) bytes (default: one
+        shared buffer, fine for builds issued on one stream)."""
         _require_cuda(row, col, w, y)
         B = int(row.numel())
         if not chunk_cap:
@@ -395,7 +396,8 @@ class GloveHip:
             plan = into
         else:
             plan = Plan(B, V, chunk_cap, row.device)
-        ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
+        if ws is None:      # builds that run concurrently on different streams each bring their own scratch
+            ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
         return plan.compact(self.lib) if compact else plan
