@@ -61,6 +61,11 @@ FLAGS = (
     Flag("save-checkpoints-secs", float, 300.0, "seconds between checkpoints (each followed by an eval pass)"),
     Flag("keep-checkpoint-max", int, 5, "checkpoints kept in the job directory"),
     Flag("skip-eval", None, False, "checkpoint without the eval pass"),
+    Flag("epoch-shuffle", str, "static", "static: the pairs are permuted once, cut into batches whose dedup index is "
+                                         "built at load, and every epoch visits the batches in a new order; full: a "
+                                         "new permutation of the pairs every epoch (single GPU), indexes built as "
+                                         "the batches are used"),
+    Flag("build-ahead", int, 4, "index builds in flight with --epoch-shuffle full"),
 )
 
 

@@ -111,7 +111,9 @@ class NonzeroStream:
     """
 
     def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
-                 chunk_cap=0):
+                 chunk_cap=0, static_plans=True):
+        """`static_plans=False`: no index is built here; the caller re-permutes the pairs every epoch
+        (`reshuffle_in_place`) and indexes each batch when it is used (--epoch-shuffle full)."""
         self.B, self.V, self.backend, self.device = int(batch_size), int(V), backend, torch.device(device)
         self.chunk_cap = chunk_cap
         self.gen = torch.Generator(device="cpu")
@@ -130,8 +132,20 @@ class NonzeroStream:
         if self.nnz < self.B:
             raise ValueError("batch size %d exceeds the %d nonzeros of this rank" % (self.B, self.nnz))
         self.plans = []
-        self.recut(first=True)
+        if static_plans:
+            self.recut(first=True)
         self._order, self._pos = None, 0
+
+    def reshuffle_in_place(self):
+        """A fresh permutation of this rank's pairs written into the SAME buffers: a captured hipGraph that reads
+        batch b at `row[b*B:(b+1)*B]` … sees the new epoch's batch there on its next replay."""
+        p = torch.randperm(self.nnz, generator=self.gen).to(self.device)
+        for t in (self.row, self.col, self.w, self.y):
+            t.copy_(t[p])
+
+    def batch(self, b: int):
+        s = slice(b * self.B, (b + 1) * self.B)
+        return self.row[s], self.col[s], self.w[s], self.y[s]
 
     def recut(self, first=False):
         if not first:
@@ -144,7 +158,7 @@ class NonzeroStream:
 
     @property
     def batches_per_epoch(self) -> int:
-        return len(self.plans)
+        return self.nnz // self.B
 
     def next_plan(self):
         if self._order is None or self._pos >= len(self._order):

@@ -72,6 +72,11 @@ class Estimator:
         self.ckpt.restore(self.model.tables)
         self._stream = None
         self._events = {}
+        self.reshuffling = params.get("epoch_shuffle", "static") == "full"
+        if params.get("epoch_shuffle", "static") not in ("static", "full"):
+            raise ValueError("--epoch-shuffle must be static or full, got %r" % (params["epoch_shuffle"],))
+        if self.reshuffling and (self.world > 1 or not hasattr(self.backend, "hip")):
+            raise ValueError("--epoch-shuffle full runs on one GPU (the data-parallel stream is static)")
         self.logistic = params.get("head", "regression") == "logistic"
 
     # ---- input_fn
@@ -83,7 +88,8 @@ class Estimator:
                                        cache_dir=self.params["job_dir"] if self.rank == 0 else None)
             self._stream = NonzeroStream(coo, a["batch_size"], self.vocab_size, self.backend, self.device,
                                          rank=self.rank, world=self.world, seed=self.params.get("seed"),
-                                         chunk_cap=self.params.get("chunk_cap", 0))
+                                         chunk_cap=self.params.get("chunk_cap", 0),
+                                         static_plans=not self.reshuffling)
         return self._stream
 
     def _log(self, name, record):
@@ -117,17 +123,30 @@ class Estimator:
                             learning_rate=p["learning_rate"])
         if self.logistic:       # logistic_matrix_factorisation.py:50-54: the stream's (w, y) are (pos, neg) weights
             hyper_kwargs.update(head=1, neg_factor=p.get("neg_factor", 1.0))
-        stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
         log_every = max(1, int(p.get("log_every", 100)))
+        if self.reshuffling:
+            from trainer.stepper import ReshufflingRunner
+            stepper = ReshufflingRunner(self.backend.hip, stream, tables,
+                                        self.backend.make_hyper(batch_size=p["batch_size"], **hyper_kwargs),
+                                        chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4), burst=log_every)
+        else:
+            stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
         if self.rank == 0 and self.ckpt.latest() is None:
             self.ckpt.save(tables)          # Estimator saves at step 0 too
         t_last, s_last = time.perf_counter(), step
         while step < max_steps:
             # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
-            burst = min(max_steps, (step // log_every + 1) * log_every) - step
-            stepper.step_many([stream.next_plan() for _ in range(burst)])
-            step += burst
-            if step % log_every == 0 or step == max_steps:
+            if self.reshuffling:
+                # a burst ends at a multiple of log_every batches of the epoch, at the epoch's end or at max_steps
+                done = stepper.run(max_steps - step)
+                step += done
+                at_log_point = True
+            else:
+                burst = min(max_steps, (step // log_every + 1) * log_every) - step
+                stepper.step_many([stream.next_plan() for _ in range(burst)])
+                step += burst
+                at_log_point = step % log_every == 0 or step == max_steps
+            if at_log_point:
                 rec = stepper.read_loss()                      # device sync
                 if not math.isfinite(rec["loss"]):
                     raise FloatingPointError("loss is %r at global_step %d" % (rec["loss"], step))   # NanTensorHook

@@ -181,3 +181,101 @@ class RowShardedStepper:
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
         return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}
+
+
+class ReshufflingRunner:
+    """Single-GPU training over a stream whose pairs are re-permuted every epoch (`--epoch-shuffle full`): the
+    batches are new every epoch, so their dedup index is built when they are used — like an input pipeline that
+    prefetches batches, `ahead` index builds are in flight on their own streams and staging plans while earlier
+    steps run.  A burst of consecutive batches [first, first + count) is captured ONCE as a hipGraph (builds,
+    steps and their cross-stream dependencies) and replayed in every later epoch: the graph reads the batch
+    positions of the stream's buffers, which `NonzeroStream.reshuffle_in_place` refills.
+    """
+
+    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128):
+        from trainer.hip_api import auto_chunk_cap
+        self.hip, self.stream, self.tables, self.hyper = hip, stream, tables, hyper
+        self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
+        self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
+        dev, B, V = tables.device, stream.B, stream.V
+        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap) for _ in range(self.ahead)]
+        self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
+                        for _ in range(self.ahead)]
+        self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
+        self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
+        self.G = hip.dense_grad_buffer(tables) if tables.optimizer == "Adam" else None
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.graphs = {}
+        self.position = 0                      # next batch of the current epoch
+        stream.reshuffle_in_place()
+        # every kernel of the sequence is launched once outside any capture (on throw-away tables of the same shape)
+        from trainer.hip_api import DeviceTables
+        real = self.tables
+        self.tables = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._issue(0, min(self.ahead + 1, stream.batches_per_epoch))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.tables = real
+        if self.G is not None:
+            self.G.zero_()
+
+    def _step(self, plan):
+        if self.G is None:
+            self.hip.step_adagrad(plan, self.tables, self.hyper, self.loss_out, self.step_ws)
+        else:
+            self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
+
+    def _issue(self, first, count):
+        """`count` steps over batches first..first+count-1 with `ahead` index builds in flight."""
+        main = torch.cuda.current_stream()
+        built, stepped = [None] * count, [None] * count
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def launch_build(i):
+            st = self.ring_streams[i % self.ahead]
+            st.wait_event(stepped[i - self.ahead] if i >= self.ahead else start)
+            with torch.cuda.stream(st):
+                self.hip.build_plan(*self.stream.batch(first + i), self.stream.V, chunk_cap=self.cap,
+                                    into=self.ring[i % self.ahead], ws=self.ring_ws[i % self.ahead])
+                built[i] = torch.cuda.Event()
+                built[i].record(st)
+        for i in range(min(self.ahead, count)):
+            launch_build(i)
+        for i in range(count):
+            main.wait_event(built[i])
+            self._step(self.ring[i % self.ahead])
+            stepped[i] = torch.cuda.Event()
+            stepped[i].record(main)
+            if i + self.ahead < count:
+                launch_build(i + self.ahead)
+
+    def run(self, n_steps: int) -> int:
+        """Up to `n_steps` steps, never across an epoch boundary or a burst boundary; returns the number done."""
+        nb = self.stream.batches_per_epoch
+        if self.position >= nb:
+            self.stream.reshuffle_in_place()
+            self.position = 0
+        first = self.position
+        count = min(n_steps, nb - first, self.burst - first % self.burst)
+        key = (first, count)
+        if key not in self.graphs and len(self.graphs) < 256:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._issue(first, count)
+            self.graphs[key] = graph
+        if key in self.graphs:
+            self.graphs[key].replay()
+        else:
+            self._issue(first, count)              # cache full: same sequence, launched eagerly
+        self.position += count
+        return count
+
+    def read_loss(self) -> dict:
+        """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
+        loss, L, reg, _ = self.loss_out.tolist()
+        return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}

@@ -247,3 +247,65 @@ def test_non_finite_loss_stops_training(hip, tmp_path):
             "--train-steps", "200", "--log-every", "10", "--seed", "1"]
     with pytest.raises(FloatingPointError, match="global_step"):
         estimator.main(argv)
+
+
+@pytest.mark.parametrize("optimizer,lr", [("Adagrad", 0.05), ("Adam", 0.001)])
+def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr):
+    """--epoch-shuffle full: cached hipGraphs of prefetched index builds + steps, replayed over re-permuted
+    buffers, give bit for bit what building and stepping batch after batch gives, across epoch boundaries."""
+    from trainer import synthetic
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ReshufflingRunner
+    V, d, B = 300, 32, 256
+    row, col, w, y = synthetic.text8_shaped(V=V, n_tokens=60_000, seed=2)
+    coo = dict(row=row.numpy(), col=col.numpy(), w=w.numpy(), y=y.numpy())
+    backend = HipBackend("cuda:0")
+    hyper = make_hyper(learning_rate=lr, batch_size=B)
+    steps = None
+    results = []
+    for mode in ("runner", "plain"):
+        stream = NonzeroStream(coo, B, V, backend, "cuda:0", seed=11, static_plans=False)
+        tables = DeviceTables(V, d, optimizer, seed=4)
+        nb = stream.batches_per_epoch
+        steps = 2 * nb + 7                                  # two full epochs and a bit
+        if mode == "runner":
+            runner = ReshufflingRunner(hip, stream, tables, hyper, ahead=3, burst=16)
+            done = 0
+            while done < steps:
+                done += runner.run(steps - done)
+            loss = runner.read_loss()["loss"]
+        else:
+            G = hip.dense_grad_buffer(tables) if optimizer == "Adam" else None
+            loss_out = torch.zeros(4, device="cuda:0")
+            pos = nb                                          # forces the first reshuffle, as the runner's constructor does
+            for _ in range(steps):
+                if pos >= nb:
+                    stream.reshuffle_in_place()
+                    pos = 0
+                plan = hip.build_plan(*stream.batch(pos), V, chunk_cap=0)
+                if G is None:
+                    hip.step_adagrad(plan, tables, hyper, loss_out)
+                else:
+                    hip.step_adam(plan, tables, hyper, G, loss_out)
+                pos += 1
+            loss = float(loss_out[0])
+        results.append((tables, loss))
+    (a, la), (b, lb) = results
+    assert a.global_step == b.global_step == steps and la == lb
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_cli_with_full_epoch_shuffle(hip, tmp_path):
+    from trainer import estimator
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    estimator.main(["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+                    "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+                    "--train-steps", "150", "--log-every", "25", "--seed", "5", "--epoch-shuffle", "full",
+                    "--build-ahead", "3"])
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert log[-1]["global_step"] == 150 and log[-1]["loss"] < log[0]["loss"]
+    assert all(b["global_step"] - a["global_step"] <= 25 for a, b in zip(log, log[1:]))    # a burst never exceeds --log-every
+    assert (job / "model.ckpt-150.pt").exists()

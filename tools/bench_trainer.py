@@ -19,12 +19,13 @@ vocab = ["<UNK>"] + ["w%d" % i for i in range(1, V)]
 tok = np.asarray(vocab, dtype=object)
 pd.DataFrame({"row_token": tok[row.numpy()], "col_token": tok[col.numpy()], "glove_weight": w.numpy(),
               "glove_value": y.numpy()}).to_csv(tmp / "interaction.csv", index=False)
-for opt, lr in (("Adagrad", "0.05"), ("Adam", "0.001")):
-    job = tmp / ("job_" + opt)
+for opt, lr, extra in (("Adagrad", "0.05", []), ("Adam", "0.001", []),
+                       ("Adagrad", "0.05", ["--epoch-shuffle", "full"]), ("Adam", "0.001", ["--epoch-shuffle", "full"])):
+    job = tmp / ("job_" + opt + "_".join(extra))
     estimator.main(["--train-csv", str(tmp / "interaction.csv"), "--vocab-txt", str(tmp / "vocab.txt"), "--job-dir", str(job),
                     "--disable-datetime-path", "--optimizer", opt, "--learning-rate", lr, "--train-steps", "20000",
-                    "--log-every", "1000", "--skip-eval", "--seed", "1"])
+                    "--log-every", "1000", "--skip-eval", "--seed", "1"] + extra)
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
-    print(opt, "bs=1024: %.0f steps/s, %.3g nonzeros/s, loss %.4f -> %.4f" % (
+    print(opt, " ".join(extra), "bs=1024: %.0f steps/s, %.3g nonzeros/s, loss %.4f -> %.4f" % (
         np.median([r["steps_per_sec"] for r in log[1:]]), np.median([r["nonzeros_per_sec"] for r in log[1:]]),
         log[0]["loss"], log[-1]["loss"]))
