@@ -4,34 +4,17 @@
 // reference's default batch of 1,024 nonzeros, where one step of the kernels takes ~10 us.  A caller
 // that hands over a fresh batch every step (the reference's input_fn does: data_utils.py:12-21) needs
 // the index in a few microseconds, so batches up to 4,096 pairs are indexed by ONE workgroup entirely
-// in LDS: two bitonic sorts of (id << 13 | position) keys — stable by construction — and three block
-// scans per side.  The result is identical to the general path and to oracle/glove_ref.py:build_plan.
+// in LDS: two stable block radix sorts by id (rocPRIM's block primitive, 8 bits per pass: two passes for a
+// 10^4-id vocabulary; the first form, a bitonic sort of 64-bit (id, position) keys, spent 70 of its 110 us at
+// B = 4,096 in its 78 LDS-bound sub-stages) and three block scans per side.  The result is identical to the
+// general path and to oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
+
+#include <rocprim/block/block_radix_sort.hpp>
 
 namespace glove {
 
 constexpr int kSmallThreads = 1024;
-constexpr int kPosBits = 13;                      // position < 8192
-constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
-
-// in-place ascending bitonic sort of np (power of two) 64-bit keys in LDS by the whole workgroup
-__device__ inline void bitonic_sort(uint64_t *keys, int np)
-{
-    for (int k = 2; k <= np; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < np / 2; t += kSmallThreads) {
-                // t-th compare-exchange of this stage: lower index i has bit j clear
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const bool up = (i & k) == 0;
-                const uint64_t a = keys[i], b = keys[l];
-                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // inclusive scan of n ints in LDS (in place) by the whole workgroup; op: 0 = sum, 1 = max
 template <int OP>
 __device__ inline void block_scan(int *v, int n, int *wave_tot /* [16] */)
@@ -124,42 +107,67 @@ __device__ inline void small_side(const int *ids, int B, int cap, int heavy_chun
     __syncthreads();
 }
 
+template <int E>
+using SmallSort = rocprim::block_radix_sort<uint32_t, kSmallThreads, E, int32_t>;
+
+// dynamic LDS: four int arrays of np (row ids / col ids / w / y in sorted order) followed by a scratch area that is
+// the sort's storage during the sorts and three int arrays of np (scan scratch) between them
+template <int E>
+constexpr size_t small_scratch_bytes()
+{
+    return sizeof(typename SmallSort<E>::storage_type) > (size_t)3 * kSmallThreads * E * 4
+               ? sizeof(typename SmallSort<E>::storage_type)
+               : (size_t)3 * kSmallThreads * E * 4;
+}
+
+template <int E>
 __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
-    const float *__restrict__ y, int B, int V, int np, glove_plan plan)
+    const float *__restrict__ y, int B, int V, int key_bits, glove_plan plan)
 {
+    constexpr int np = kSmallThreads * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);                 // [np]
-    int *srow = reinterpret_cast<int *>(keys + np);                      // [np] row ids, row-sorted
+    int *srow = reinterpret_cast<int *>(smem);                           // [np] row ids, row-sorted
     int *scol = srow + np;                                               // [np] col ids, row-sorted; then col-sorted
     float *sw = reinterpret_cast<float *>(scol + np);                    // [np] w, row-sorted
     float *sy = sw + np;                                                 // [np]
-    int *sa = reinterpret_cast<int *>(sy + np);                          // scan scratch
+    unsigned char *scratch = reinterpret_cast<unsigned char *>(sy + np);
+    auto &sort_storage = *reinterpret_cast<typename SmallSort<E>::storage_type *>(scratch);
+    int *sa = reinterpret_cast<int *>(scratch);                          // scan scratch, live between the sorts
     int *sb = sa + np;
     int *sc = sb + np;
     __shared__ int wave_tot[16];
     if (threadIdx.x < 8) plan.counts[threadIdx.x] = 0;
     __syncthreads();
+    const uint32_t pad_key = 1u << (key_bits - 1);                       // sorts behind every id: ids < 2^(key_bits-1)
 
-    // ---- row side: stable sort by (row id, position); ids outside [0, V) count as id 0 (see prepare_ids)
+    // ---- row side: stable sort by row id (blocked arrangement: thread t holds positions t E .. t E + E - 1);
+    // ids outside [0, V) count as id 0 (see prepare_ids in glove_plan.hip)
+    uint32_t key[E];
+    int32_t pos[E];
     int mapped = 0;
-    for (int i = threadIdx.x; i < np; i += kSmallThreads) {
-        uint64_t key = ~0ull;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = threadIdx.x * E + e;
+        key[e] = pad_key;
+        pos[e] = i;
         if (i < B) {
             uint32_t r = (uint32_t)row[i];
             if (r >= (uint32_t)V) { r = 0; ++mapped; }
-            key = ((uint64_t)r << kPosBits) | (uint64_t)i;
+            key[e] = r;
         }
-        keys[i] = key;
     }
+    SmallSort<E>().sort(key, pos, sort_storage, 0, key_bits);
     __syncthreads();
-    bitonic_sort(keys, np);
-    for (int k = threadIdx.x; k < B; k += kSmallThreads) {
-        const int p = (int)(keys[k] & kPosMask);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = threadIdx.x * E + e;
+        if (k >= B) continue;
+        const int p = pos[e];
         int c = col[p];
         if ((uint32_t)c >= (uint32_t)V) { c = 0; ++mapped; }
         const float wv = w[p], yv = y[p];
-        srow[k] = (int)(keys[k] >> kPosBits);
+        srow[k] = (int)key[e];
         scol[k] = c; sw[k] = wv; sy[k] = yv;
         plan.r_partner[k] = c; plan.r_w[k] = wv; plan.r_y[k] = yv;
     }
@@ -169,40 +177,62 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
                SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts + 0,
                plan.heavy, plan.counts + 4);
 
-    // ---- col side: stable sort of the row-sorted pairs by (col id, row-sorted position)
-    for (int i = threadIdx.x; i < np; i += kSmallThreads)
-        keys[i] = i < B ? (((uint64_t)(uint32_t)scol[i] << kPosBits) | (uint64_t)i) : ~0ull;
+    // ---- col side: stable sort of the row-sorted pairs by col id
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = threadIdx.x * E + e;
+        key[e] = i < B ? (uint32_t)scol[i] : pad_key;
+        pos[e] = i;
+    }
+    __syncthreads();                                                     // scol read, scan scratch dead: storage free
+    SmallSort<E>().sort(key, pos, sort_storage, 0, key_bits);
     __syncthreads();
-    bitonic_sort(keys, np);
-    for (int j = threadIdx.x; j < B; j += kSmallThreads) {
-        const int p = (int)(keys[j] & kPosMask);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = threadIdx.x * E + e;
+        if (j >= B) continue;
+        const int p = pos[e];
         plan.c_perm[j] = p;
         plan.r_to_c[p] = j;
         plan.c_partner[j] = srow[p];
         plan.c_w[j] = sw[p];
         plan.c_y[j] = sy[p];
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < B; j += kSmallThreads) scol[j] = (int)(keys[j] >> kPosBits);   // col ids, col-sorted
+    __syncthreads();                                                     // srow / sw / sy gathers done before scol changes
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = threadIdx.x * E + e;
+        if (j < B) scol[j] = (int)key[e];                                // col ids, col-sorted
+    }
     __syncthreads();
     small_side(scol, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 1, sa, sb, sc, wave_tot,
                SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec}, plan.counts + 2,
                plan.heavy, plan.counts + 4);
 }
 
+template <int E>
+static int launch_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
+                        const glove_plan *plan, hipStream_t st)
+{
+    const size_t smem = (size_t)4 * kSmallThreads * E * 4 + small_scratch_bytes<E>();
+    int key_bits = 2;                                                    // ids < 2^(key_bits-1), padding key 2^(key_bits-1)
+    while (key_bits < 32 && (1u << (key_bits - 1)) < (uint32_t)V) ++key_bits;
+    // above the 64 KiB default of dynamic LDS: the limit is raised explicitly
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<E>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plan_small_kernel<E>, dim3(1), dim3(kSmallThreads), smem, st, row, col, w, y, (int)B, (int)V,
+                       key_bits, *plan);
+    return (int)hipGetLastError();
+}
+
 // host side: called from glove_plan_build for B <= kSmallPlanMax
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st)
 {
-    int np = 64;
-    while (np < B) np <<= 1;
-    const size_t smem = (size_t)np * (8 + 4 * 7);
-    // up to 144 KiB of the CU's 160 KiB LDS: above the 64 KiB default, so the limit is raised explicitly
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(kSmallThreads), smem, st, row, col, w, y, (int)B, (int)V, np, *plan);
-    return (int)hipGetLastError();
+    if (B <= kSmallThreads) return launch_small<1>(row, col, w, y, B, V, plan, st);
+    if (B <= 2 * kSmallThreads) return launch_small<2>(row, col, w, y, B, V, plan, st);
+    return launch_small<4>(row, col, w, y, B, V, plan, st);
 }
 
 }  // namespace glove

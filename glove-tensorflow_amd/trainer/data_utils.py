@@ -135,11 +135,15 @@ class NonzeroStream:
         if static_plans:
             self.recut(first=True)
         self._order, self._pos = None, 0
+        self._dev_gen = None
 
     def reshuffle_in_place(self):
         """A fresh permutation of this rank's pairs written into the SAME buffers: a captured hipGraph that reads
         batch b at `row[b*B:(b+1)*B]` … sees the new epoch's batch there on its next replay."""
-        p = torch.randperm(self.nnz, generator=self.gen).to(self.device)
+        if self._dev_gen is None:       # permutations drawn on the device (a host randperm of 10^6 pairs per epoch would
+            self._dev_gen = torch.Generator(device=self.device)      # cost as much as the epoch's steps), seeded from the stream's generator
+            self._dev_gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,), generator=self.gen)))
+        p = torch.randperm(self.nnz, generator=self._dev_gen, device=self.device)
         for t in (self.row, self.col, self.w, self.y):
             t.copy_(t[p])
 

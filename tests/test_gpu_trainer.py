@@ -307,5 +307,5 @@ def test_cli_with_full_epoch_shuffle(hip, tmp_path):
                     "--build-ahead", "3"])
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
     assert log[-1]["global_step"] == 150 and log[-1]["loss"] < log[0]["loss"]
-    assert all(b["global_step"] - a["global_step"] <= 25 for a, b in zip(log, log[1:]))    # a burst never exceeds --log-every
+    assert all(b["global_step"] - a["global_step"] < 50 for a, b in zip(log, log[1:]))     # a line per crossed multiple of --log-every
     assert (job / "model.ckpt-150.pt").exists()
