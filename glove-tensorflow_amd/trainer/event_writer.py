@@ -118,9 +118,11 @@ def read_events(path):
     while pos < len(data):
         header = data[pos:pos + 8]
         (n,) = struct.unpack("<Q", header)
-        assert data[pos + 8:pos + 12] == _masked(header), "length checksum"
+        if data[pos + 8:pos + 12] != _masked(header):
+            raise ValueError("%s: corrupt record length at byte %d" % (path, pos))
         payload = data[pos + 12:pos + 12 + n]
-        assert data[pos + 12 + n:pos + 16 + n] == _masked(payload), "payload checksum"
+        if data[pos + 12 + n:pos + 16 + n] != _masked(payload):
+            raise ValueError("%s: corrupt record payload at byte %d" % (path, pos))
         pos += 16 + n
         wall, step, scalars = 0.0, 0, {}
         for number, val in parse(payload):

@@ -140,7 +140,8 @@ def route_by_row_owner(coo: dict, world: int, rank: int, dist) -> dict:
         dst = torch.empty(int(sum(r_list)), dtype=src.dtype, device=src.device)
         dist.all_to_all_single(dst, src, output_split_sizes=r_list, input_split_sizes=s_list)
         out[k] = dst
-    assert bool((out["row"] % world == rank).all())
+    if not bool((out["row"] % world == rank).all()):
+        raise RuntimeError("all-to-all routing delivered a nonzero to a rank that does not own its row")
     out["row"] = (out["row"] // world).to(coo["row"].dtype)
     return out
 
