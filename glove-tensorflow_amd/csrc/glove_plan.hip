@@ -355,6 +355,12 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     return p;
 }
 
+// Below 2^20 items rocPRIM's radix_sort_pairs is a merge sort: a block sort of tiles, then one launch per doubling.
+// The default tile is 512 items (nine launches for a 131 k batch, each a few microseconds of mostly latency);
+// 8,192-item tiles (512 threads x 16) need four merges: 150 -> 133 us per dynamic step, 90 -> 67 with six builds in
+// flight.  (Tiles of 4,096 / 16,384: 139 / 156 us; forcing the onesweep radix path instead: 180 us.)
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<256, 512, 16>>;
+
 static int ceil_log2(int32_t v)
 {
     int b = 1;
@@ -411,19 +417,19 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     // ---- row side: stable sort (row id, position)
     hipLaunchKernelGGL(prepare_ids, dim3(nb), dim3(kBlock), 0, st, row, col, B, V, pw.iota, pw.row_clean, pw.col_clean,
                        plan->counts + 5);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
+    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
                                       (size_t)B, 0, bits, st));
     if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
+    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(pw.prim, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
                                       (size_t)B, 0, bits, st));
     hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, pw.col_clean, w, y, B, plan->r_partner,
                        plan->r_w, plan->r_y);
 
     // ---- col side: stable sort of the row-sorted pairs by col id
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
+    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
                                       plan->c_perm, (size_t)B, 0, bits, st));
     if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::radix_sort_pairs(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
+    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
                                       plan->c_perm, (size_t)B, 0, bits, st));
     hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, plan->r_w, plan->r_y, B,
                        plan->c_partner, plan->r_to_c, plan->c_w, plan->c_y);
