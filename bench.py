@@ -155,7 +155,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from trainer import synthetic
+    from trainer import hip_api, synthetic
+    if not hip_api.LIB_PATH.exists():
+        # sources arrived without the built library: the first local rank compiles it (hipcc is part of the image),
+        # the others wait for the file; a failing build ends the run
+        if local_rank == 0 or args.rehearse_on_one_gpu and rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        for _ in range(600):
+            if hip_api.LIB_PATH.exists():
+                break
+            time.sleep(1.0)
     from trainer.hip_api import DeviceTables, GloveHip, make_hyper
 
     hip = GloveHip(dev)
@@ -401,8 +411,12 @@ def main():
             "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1 and not args.force_dense:
-            out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds,
-                                               args.optimizer)
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds,
+                                                   args.optimizer)
+            except Exception as exc:                     # the baseline is a side measurement: never lose the bench line to it
+                out["cpu_baseline"] = {"value": None, "unit": "nonzeros/s", "cores": 1, "kind": "port",
+                                       "sample": "failed: %s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     if dense:
         dist.destroy_process_group()

@@ -22,5 +22,10 @@ def hip():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU in this container")
-    from trainer.hip_api import GloveHip
-    return GloveHip("cuda:0")
+    from trainer import hip_api
+    if not hip_api.LIB_PATH.exists():
+        # a GPU box that received the sources without the built library: compile it here (hipcc is part of the image);
+        # a failing build is an error like a missing library is
+        import __graft_entry__
+        __graft_entry__.build()
+    return hip_api.GloveHip("cuda:0")
