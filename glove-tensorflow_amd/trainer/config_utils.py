@@ -66,6 +66,9 @@ FLAGS = (
                                          "new permutation of the pairs every epoch (single GPU), indexes built as "
                                          "the batches are used"),
     Flag("build-ahead", int, 4, "index builds in flight with --epoch-shuffle full"),
+    Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
+                                     "nonzero to the rank that owns its row, instead of replicating all tables "
+                                     "(BASELINE config 5; Adagrad only)"),
 )
 
 

@@ -111,7 +111,7 @@ class NonzeroStream:
     """
 
     def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
-                 chunk_cap=0, static_plans=True):
+                 chunk_cap=0, static_plans=True, route=None):
         """`static_plans=False`: no index is built here; the caller re-permutes the pairs every epoch
         (`reshuffle_in_place`) and indexes each batch when it is used (--epoch-shuffle full)."""
         self.B, self.V, self.backend, self.device = int(batch_size), int(V), backend, torch.device(device)
@@ -128,6 +128,17 @@ class NonzeroStream:
         mine = perm[rank * per:(rank + 1) * per] if world > 1 else perm
         take = lambda a: torch.from_numpy(np.ascontiguousarray(a))[mine].to(self.device)
         self.row, self.col, self.w, self.y = take(coo["row"]), take(coo["col"]), take(coo["w"]), take(coo["y"])
+        if route is not None:
+            # row-sharded model: every nonzero moves to the rank that owns its row (one all-to-all at load), row ids
+            # become local; the ranks then agree on a common number of nonzeros, so that they run the same number of
+            # (collective) steps per epoch
+            from trainer.stepper import route_by_row_owner
+            dist = route
+            got = route_by_row_owner(dict(row=self.row, col=self.col, w=self.w, y=self.y), world, rank, dist)
+            keep = torch.tensor([got["row"].numel()], dtype=torch.int64, device=self.device)
+            dist.all_reduce(keep, op=dist.ReduceOp.MIN)
+            keep = int(keep.item())
+            self.row, self.col, self.w, self.y = (got[k][:keep].contiguous() for k in ("row", "col", "w", "y"))
         self.nnz = int(self.row.numel())
         if self.nnz < self.B:
             raise ValueError("batch size %d exceeds the %d nonzeros of this rank" % (self.B, self.nnz))

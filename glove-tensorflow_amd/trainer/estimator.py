@@ -67,9 +67,21 @@ class Estimator:
             t = self.model.tables
             for buf in (t.R, t.C, t.br, t.bc):
                 self.dist.broadcast(buf, src=0)
+        self.row_sharded = bool(params.get("row_sharded")) and self.world > 1
+        if self.row_sharded:
+            if self.optimizer_name != "Adagrad":
+                raise ValueError("--row-sharded is implemented for Adagrad (Keras' Adam has no sparse form)")
+            # keep this rank's rows (u % world == rank) of the row side; the col side stays replicated
+            from trainer.hip_api import DeviceTables
+            from trainer.stepper import owned_rows
+            whole = self.model.tables
+            shard = DeviceTables(whole.V, whole.d_model, whole.optimizer, device=self.device, seed=0,
+                                 V_row=owned_rows(whole.V, self.world, self.rank))
+            shard.load_whole_state_dict(whole.state_dict(), self.world, self.rank)
+            self.model.tables = shard
         self.ckpt = CheckpointManager(params["job_dir"], params.get("save_checkpoints_secs", 300.0),
                                       params.get("keep_checkpoint_max", 5))
-        self.ckpt.restore(self.model.tables)
+        self.ckpt.restore(self.model.tables, shard=(self.world, self.rank) if self.row_sharded else None)
         self._stream = None
         self._events = {}
         self.reshuffling = params.get("epoch_shuffle", "static") == "full"
@@ -89,7 +101,8 @@ class Estimator:
             self._stream = NonzeroStream(coo, a["batch_size"], self.vocab_size, self.backend, self.device,
                                          rank=self.rank, world=self.world, seed=self.params.get("seed"),
                                          chunk_cap=self.params.get("chunk_cap", 0),
-                                         static_plans=not self.reshuffling)
+                                         static_plans=not self.reshuffling,
+                                         route=self.dist if self.row_sharded else None)
         return self._stream
 
     def _log(self, name, record):
@@ -130,10 +143,18 @@ class Estimator:
                                         self.backend.make_hyper(batch_size=p["batch_size"], **hyper_kwargs),
                                         chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4),
                                         burst=min(log_every, 100))      # graphs of ~100 steps replay fastest (measured)
+        elif self.row_sharded:
+            from trainer.stepper import RowShardedStepper
+            stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
         else:
             stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
-        if self.rank == 0 and self.ckpt.latest() is None:
-            self.ckpt.save(tables)          # Estimator saves at step 0 too
+        fresh = self.ckpt.latest() is None
+        if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
+            flag = torch.tensor([1 if fresh else 0], device=self.device)
+            self.dist.broadcast(flag, src=0)
+            fresh = bool(flag.item())
+        if fresh:
+            self._save_checkpoint()         # Estimator saves at step 0 too
         t_last, s_last = time.perf_counter(), step
         while step < max_steps:
             # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
@@ -165,11 +186,17 @@ class Estimator:
                 self.dist.broadcast(flag, src=0)
                 due = bool(flag.item())
             if due:
-                if self.rank == 0:
-                    self.ckpt.save(tables)
+                self._save_checkpoint()
                 if not p.get("skip_eval"):
                     self.evaluate()
         torch.cuda.synchronize() if self.device.type == "cuda" else None
+
+    def _save_checkpoint(self):
+        """Rank 0 writes; a row-sharded run first gathers the whole model (collective: every rank calls this)."""
+        tables = self.model.tables
+        state = tables.gathered_state_dict(self.dist, self.world) if self.row_sharded else None
+        if self.rank == 0:
+            self.ckpt.save(tables, state=state)
 
     # ---- EVAL
     def evaluate(self) -> dict:

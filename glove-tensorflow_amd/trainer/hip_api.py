@@ -246,6 +246,40 @@ class DeviceTables:
             if n in self.s2:
                 self._store(self.s2[n], sd["slot2_" + n])
 
+    # ---- row-sharded tables (BASELINE config 5): row u lives on rank u % world at local index u // world
+    ROW_SIDE = ("R", "br")
+
+    def gathered_state_dict(self, dist, world: int) -> dict:
+        """state_dict() of the WHOLE model: the row-side shards of all ranks are all-gathered and interleaved
+        back into [V, ...] arrays, so the checkpoint has the same format as an unsharded run's (collective)."""
+        per = (self.V + world - 1) // world
+
+        def whole(x):
+            pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            pad[:x.shape[0]] = x
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            return torch.stack(parts, 1).reshape((per * world,) + tuple(x.shape[1:]))[:self.V]
+        out = self.state_dict()
+        out["V_row"] = self.V
+        for n in self.ROW_SIDE:
+            out[n] = self._logical(whole(getattr(self, n)))
+            out["slot1_" + n] = self._logical(whole(self.s1[n]))
+            if n in self.s2:
+                out["slot2_" + n] = self._logical(whole(self.s2[n]))
+        return out
+
+    def load_whole_state_dict(self, sd: dict, world: int, rank: int):
+        """Takes this rank's rows out of a whole-model state dict (the inverse of gathered_state_dict)."""
+        if sd.get("V_row", sd["V"]) != sd["V"]:
+            raise ValueError("the checkpoint holds a row shard, not the whole model")
+        mine = dict(sd, V_row=self.V_row)
+        for n in self.ROW_SIDE:
+            for key in (n, "slot1_" + n, "slot2_" + n):
+                if key in sd:
+                    mine[key] = sd[key][rank::world]
+        self.load_state_dict(mine)
+
     @property
     def global_bias(self) -> float:
         return float(self.scalars[0].item())

@@ -179,6 +179,10 @@ class RowShardedStepper:
             self.dist.all_reduce(b.col_half(t, self.G))
         b.apply_dense(t, self.hyper_cols, self.G, self.loss_out)
 
+    def step_many(self, plans):
+        for plan in plans:
+            self.step(plan)
+
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
         return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}

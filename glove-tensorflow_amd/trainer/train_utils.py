@@ -67,12 +67,14 @@ class CheckpointManager:
     def due(self) -> bool:
         return time.monotonic() - self._last_save >= self.save_secs
 
-    def save(self, tables, extra=None) -> str:
+    def save(self, tables, extra=None, state=None) -> str:
+        """`state`: the state dict to store instead of tables.state_dict() (a row-sharded run hands over the
+        gathered whole-model dict, so the file looks like any other checkpoint)."""
         step = tables.global_step
         name = "%s%d" % (self.PREFIX, step)
         os.makedirs(self.model_dir, exist_ok=True)
         tmp = os.path.join(self.model_dir, name + ".pt.tmp")
-        torch.save({"tables": tables.state_dict(), "extra": extra or {}}, tmp)
+        torch.save({"tables": state if state is not None else tables.state_dict(), "extra": extra or {}}, tmp)
         os.replace(tmp, os.path.join(self.model_dir, name + ".pt"))
         names = [n for n in self.all_checkpoints() if n != name] + [name]
         for old in names[:-self.keep_max]:
@@ -90,11 +92,16 @@ class CheckpointManager:
         logger.info("saved checkpoint %s", name)
         return name
 
-    def restore(self, tables) -> bool:
+    def restore(self, tables, shard=None) -> bool:
+        """`shard = (world, rank)`: the tables hold one rank's rows of a row-sharded run; checkpoints always hold
+        the whole model."""
         f = self.latest()
         if f is None:
             return False
         blob = torch.load(f, map_location="cpu", weights_only=False)
-        tables.load_state_dict(blob["tables"])
+        if shard is None:
+            tables.load_state_dict(blob["tables"])
+        else:
+            tables.load_whole_state_dict(blob["tables"], *shard)
         logger.info("restored %s (global_step %d)", f, tables.global_step)
         return True

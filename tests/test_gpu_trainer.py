@@ -185,7 +185,7 @@ def _two_rank_trainer(rank, port, argv, out_dir):
     est = estimator.Estimator(params, backend=HipBackend("cuda:0"), dist=dist, device="cuda:0")
     est.train(params["train_steps"])
     t = est.model.tables
-    torch.save({"R": t.R.cpu(), "C": t.C.cpu(), "br": t.br.cpu(), "bc": t.bc.cpu(), "g": t.global_bias,
+    torch.save({"R": t.embeddings("R").cpu(), "C": t.embeddings("C").cpu(), "br": t.br.cpu(), "bc": t.bc.cpu(), "g": t.global_bias,
                 "step": t.global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -309,3 +309,35 @@ def test_cli_with_full_epoch_shuffle(hip, tmp_path):
     assert log[-1]["global_step"] == 150 and log[-1]["loss"] < log[0]["loss"]
     assert all(b["global_step"] - a["global_step"] < 50 for a, b in zip(log, log[1:]))     # a line per crossed multiple of --log-every
     assert (job / "model.ckpt-150.pt").exists()
+
+
+def test_two_rank_row_sharded_trainer_on_one_gpu(hip, tmp_path):
+    """--row-sharded (BASELINE config 5) end to end with two ranks on the box's one GPU (gloo transport): every
+    nonzero is routed to the owner of its row, the row side trains locally, the col side through one all-reduce;
+    the checkpoint rank 0 writes holds the WHOLE model again, and a single process can resume / export from it."""
+    import torch.multiprocessing as mp
+    from trainer import estimator, export_embeddings
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "24", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "48",
+            "--train-steps", "60", "--log-every", "20", "--seed", "9", "--row-sharded"]
+    mp.spawn(_two_rank_trainer, args=(29900 + os.getpid() % 90, argv, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
+    V = len(vocab.read_text().split("\n"))
+    assert a["R"].shape[0] + b["R"].shape[0] == V and a["R"].shape[0] == (V + 1) // 2      # disjoint row shards
+    assert torch.equal(a["C"], b["C"]) and torch.equal(a["bc"], b["bc"]) and a["g"] == b["g"]   # replicated col side
+    log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+    assert [r["global_step"] for r in log] == [20, 40, 60] and log[-1]["loss"] < log[0]["loss"]
+    # the checkpoint is a whole-model checkpoint: rows interleave back (row u on rank u % 2 at index u // 2)
+    blob = torch.load(job / "model.ckpt-60.pt", weights_only=False)["tables"]
+    assert blob["R"].shape == (V, 24) and blob["V_row"] == V
+    assert torch.equal(blob["R"][0::2], a["R"]) and torch.equal(blob["R"][1::2], b["R"])
+    assert torch.equal(blob["br"][1::2], b["br"]) and torch.equal(blob["C"], a["C"])
+    out = tmp_path / "embeddings.json"
+    export_embeddings.main(job_dir=str(job), embeddings_json=str(out))      # one process, whole model
+    emb = json.loads(out.read_text())
+    assert len(emb["the"]["item_embedding"]) == 24
+    # a single process resumes from it as an ordinary (unsharded) run
+    estimator.main([x for x in argv if x != "--row-sharded"][:-6] + ["--train-steps", "70", "--log-every", "10", "--seed", "9"])
+    assert (job / "model.ckpt-70.pt").exists()
