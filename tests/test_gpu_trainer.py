@@ -249,15 +249,15 @@ def test_non_finite_loss_stops_training(hip, tmp_path):
         estimator.main(argv)
 
 
-@pytest.mark.parametrize("optimizer,lr", [("Adagrad", 0.05), ("Adam", 0.001)])
-def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr):
+@pytest.mark.parametrize("optimizer,lr,B", [("Adagrad", 0.05, 256), ("Adam", 0.001, 256), ("Adagrad", 0.05, 5000)])
+def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B):
     """--epoch-shuffle full: cached hipGraphs of prefetched index builds + steps, replayed over re-permuted
     buffers, give bit for bit what building and stepping batch after batch gives, across epoch boundaries."""
     from trainer import synthetic
     from trainer.data_utils import NonzeroStream
     from trainer.hip_api import DeviceTables, make_hyper
     from trainer.stepper import HipBackend, ReshufflingRunner
-    V, d, B = 300, 32, 256
+    V, d = 300, 32                                           # B = 5000: the tiled (multi-launch) index builder on the side streams
     row, col, w, y = synthetic.text8_shaped(V=V, n_tokens=60_000, seed=2)
     coo = dict(row=row.numpy(), col=col.numpy(), w=w.numpy(), y=y.numpy())
     backend = HipBackend("cuda:0")
