@@ -409,6 +409,47 @@ def test_randomized_step_parity(hip, seed):
     assert_tables_close(dt, t, PARAM_RTOL * c["steps"], PARAM_ATOL * c["steps"])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GLOVE_FUZZ_CASES", "40"))))
+def test_randomized_forms_agree_bitwise(hip, seed):
+    """The same random step through the two forms the product has of it must give the same bits: Adagrad sparse
+    apply vs dense gradient + dense apply (the data-parallel form), Adam through glove_step_adam_f32 (two-launch
+    form for small batches) vs passes + dense gradient + dense sweep."""
+    from trainer.hip_api import DeviceTables
+    c = _random_case(50000 + seed)
+    y = np.abs(c["y"]).astype(np.float32) if c["head"] else c["y"]
+    hp = ref.Hyper(learning_rate=0.05 if c["optimizer"] == "Adagrad" else 0.001, head=c["head"], neg_factor=c["nf"])
+    t = oracle_tables(c["V"], c["d"], c["optimizer"], seed=seed)
+    if c["optimizer"] == "Adam":                           # mid-run slots, so that decay of untouched rows shows
+        rng = np.random.default_rng(seed)
+        for n in ("R", "C", "br", "bc"):
+            setattr(t, "M_" + n, rng.normal(0, 1e-3, getattr(t, n).shape).astype(np.float32).astype(np.float64))
+            setattr(t, "V_" + n, rng.uniform(0, 1e-5, getattr(t, n).shape).astype(np.float32).astype(np.float64))
+        t.step = int(rng.integers(0, 1000))
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    plan = hip.build_plan(*to_dev(c["row"], c["col"], c["w"], y), c["V"], chunk_cap=c["cap"])
+    h = _hyper(hp, c["B"])
+    Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
+    for _ in range(c["steps"]):
+        if c["optimizer"] == "Adagrad":
+            hip.step_adagrad(plan, a, h)
+            hip.passes(plan, b, h)
+            hip.dense_grad(plan, b, h, Gb)
+            hip.dense_adagrad(b, h, Gb)
+        else:
+            hip.step_adam(plan, a, h, Ga)
+            hip.passes(plan, b, h)
+            hip.dense_grad(plan, b, h, Gb)
+            hip.dense_adam(b, h, Gb)
+    info = str({k: c[k] for k in ("V", "B", "d", "cap", "optimizer", "head", "steps")})
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n + " " + info
+        assert torch.equal(a.s1[n], b.s1[n]), "slot1 " + n + " " + info
+        if n in a.s2:
+            assert torch.equal(a.s2[n], b.s2[n]), "slot2 " + n + " " + info
+    assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step, info
+    assert float(Ga.abs().max()) == 0.0 and float(Gb.abs().max()) == 0.0, info
+
+
 def test_step_is_bitwise_repeatable(hip):
     from trainer.hip_api import DeviceTables
     B, V, d = 20000, 500, 64
