@@ -572,14 +572,15 @@ def test_argument_errors_are_reported_not_swallowed(hip):
         hip.build_plan(*[a.cpu() for a in to_dev(row, col, w, y)], 10)
 
 
-def test_row_sharded_pieces_on_one_gpu(hip):
+@pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 77, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8)])
+def test_row_sharded_pieces_on_one_gpu(hip, B, V, d, W):
     """BASELINE config 5 kernels on one GPU: two virtual ranks, each with half of the row table (V_row < V, local
     row ids) and a replica of the col table; the col halves of their gradient buffers are summed by hand where
     the all-reduce would run.  Result == oracle step on the union batch; and with a single shard the mixed
     form (row side sparse, col side dense) is bit-identical to the plain sparse step."""
     from trainer.hip_api import DeviceTables, make_hyper
     from trainer.stepper import owned_rows
-    B, V, d, W = 3000, 101, 64, 2                       # odd V: unequal shards, unaligned bias sections
+    # odd V: unequal shards, unaligned bias sections; d = 50: padded rows; W up to 8 virtual ranks
     hp = ref.Hyper(learning_rate=0.05)
     t = oracle_tables(V, d, "Adagrad")
     full = tables_from_oracle(t, DeviceTables)
@@ -592,7 +593,7 @@ def test_row_sharded_pieces_on_one_gpu(hip):
         dt = DeviceTables(V, d, "Adagrad", seed=0, V_row=owned_rows(V, W, r))
         assert dt.R.shape[0] == len(rows)
         idx = torch.from_numpy(rows).cuda()
-        dt.R.copy_(full.R[idx]); dt.br.copy_(full.br[idx]); dt.s1["R"].copy_(full.s1["R"][idx]); dt.s1["br"].copy_(full.s1["br"][idx])
+        dt.R.copy_(full.R[idx]); dt.br.copy_(full.br[idx]); dt.s1["R"].copy_(full.s1["R"][idx]); dt.s1["br"].copy_(full.s1["br"][idx])   # padded widths agree
         dt.C.copy_(full.C); dt.bc.copy_(full.bc); dt.s1["C"].copy_(full.s1["C"]); dt.s1["bc"].copy_(full.s1["bc"])
         dt.scalars.copy_(full.scalars)
         mine = joint[0] % W == r                         # route the union batch by row owner
@@ -605,7 +606,7 @@ def test_row_sharded_pieces_on_one_gpu(hip):
     lay = hip.grad_layout(ranks[0][0])
     assert lay["G_C"] % 4 == 0 and lay["tail"] % 4 == 0
     assert float(ranks[0][1][:lay["G_C"]].abs().max()) == 0.0           # sides = 2 left the row half untouched
-    total = ranks[0][1][lay["G_C"]:] + ranks[1][1][hip.grad_layout(ranks[1][0])["G_C"]:]   # the "all-reduce"
+    total = sum(G[hip.grad_layout(dt)["G_C"]:] for dt, G, _ in ranks)            # the "all-reduce"
     loss_out = torch.zeros(4, device="cuda:0")
     for dt, G, _ in ranks:
         G[hip.grad_layout(dt)["G_C"]:] = total
@@ -614,10 +615,10 @@ def test_row_sharded_pieces_on_one_gpu(hip):
     loss, L, reg = ref.train_step(t, *joint, hp)
     np.testing.assert_allclose(loss_out.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
     for dt, _, rows in ranks:
-        np.testing.assert_allclose(dt.R.cpu().numpy(), t.R[rows], rtol=PARAM_RTOL, atol=PARAM_ATOL)
+        np.testing.assert_allclose(dt.embeddings("R").cpu().numpy(), t.R[rows], rtol=PARAM_RTOL, atol=PARAM_ATOL)
         np.testing.assert_allclose(dt.br.cpu().numpy(), t.br[rows], rtol=PARAM_RTOL, atol=PARAM_ATOL)
-        np.testing.assert_allclose(dt.s1["R"].cpu().numpy(), t.A_R[rows], rtol=PARAM_RTOL, atol=PARAM_ATOL)
-        np.testing.assert_allclose(dt.C.cpu().numpy(), t.C, rtol=PARAM_RTOL, atol=PARAM_ATOL)
+        np.testing.assert_allclose(dt.s1["R"][:, :d].cpu().numpy(), t.A_R[rows], rtol=PARAM_RTOL, atol=PARAM_ATOL)
+        np.testing.assert_allclose(dt.embeddings("C").cpu().numpy(), t.C, rtol=PARAM_RTOL, atol=PARAM_ATOL)
         np.testing.assert_allclose(dt.bc.cpu().numpy(), t.bc, rtol=PARAM_RTOL, atol=PARAM_ATOL)
         np.testing.assert_allclose(dt.scalars[0].item(), t.g, rtol=PARAM_RTOL, atol=PARAM_ATOL)
     assert torch.equal(ranks[0][0].C, ranks[1][0].C)
