@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
+    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches")
+    ap.add_argument("--single", action="store_true", help="only the named workload (no configs[] array)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
                          "collectives go through gloo; its numbers mean nothing")
@@ -207,7 +209,7 @@ def main():
     chunks = sum(c[0] + c[2] for c in counts) / nb
 
     tables = DeviceTables(V, d, args.optimizer, device=dev, seed=1, V_row=V_row)      # identical replicas on every rank
-    hyper = make_hyper(learning_rate=args.learning_rate, batch_size=B * world)
+    hyper = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, step_form=args.step_form)
     ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
                      else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     loss_out = torch.zeros(4, device=dev)

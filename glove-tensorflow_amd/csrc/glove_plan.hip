@@ -277,6 +277,7 @@ __global__ void emit_uniq_rec(const int32_t *__restrict__ counts, UniqRecArgs a,
 
 // per-chunk records of both sides (blockIdx.y = side): one thread per (chunk, float4 of the record)
 struct RecordArgs {
+    const int32_t *uniq_slot[2];
     const int32_t *chunk_id[2], *chunk_start[2], *partner[2];
     const float *w[2], *y[2];
     int32_t *crec[2];
@@ -294,7 +295,17 @@ __global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, i
         const int s = chunk_start[j], n = chunk_start[j + 1] - s;
         int4 v;
         if (f == 0) {
-            v = make_int4(chunk_id[j], n, s, 0);
+            // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
+            // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
+            const int32_t id = chunk_id[j];
+            const int32_t *slot = a.uniq_slot[side];
+            int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (slot[mid] <= j) lo = mid; else hi = mid;
+            }
+            const uint32_t rem = (uint32_t)(slot[lo + 1] - 1 - j);
+            v = make_int4(id, n, s, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
         } else {
             const int field = (f - 1) / (capP / 4), t0 = ((f - 1) % (capP / 4)) * 4;
             int o[4];
@@ -313,7 +324,7 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 {
     const int capP = (plan->chunk_cap + 7) & ~7;      // a trip of the pass kernel reads up to 8 slots from q0
     const int64_t work = (int64_t)plan->cap_chunks * (1 + 3 * capP / 4);
-    const RecordArgs a = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+    const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                           {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
                           {plan->r_crec, plan->c_crec}};
     hipLaunchKernelGGL(fill_records, dim3(blocks_for(work, kBlock), 2), dim3(kBlock), 0, st,
@@ -455,6 +466,7 @@ int glove_plan_fill_records(const glove_plan *plan, void *stream)
 {
     if (!plan || !plan->r_crec || !plan->c_crec || !plan->counts || plan->chunk_cap <= 0) return GLOVE_E_BADARG;
     if (plan->B == 0) return 0;
+    if (!plan->r_uniq_slot || !plan->c_uniq_slot) return GLOVE_E_BADARG;
     if (!plan->r_chunk_id || !plan->r_chunk_start || !plan->r_partner || !plan->r_w || !plan->r_y || !plan->c_chunk_id ||
         !plan->c_chunk_start || !plan->c_partner || !plan->c_w || !plan->c_y)
         return GLOVE_E_BADARG;

@@ -166,15 +166,36 @@ struct PassSide {
     int n_host;                    // chunks of this side if known on the host, else -1
     int count_index;               // counts[0] (row) or counts[2] (col)
     float *mark;                   // if not null: mark[id] = 1 for every id of this side (fused Adam step)
-    const int32_t *crec;           // per-chunk records {id, n, 0, 0 | partner | w | y} or nullptr
+    const int32_t *crec;           // per-chunk records {id, n, first pair, only chunk of its id | partner | w | y} or nullptr
     int capP;                      // chunk_cap rounded up to a multiple of 8 (record field length)
+    // fused Adagrad apply (FUSE kernels): a chunk that is its id's ONLY chunk holds the id's whole gradient in
+    // registers, next to the id's own row, so the update is formed here instead of travelling through a partial
+    // row: the accumulator is updated in place (nobody else reads it), the new row goes
+    //   fuse == kFuseInPlace  into the table (only legal when no concurrent work reads this side's table as partner
+    //                         rows: the col side in a launch of its own, after the row side)
+    //   fuse == kFuseSlot     into the chunk's partial-row slot (gp / gb), from where the apply kernel copies it
+    //                         into the table once every pass that gathers the old rows has finished
+    // fuse == kFuseNone: every chunk stores its partial sums (the apply / dense-gradient kernels do the rest)
+    int fuse;
+    float *own_out, *own_bias_out; // this side's table / bias vector, written by kFuseInPlace
+    float *S1, *S1b;               // this side's Adagrad accumulators
 };
 
-template <int LPR, int NV, bool FULL, bool REC>
-__global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel(
+constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2;
+
+struct StepConsts {
+    float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
+    float lr, eps;
+    float l2, m, inv_batch, inv_d;
+};
+
+// FUSE kernels keep the accumulator row of a run in registers as well: held to 3 waves per SIMD (168 VGPRs), which the
+// d = 300 shape misses by one register otherwise
+template <int LPR, int NV, bool FULL, bool REC, bool FUSE>
+__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
-    float *__restrict__ blockpart, int head, float neg_factor)
+    float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per)
 {
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
@@ -201,11 +222,32 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
     // [2] sum b^2, [3] sum e
     float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int j = bid * GPB + grp; j < n_chunks; j += nblk * GPB) {
-        int32_t u;
-        int s = 0, n;
+    // Chunk schedule.
+    //   classic: group (bid, grp) takes chunks bid*GPB+grp, += nblk*GPB; every chunk stores its own partial row.
+    //   FUSE:    group number gq = bid*GPB+grp owns the `per` CONSECUTIVE chunks [gq*per, (gq+1)*per).  Chunks are sorted
+    //            by id, so the group meets its ids as runs of consecutive chunks: the own row is loaded once per run, the
+    //            gradient keeps accumulating in registers across the run's chunks (pairs in plan order), and a run that
+    //            holds ALL chunks of its id is applied right here (sd.fuse); any other run stores ONE partial row, in the
+    //            slot of its first chunk.  The apply kernel derives the same runs from (first chunk, chunks, per).
+    int j = FUSE ? (bid * GPB + grp) * per : bid * GPB + grp;
+    const int j_end = FUSE ? (j + per < n_chunks ? j + per : n_chunks) : n_chunks;
+    const int j_step = FUSE ? 1 : nblk * GPB;
+    int32_t cur_u = -1;
+    int run_first = 0, run_pairs = 0;
+    bool run_whole = false;
+    f4 r[NV], acc[NV], A[NV];
+    float own_b = 0.f, bg = 0.f, Ab = 0.f, se = 0.f;
+    (void)A; (void)Ab;
+
+    bool pending = false;                   // FUSE: a run whose sums are still in registers
+    for (;; j += j_step) {
+        const bool have = j < j_end;
+        int32_t u = -1;
+        int s = 0, n = 0;
+        uint32_t hw = 0;                    // record header word 3: (first chunk of its id) << 31 | chunks of the id after this one
         const int capP = sd.capP;
-        if (REC) {
+        if (!have) {
+        } else if (REC) {
             // ONE round trip: the whole record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
             const int rq = 1 + 3 * capP / 4;
             const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rq;
@@ -215,6 +257,7 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
             u = (int32_t)hdr.x;
             n = (int)hdr.y;
             s = (int)hdr.z;
+            hw = hdr.w;
             GLOVE_DRAIN(); GLOVE_STAMP(1);
         } else {
             u = sd.chunk_id[j];
@@ -235,12 +278,56 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
                 }
             }
         }
-        f4 r[NV], acc[NV];
-        load_row<LPR, NV>(r, sd.own, u, d4, lg);
-        const float bg = sd.own_bias[u] + g;
+        const bool new_run = !FUSE || !pending || u != cur_u;
+        if (FUSE && pending && (!have || new_run)) {        // the run in registers is complete
+            pending = false;
+            if (FUSE && run_whole) {
+                // the id's whole gradient is here: G = sum + activity-L2 term, then Adagrad (the arithmetic of
+                // for_each_id + AdagradApply; on an id with a single chunk expression for expression, bit-identical)
+                const float cnt = (float)run_pairs;
+                const float kcn = kc.kappa * cnt;
+                float bval = own_b, Gb = se;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
-        float se = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
+                for (int k = 0; k < NV; ++k) acc[k] += kcn * r[k];
+                Gb += kc.kappa_b * cnt * bval;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], acc[k], kc.lr, kc.eps);
+                store_row<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
+                const bool in_place = sd.fuse == kFuseInPlace;
+                store_row<LPR, NV>(in_place ? sd.own_out : sd.gp, in_place ? (size_t)cur_u : (size_t)run_first, d4, lg, r);
+                if (lg == 0) {
+                    adagrad_elem(bval, Ab, Gb, kc.lr, kc.eps);
+                    sd.S1b[cur_u] = Ab;
+                    if (in_place) sd.own_bias_out[cur_u] = bval; else sd.gb[run_first] = bval;
+                }
+            } else {
+                store_row<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
+                if (lg == 0) {
+                    sd.gb[run_first] = se;
+                    if (sd.mark) sd.mark[cur_u] = 1.0f;
+                }
+            }
+        }
+        if (!have) break;
+        if (new_run) {
+            cur_u = u;
+            run_first = j;
+            run_pairs = 0;
+            load_row<LPR, NV>(r, sd.own, u, d4, lg);
+            own_b = sd.own_bias[u];
+            bg = own_b + g;
+            // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
+            run_whole = FUSE && sd.fuse != kFuseNone && (hw >> 31) != 0 && j + (int)(hw & 0x7fffffffu) < j_end;
+            if (FUSE && run_whole) {            // requested with the own row: arrives under the partner-row trips
+                load_row<LPR, NV>(A, sd.S1, u, d4, lg);
+                Ab = sd.S1b[u];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+            se = 0.f;
+        }
+        run_pairs += n;
+        float se_c = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
         GLOVE_DRAIN(); GLOVE_STAMP(2);      // pair fields staged, own row arrived
         // fields written by this wave's own lanes: LDS ops of one wave complete in order
 
@@ -318,7 +405,7 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
                 }
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
-                se += e;
+                se_c += e;
                 cc_sum += valid * cc[a];
                 bsq += valid * bcv[a] * bcv[a];
                 ev[a] = e;
@@ -336,21 +423,25 @@ __global__ __launch_bounds__(kBlock, PassWaves<LPR>::value) void sidepass_kernel
             }
         }
         GLOVE_STAMP(3);                     // all partner-row trips issued and consumed
-        store_row<LPR, NV>(sd.gp, (size_t)j, d4, lg, acc);
-        if (lg == 0) {
-            sd.gb[j] = se;
-            if (sd.mark) sd.mark[u] = 1.0f;
-        }
+        se += se_c;
         if (is_row) {
             float rr = 0.f;
 #pragma unroll
             for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
             part[1] += cc_sum + (float)n * rr;
             if (lg == 0) {
-                const float bru = bg - g;
                 part[0] += ed;
-                part[2] += bsq + (float)n * bru * bru;
-                part[3] += se;
+                part[2] += bsq + (float)n * own_b * own_b;
+                part[3] += se_c;
+            }
+        }
+        if (FUSE) {
+            pending = true;
+        } else {
+            store_row<LPR, NV>(sd.gp, (size_t)j, d4, lg, acc);
+            if (lg == 0) {
+                sd.gb[j] = se;
+                if (sd.mark) sd.mark[u] = 1.0f;
             }
         }
     }
@@ -383,34 +474,42 @@ struct IdWork {
     int heavy_blocks;           // leading blocks of the grid reserved for heavy ids
     int heavy_chunks;           // threshold
     int sides;                  // 1 = rows only, 2 = cols only, 3 = both
+    int pre_r, pre_c;           // what a FUSE pass already did for the ids one run held completely (kFuse*), per side
+    int per;                    // consecutive chunks per group of that FUSE pass
 };
 
-struct StepConsts {
-    float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
-    float lr, eps;
-    float l2, m, inv_batch, inv_d;
+// The partial rows of one id.  Classic passes: one per chunk, slots f .. f+n-1 (per == 1).  FUSE passes: one per run, a
+// run being the id's chunks inside one group's range of `per` consecutive chunks: the k-th run starts at the id's
+// first chunk (k == 0) or at the k-th multiple of `per` behind it.
+struct Slots {
+    int f, per, count;
+    __device__ Slots(int first_chunk, int chunks, int per_) : f(first_chunk), per(per_)
+    {
+        count = 1 + (first_chunk + chunks - 1) / per_ - first_chunk / per_;
+    }
+    __device__ int at(int k) const { return k == 0 ? f : (f / per + k) * per; }
 };
 
-// G += partial rows first, first+stride, ... (< last), PB loads in flight at a time, added in order
+// G += partial rows k0, k0+stride, ... (< sl.count), PB loads in flight at a time, added in order
 template <int LPR, int NV, int PB = 4>
-__device__ inline void sum_partials(const SideBufs &sb, int first, int last, int stride, int d4, int lg,
+__device__ inline void sum_partials(const SideBufs &sb, const Slots &sl, int k0, int stride, int d4, int lg,
                                     f4 (&G)[NV], float &Gb)
 {
-    for (int sl = first; sl < last; sl += stride * PB) {
+    for (int k = k0; k < sl.count; k += stride * PB) {
         f4 p[PB][NV];
         float pbias[PB];
 #pragma unroll
         for (int a = 0; a < PB; ++a) {
-            const int x = sl + a * stride;
-            const int xs = x < last ? x : first;
+            const int x = k + a * stride;
+            const int xs = sl.at(x < sl.count ? x : 0);
             load_row<LPR, NV>(p[a], sb.gp, xs, d4, lg);
             pbias[a] = sb.gb[xs];
         }
 #pragma unroll
         for (int a = 0; a < PB; ++a) {
-            const float on = (sl + a * stride < last) ? 1.0f : 0.f;
+            const float on = (k + a * stride < sl.count) ? 1.0f : 0.f;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) G[k] += on * p[a][k];
+            for (int kk = 0; kk < NV; ++kk) G[kk] += on * p[a][kk];
             Gb += on * pbias[a];
         }
     }
@@ -444,8 +543,19 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         if (!(wk.sides & (is_row ? 1 : 2))) return false;
         const SideBufs &sb = is_row ? rs : cs;
         const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[code & 0x3fffffff];
-        const int sl0 = rec.y, sl1 = rec.y + rec.z;
         const int32_t id = rec.x;
+        const int pre = is_row ? wk.pre_r : wk.pre_c;
+        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1);
+        if (pre != kFuseNone && sl.count == 1) {       // one run held the whole id: the pass kernel applied it
+            if (pre == kFuseSlot && grp == 0) {
+                f4 Wn[NV];
+                load_row<LPR, NV>(Wn, sb.gp, sl.f, d4, lg);
+                const float bn = sb.gb[sl.f];
+                store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
+                if (lg == 0) sb.bias[id] = bn;
+            }
+            return false;
+        }
         f4 G[NV], Wv[NV];
         typename F::State st;
         float Gb = 0.f, bval = 0.f;
@@ -458,7 +568,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         }
         // a heavy id is the longest dependent chain of the launch (the head of a Zipf batch: ~50 rows per group):
         // four rows in flight per trip at every row width (16 cost the d = 64 shape its occupancy: 8.4 -> 9.3 us)
-        sum_partials<LPR, NV, 4>(sb, sl0 + grp, sl1, GPB, d4, lg, G, Gb);
+        sum_partials<LPR, NV, 4>(sb, sl, grp, GPB, d4, lg, G, Gb);
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) red[grp][lg + kk * LPR] = G[kk];
         if (lg == 0) redb[grp] = Gb;
@@ -494,8 +604,23 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[qq];   // {id, first chunk, chunks, pairs}
         if (rec.z > wk.heavy_chunks) continue;                               // a heavy block has it
         GLOVE_DRAIN(); GLOVE_STAMP(1);      // record arrived
-        const int sl0 = rec.y, sl1 = rec.y + rec.z;
         const int32_t id = rec.x;
+        const int pre = is_row ? wk.pre_r : wk.pre_c;
+        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1);
+        const int sl0 = sl.f;
+        if (pre != kFuseNone && sl.count == 1) {
+            // one run held the whole id and the pass kernel already applied it (sidepass_kernel FUSE): in place ->
+            // nothing left to do; into its slot -> move the finished row and bias into the table now that no pass
+            // reads the old ones
+            if (pre == kFuseSlot) {
+                f4 Wn[NV];
+                load_row<LPR, NV>(Wn, sb.gp, sl0, d4, lg);
+                const float bn = sb.gb[sl0];
+                store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
+                if (lg == 0) sb.bias[id] = bn;
+            }
+            continue;
+        }
         const float cnt = (float)rec.w;
         f4 G[NV], Wv[NV];
         typename F::State st;
@@ -504,7 +629,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
         const float bval = sb.bias[id];
         fn.prefetch(is_row, id, st);
-        sum_partials<LPR, NV>(sb, sl0 + 1, sl1, 1, d4, lg, G, Gb);
+        sum_partials<LPR, NV>(sb, sl, 1, 1, d4, lg, G, Gb);
         const float kc = k.kappa * cnt;
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
@@ -903,6 +1028,8 @@ static IdWork id_work(const glove_plan *p)
     w.heavy_blocks = p->host_counts[4] >= 0 ? p->host_counts[4] : p->cap_heavy;
     w.heavy_chunks = p->heavy_chunks;
     w.sides = 3;
+    w.pre_r = w.pre_c = kFuseNone;
+    w.per = 1;
     return w;
 }
 
@@ -922,6 +1049,24 @@ static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
 }
 
 static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_for(p->cap_chunks, kBlock / lpr); }
+
+// FUSE passes: consecutive chunks per lane group.  At least 4 (a heavy id then leaves one partial row per 4 chunks
+// instead of one per chunk, and an id of up to 4 chunks is usually applied by the pass itself; 1 ... 8 measured alike at
+// V = 400 k, d = 300, 16 and 32 slower: fewer, longer-running groups), more when the plan has more chunks than
+// kMaxBlocks workgroups of such groups cover (the loss partials are kept per workgroup).  GLOVE_FUSE_PER overrides
+// the minimum (experiments).
+static int fuse_per(const glove_plan *p, int lpr)
+{
+    static const int floor_ = [] { const char *e = getenv("GLOVE_FUSE_PER"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    const int64_t groups = (int64_t)kMaxBlocks * (kBlock / lpr);
+    const int need = (int)((p->cap_chunks + groups - 1) / groups);
+    return need > floor_ ? need : floor_;
+}
+static inline int fusepass_blocks(const glove_plan *p, int lpr, int per, bool row)
+{
+    const int n = p->host_counts[row ? 0 : 2] >= 0 ? p->host_counts[row ? 0 : 2] : p->cap_chunks;
+    return blocks_for(n, per * (kBlock / lpr));
+}
 
 static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tables *t, bool row)
 {
@@ -962,7 +1107,8 @@ size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *off
     return (size_t)L.total;
 }
 
-static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row, bool want_e = false)
+static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row, bool want_e = false,
+                          int fuse = kFuseNone)
 {
     PassSide sd;
     sd.partner = row ? p->r_partner : p->c_partner;
@@ -982,34 +1128,51 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.count_index = row ? 0 : 2;
     sd.crec = row ? p->r_crec : p->c_crec;
     sd.capP = (p->chunk_cap + 7) & ~7;
+    sd.fuse = fuse;
+    sd.own_out = row ? t->R : t->C;
+    sd.own_bias_out = row ? t->br : t->bc;
+    sd.S1 = row ? t->s1_R : t->s1_C;
+    sd.S1b = row ? t->s1_br : t->s1_bc;
     return sd;
 }
 
 // which: 1 = row side, 2 = col side, 3 = both in one launch
 static int launch_passes(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
-                         void *stream, int which, float *mark_rows = nullptr, float *mark_cols = nullptr)
+                         void *stream, int which, float *mark_rows = nullptr, float *mark_cols = nullptr,
+                         bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
+    const bool fuse = fuse_r != kFuseNone || fuse_c != kFuseNone;
+    if (fuse && (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc)) return GLOVE_E_BADARG;
+    // in place is only legal for a side whose table no concurrent chunk gathers from: one side per launch
+    if ((fuse_r == kFuseInPlace && (which & 2)) || (fuse_c == kFuseInPlace && (which & 1))) return GLOVE_E_BADARG;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     const int d4 = t->d / 4;
     const RowShape shape = pass_shape(d4);
-    const int nb_side = rowpass_blocks(p, shape.lpr);
-    const int row_blocks = (which & 1) ? nb_side : 0;
-    const int nb = row_blocks + ((which & 2) ? nb_side : 0);
-    PassSide rs = pass_side(p, t, w, true, which == 1), cs = pass_side(p, t, w, false);
+    const int per = fuse ? fuse_per(p, shape.lpr) : 1;
+    const int row_blocks = !(which & 1) ? 0 : fuse ? fusepass_blocks(p, shape.lpr, per, true) : rowpass_blocks(p, shape.lpr);
+    const int nb = row_blocks + (!(which & 2) ? 0 : fuse ? fusepass_blocks(p, shape.lpr, per, false) : rowpass_blocks(p, shape.lpr));
+    PassSide rs = pass_side(p, t, w, true, want_e, fuse_r), cs = pass_side(p, t, w, false, false, fuse_c);
     rs.mark = mark_rows;
     cs.mark = mark_cols;
+    const StepConsts kc = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor
+#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;
-#define CALL(LPR, NV)                                                                                          \
-    if (LPR * NV == d4 && rec) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else if (LPR * NV == d4) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, true, false>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else if (rec) hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false, true>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
-    else hipLaunchKernelGGL((sidepass_kernel<LPR, NV, false, false>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+#define LAUNCH(LPR, NV, FULL, REC, FUSE) \
+    hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+#define CALL(LPR, NV)                                                                   \
+    if (LPR * NV == d4) {                                                               \
+        if (rec) { if (fuse) LAUNCH(LPR, NV, true, true, true); else LAUNCH(LPR, NV, true, true, false); }      \
+        else { if (fuse) LAUNCH(LPR, NV, true, false, true); else LAUNCH(LPR, NV, true, false, false); }        \
+    } else {                                                                            \
+        if (rec) { if (fuse) LAUNCH(LPR, NV, false, true, true); else LAUNCH(LPR, NV, false, true, false); }    \
+        else { if (fuse) LAUNCH(LPR, NV, false, false, true); else LAUNCH(LPR, NV, false, false, false); }      \
+    }
     GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
+#undef LAUNCH
 #undef ARGS
     return (int)hipGetLastError();
 }
@@ -1023,7 +1186,7 @@ int glove_passes_f32(const glove_plan *p, const glove_tables *t, const glove_hyp
 int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                       void *stream)
 {
-    return launch_passes(p, t, h, ws, ws_bytes, stream, 1);
+    return launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, true);
 }
 
 int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
@@ -1032,8 +1195,8 @@ int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
     return launch_passes(p, t, h, ws, ws_bytes, stream, 2);
 }
 
-int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
-                            size_t ws_bytes, float *loss_out, void *stream)
+static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
+                                size_t ws_bytes, float *loss_out, void *stream, int pre_r, int pre_c)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
@@ -1043,8 +1206,13 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     const RowShape shape = pick_row_shape(d4);
     IdWork wk = id_work(p);
     wk.sides = sides_of(h);
+    wk.pre_r = pre_r;
+    wk.pre_c = pre_c;
+    const bool fused = pre_r != kFuseNone || pre_c != kFuseNone;
+    wk.per = fused ? fuse_per(p, pass_shape(d4).lpr) : 1;
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
-    const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
+    // workgroups of the row-side pass, whose loss partials the scalar duty sums (the first launch of the step)
+    const int nb_row = fused ? fusepass_blocks(p, pass_shape(d4).lpr, wk.per, true) : rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     hipStream_t st = (hipStream_t)stream;
@@ -1054,6 +1222,12 @@ int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const gl
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();
+}
+
+int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
+                            size_t ws_bytes, float *loss_out, void *stream)
+{
+    return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseNone, kFuseNone);
 }
 
 int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
@@ -1128,9 +1302,39 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
     return (int)hipGetLastError();
 }
 
+// Which form a sparse Adagrad step takes (glove_hyper.step_form; see include/glove_hip.h).
+static int pick_step_form(const glove_plan *p, const glove_tables *t, const glove_hyper *h)
+{
+    if (!p || !t || !h) return GLOVE_STEP_TWO_LAUNCH;
+    if (sides_of(h) != 3) return GLOVE_STEP_TWO_LAUNCH;
+    if (!p->r_crec || !p->c_crec) return GLOVE_STEP_TWO_LAUNCH;      // the fused forms read the id layout from the chunk records
+    if (h->step_form != GLOVE_STEP_AUTO) return h->step_form;
+    // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
+    // are only known on the host for a plan whose build has been synchronised (a resident plan)
+    const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
+    return ids * t->d * 16 >= ((int64_t)128 << 20) ? GLOVE_STEP_FUSED_THREE_LAUNCH : GLOVE_STEP_TWO_LAUNCH;
+}
+
 int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                            float *loss_out, void *stream)
 {
+    switch (pick_step_form(p, t, h)) {
+    case GLOVE_STEP_FUSED_ONE_PASS:
+        // both sides in one launch: neither table may change under the other side's gathers, so both put their
+        // finished rows into the slots and the apply launch moves them
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3, nullptr, nullptr, false, kFuseSlot, kFuseSlot)) return rc;
+        return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseSlot, kFuseSlot);
+    case GLOVE_STEP_FUSED_THREE_LAUNCH:
+        // row side first (C is read only); then the col side alone may update C in place while it gathers the
+        // still unchanged R; the apply launch moves the row side's finished rows and does the multi-chunk ids
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, false, kFuseSlot, kFuseNone)) return rc;
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 2, nullptr, nullptr, false, kFuseNone, kFuseInPlace)) return rc;
+        return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseSlot, kFuseInPlace);
+    case GLOVE_STEP_TWO_LAUNCH:
+        break;
+    default:
+        return GLOVE_E_BADARG;
+    }
     if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
     return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
 }
@@ -1139,11 +1343,8 @@ int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glo
                             void *ws, size_t ws_bytes, float *loss_out, void *stream)
 {
     if (!plans || n < 0) return GLOVE_E_BADARG;
-    for (int32_t i = 0; i < n; ++i) {
-        if (int rc = glove_passes_f32(plans[i], t, h, ws, ws_bytes, stream)) return rc;
-        if (int rc = glove_apply_adagrad_f32(plans[i], t, h, ws, ws_bytes, i == n - 1 ? loss_out : nullptr, stream))
-            return rc;
-    }
+    for (int32_t i = 0; i < n; ++i)
+        if (int rc = glove_step_adagrad_f32(plans[i], t, h, ws, ws_bytes, i == n - 1 ? loss_out : nullptr, stream)) return rc;
     return 0;
 }
 

@@ -63,6 +63,8 @@ class Estimator:
         self.model = MatrixFactorisation(self.vocab_size, params["embedding_size"], params["l2_reg"],
                                          optimizer=self.optimizer_name, device=self.device,
                                          seed=None if seed is None else seed + 1)
+        if hasattr(self.backend, "row_floats"):
+            self.backend.row_floats = self.model.tables.d
         if self.world > 1:      # identical replicas: rank 0's init wins
             t = self.model.tables
             for buf in (t.R, t.C, t.br, t.bc):

@@ -18,18 +18,26 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 2
+GLOVE_ABI_VERSION = 3
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
+STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH = 0, 1, 2, 3      # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
 RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
-def auto_chunk_cap(B: int, V: int) -> int:
+FUSED_STEP_BYTES = 128 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
+
+
+def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
     """Chunk length used when the caller does not choose one.  Short chunks shorten the dependent
     chain of the gather passes (fewer partner-row round trips per chunk) and win while a batch holds
     few pairs per id; long chunks mean fewer partial rows and win for dense batches (bench.py --chunk-cap,
-    V = 10000: B = 131072: 8 / 16 / 24 / 32 -> 22.4 / 21.2 / 22.3 / 23.3 us per step; B = 1048576: 16 -> 59.4, 32 -> 53.8)."""
+    V = 10000: B = 131072: 8 / 16 / 24 / 32 -> 22.4 / 21.2 / 22.3 / 23.3 us per step; B = 1048576: 16 -> 59.4, 32 -> 53.8).
+    Tables far beyond the caches (`d` given: V x d x 4 B >= 256 MB) take the fused step, which is bandwidth-bound
+    and likes long chunks (V = 400 k, d = 300, B = 1 M: 8 / 16 / 32 -> 746 / 734 / 722 us per step)."""
+    if d is not None and V * d * 4 >= (256 << 20):
+        return 32
     return 16 if B <= 20 * V else 32
 
 # every symbol include/glove_hip.h declares
@@ -56,7 +64,7 @@ class GloveHyper(C.Structure):
     _fields_ = [("beta1", C.c_double), ("beta2", C.c_double),
                 ("l2_reg", C.c_float), ("reg_mult", C.c_float), ("learning_rate", C.c_float),
                 ("epsilon", C.c_float), ("inv_batch", C.c_float), ("sides", C.c_int32),
-                ("head", C.c_int32), ("neg_factor", C.c_float), ("reserved", C.c_int32)]
+                ("head", C.c_int32), ("neg_factor", C.c_float), ("step_form", C.c_int32)]
 
 
 class GlovePlan(C.Structure):
@@ -342,9 +350,10 @@ class Plan:
             self._struct = s
         return self._struct
 
-    def compact(self, lib=None) -> "Plan":
+    def compact(self, lib=None, d: int | None = None) -> "Plan":
         """Exact-size copy (one host sync): used when plans of a static stream stay resident.  With `lib`
-        (the loaded C library) the copy also gets its per-chunk records."""
+        (the loaded C library) the copy also gets its per-chunk records; `d` (floats per table row) tells whether
+        the batch is one the library steps in its fused form, which reads the id layout from the records."""
         nc_r, nu_r, nc_c, nu_c, n_heavy, n_mapped = (int(x) for x in self.counts.tolist()[:6])
         if n_mapped:
             logger.warning("%d ids outside [0, %d) were treated as id 0 (the unknown token)", n_mapped, self.V)
@@ -369,7 +378,10 @@ class Plan:
         out.r_crec = out.c_crec = None
         # records pad every chunk to the cap: worth it for the latency they save unless the chunks are nearly
         # empty (V = 400 k, B = 1 M: 2.6 pairs per 16-slot chunk -> 7 % more traffic, measured slower)
-        if lib is not None and out.B > 0 and 4 * out.B >= out.chunk_cap * max(nc_r, nc_c):
+        want = os.environ.get("GLOVE_RECORDS")          # experiments: "0" never, "1" always
+        fused = d is not None and (nu_r + nu_c) * d * 16 >= FUSED_STEP_BYTES
+        if lib is not None and out.B > 0 and want != "0" and (
+                want == "1" or fused or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)):
             n = max(out.cap_chunks, 1) * out.rec_dwords
             out.r_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
             out.c_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
@@ -382,11 +394,12 @@ class Plan:
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
-               batch_size=None, inv_batch=None, sides=0, head=HEAD_REGRESSION, neg_factor=1.0) -> GloveHyper:
+               batch_size=None, inv_batch=None, sides=0, head=HEAD_REGRESSION, neg_factor=1.0,
+               step_form=STEP_AUTO) -> GloveHyper:
     """`sides`: 0/3 both sides, 1 row side only, 2 col side only; `head`: HEAD_REGRESSION (GloVe) or
     HEAD_LOGISTIC (pos/neg logistic matrix factorisation, with `neg_factor`) — see glove_hyper in the header."""
     h = GloveHyper()
-    h.sides, h.head, h.neg_factor = sides, head, neg_factor
+    h.sides, h.head, h.neg_factor, h.step_form = sides, head, neg_factor, step_form
     h.beta1, h.beta2 = beta1, beta2
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
     h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
@@ -415,7 +428,7 @@ class GloveHip:
 
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
-                   into: Plan | None = None, ws: torch.Tensor | None = None) -> Plan:
+                   into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None) -> Plan:
         """Builds the dedup index of one batch on the device.  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
         allocations per step this way.  `ws`: scratch of glove_plan_workspace_bytes(B, V) bytes (default: one
@@ -423,7 +436,7 @@ class GloveHip:
         _require_cuda(row, col, w, y)
         B = int(row.numel())
         if not chunk_cap:
-            chunk_cap = auto_chunk_cap(B, V)
+            chunk_cap = auto_chunk_cap(B, V, d)
         if into is not None:
             if (into.B, into.V, into.chunk_cap) != (B, V, chunk_cap) or into.cap_chunks < B:
                 raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
@@ -434,7 +447,7 @@ class GloveHip:
             ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
-        return plan.compact(self.lib) if compact else plan
+        return plan.compact(self.lib, d) if compact else plan
 
     # ---- passes
     def passes(self, plan, tables, hyper, ws=None):

@@ -25,10 +25,11 @@ class HipBackend:
         from trainer.hip_api import GloveHip
         self.hip = GloveHip(device)
         self.device = torch.device(device)
+        self.row_floats = None      # floats per table row, once the tables exist: lets resident plans carry what the fused step needs
 
     def build_plan(self, row, col, w, y, V, chunk_cap):
         return self.hip.build_plan(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), V,
-                                   chunk_cap=chunk_cap, compact=True)
+                                   chunk_cap=chunk_cap, compact=True, d=self.row_floats)
 
     def make_hyper(self, **kw):
         from trainer.hip_api import make_hyper

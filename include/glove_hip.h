@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 2
+#define GLOVE_ABI_VERSION 3
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -77,11 +77,25 @@ typedef struct glove_hyper {
      * both summed over the batch and divided by the batch size. */
     int32_t head;
     float neg_factor;           /* --neg-factor; read by the logistic head only */
-    int32_t reserved;
+    /* form of glove_step_adagrad_f32 / glove_steps_adagrad_f32 (same result bit for bit in every form):
+     *   GLOVE_STEP_AUTO                the library chooses from the plan's id counts and the row width
+     *   GLOVE_STEP_TWO_LAUNCH          passes (both sides) -> apply: every chunk's sums travel through a partial row
+     *   GLOVE_STEP_FUSED_ONE_PASS      a chunk that holds ALL pairs of its id (most ids of a large vocabulary)
+     *                                  applies Adagrad itself: accumulator in place, the new row into the chunk's
+     *                                  partial-row slot; the apply launch moves those rows into the tables and
+     *                                  handles the ids with several chunks
+     *   GLOVE_STEP_FUSED_THREE_LAUNCH  row side as above, then the col side in a launch of its own, updating C and
+     *                                  bc in place (nothing reads them any more), then the apply launch */
+    int32_t step_form;
 } glove_hyper;
 
 #define GLOVE_HEAD_REGRESSION 0
 #define GLOVE_HEAD_LOGISTIC 1
+
+#define GLOVE_STEP_AUTO 0
+#define GLOVE_STEP_TWO_LAUNCH 1
+#define GLOVE_STEP_FUSED_ONE_PASS 2
+#define GLOVE_STEP_FUSED_THREE_LAUNCH 3
 
 /*
  * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,
@@ -129,7 +143,7 @@ typedef struct glove_plan {
      * them a whole workgroup that starts ahead of the per-lane-group work on the light ids. */
     int32_t *heavy;
     /* Optional per-chunk records (NULL = absent): chunk j of a side owns rec_dwords = 4 + 3*capP dwords
-     * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, first pair, 0 | partner[capP] | w[capP] |
+     * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, first pair, (1 << 31 if it is the first chunk of its id) | chunks of the same id behind it | partner[capP] | w[capP] |
      * y[capP]}, padding slots carrying weight 0.  With them the pass kernel gets a chunk's descriptor AND
      * its pair fields in ONE memory round trip (contiguous 16-B loads) instead of two dependent ones.
      * Filled by glove_plan_build when non-NULL, or later by glove_plan_fill_records for an exact-size

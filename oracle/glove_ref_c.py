@@ -19,6 +19,48 @@ class State(C.Structure):
             "G_R", "G_C", "G_br", "G_bc", "touch_r", "touch_c", "mark_r", "mark_c")]
 
 
+class SideIndexC(C.Structure):
+    _fields_ = [("n_uniq", C.c_int32), ("n_chunks", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "order", "uid", "first", "ch_lo", "ch_q")]
+
+
+class IndexC(C.Structure):
+    _fields_ = [("r", SideIndexC), ("c", SideIndexC)] + [(n, C.c_void_p) for n in ("e", "P_r", "P_c", "Pb_r", "Pb_c")]
+
+
+class BatchIndex:
+    """Grouping of one batch's pairs by row id and by col id for the all-core step (built once per resident
+    batch, outside any timed region): stable order inside an id, ids with more than `chunk` pairs cut into chunks."""
+
+    def __init__(self, row, col, d, chunk=256):
+        self.keep = []
+
+        def side(ids):
+            order = np.argsort(ids, kind="stable").astype(np.int32)
+            uid, start = np.unique(ids[order], return_index=True)
+            cnt = np.diff(np.r_[start, len(ids)])
+            nch = (cnt + chunk - 1) // chunk
+            first = np.r_[0, np.cumsum(nch)].astype(np.int32)
+            ch_q = np.repeat(np.arange(len(uid)), nch).astype(np.int32)
+            within = np.arange(int(first[-1])) - first[:-1][ch_q]
+            ch_lo = np.r_[start[ch_q] + within * chunk, len(ids)].astype(np.int32)
+            arrs = [order, uid.astype(np.int32), first, ch_lo, ch_q]
+            self.keep += arrs
+            sx = SideIndexC()
+            sx.n_uniq, sx.n_chunks = len(uid), int(first[-1])
+            for n, a in zip(("order", "uid", "first", "ch_lo", "ch_q"), arrs):
+                setattr(sx, n, np.ascontiguousarray(a).ctypes.data)
+            return sx
+        ix = IndexC()
+        ix.r, ix.c = side(np.asarray(row)), side(np.asarray(col))
+        self.e = np.zeros(len(row), np.float32)
+        self.P_r, self.P_c = np.zeros((ix.r.n_chunks, d), np.float32), np.zeros((ix.c.n_chunks, d), np.float32)
+        self.Pb_r, self.Pb_c = np.zeros(ix.r.n_chunks, np.float32), np.zeros(ix.c.n_chunks, np.float32)
+        for n in ("e", "P_r", "P_c", "Pb_r", "Pb_c"):
+            setattr(ix, n, getattr(self, n).ctypes.data)
+        self.c_struct = ix
+
+
 class HyperC(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("l2_reg", "reg_mult", "lr", "eps", "beta1", "beta2", "inv_batch")]
 
@@ -76,6 +118,24 @@ class CPort:
                 self.out.ctypes.data_as(C.c_void_p))
         assert rc == 0
         return tuple(float(x) for x in self.out)
+
+    def step_mt(self, index: "BatchIndex", row, col, w, y, hp, threads=0, inv_batch=None):
+        """The same step on `threads` cores (0 = all OpenMP offers): oracle/glove_ref.c glove_ref_step_mt_f32."""
+        B = len(row)
+        h = HyperC(hp.l2_reg, hp.reg_mult, hp.learning_rate, hp.epsilon, hp.beta1, hp.beta2,
+                   (1.0 / B) if inv_batch is None else inv_batch)
+        row, col = np.ascontiguousarray(row, np.int32), np.ascontiguousarray(col, np.int32)
+        w, y = np.ascontiguousarray(w, np.float32), np.ascontiguousarray(y, np.float32)
+        rc = self.lib.glove_ref_step_mt_f32(C.byref(self.st), C.byref(h), C.byref(index.c_struct),
+                                            row.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                            w.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_int64(B),
+                                            C.c_int(0 if self.optimizer == "Adagrad" else 1), C.c_int(int(threads)),
+                                            self.out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return tuple(float(x) for x in self.out)
+
+    def max_threads(self) -> int:
+        return int(self.lib.glove_ref_max_threads())
 
     @property
     def g(self):

@@ -18,10 +18,28 @@ LOSS_RTOL = 1e-5
 PARAM_RTOL, PARAM_ATOL = 1e-5, 1e-6
 
 
-def _hyper(hp: ref.Hyper, B):
+def _hyper(hp: ref.Hyper, B, step_form=0):
     from trainer.hip_api import make_hyper
     return make_hyper(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=hp.learning_rate, epsilon=hp.epsilon,
-                      beta1=hp.beta1, beta2=hp.beta2, batch_size=B, head=hp.head, neg_factor=hp.neg_factor)
+                      beta1=hp.beta1, beta2=hp.beta2, batch_size=B, head=hp.head, neg_factor=hp.neg_factor,
+                      step_form=step_form)
+
+
+def _assert_tables_agree(a, b, rtol, atol, info=""):
+    for n in ("R", "C", "br", "bc"):
+        np.testing.assert_allclose(getattr(a, n).cpu().numpy(), getattr(b, n).cpu().numpy(), rtol=rtol, atol=atol, err_msg=n + " " + info)
+        np.testing.assert_allclose(a.s1[n].cpu().numpy(), b.s1[n].cpu().numpy(), rtol=rtol, atol=atol, err_msg="slot1 " + n + " " + info)
+    np.testing.assert_allclose(a.scalars.cpu().numpy(), b.scalars.cpu().numpy(), rtol=rtol, atol=atol, err_msg=info)
+    assert a.global_step == b.global_step, info
+
+
+def _assert_same_bits(a, b, info=""):
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n + " " + info
+        assert torch.equal(a.s1[n], b.s1[n]), "slot1 " + n + " " + info
+        if n in a.s2:
+            assert torch.equal(a.s2[n], b.s2[n]), "slot2 " + n + " " + info
+    assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step, info
 
 
 @pytest.mark.parametrize("B", [300, 9000])        # one-workgroup builder / rocPRIM builder
@@ -98,9 +116,16 @@ def test_plan_build_bit_exact(hip, B, V, cap):
         for p_ in [q_ for q_ in (plan, cpr) if q_.r_crec is not None]:
             rec = getattr(p_, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
             n = np.diff(starts)
+            ids = np.asarray(ids)
             np.testing.assert_array_equal(rec[:, 0], ids)
             np.testing.assert_array_equal(rec[:, 1], n)
             np.testing.assert_array_equal(rec[:, 2], starts[:-1])
+            # word 3: first-chunk-of-its-id flag in bit 31, chunks of the same id behind this one below it
+            first = np.r_[True, ids[1:] != ids[:-1]]
+            run_id = np.cumsum(first) - 1
+            run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
+            want_w3 = (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31)
+            np.testing.assert_array_equal(rec[:, 3].view(np.uint32), want_w3)
             for j in (0, nc // 2, nc - 1):
                 sl = slice(starts[j], starts[j + 1])
                 np.testing.assert_array_equal(rec[j, 4:4 + n[j]], partner[sl])
@@ -427,9 +452,15 @@ def test_randomized_forms_agree_bitwise(hip, seed):
         t.step = int(rng.integers(0, 1000))
     a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
     plan = hip.build_plan(*to_dev(c["row"], c["col"], c["w"], y), c["V"], chunk_cap=c["cap"])
-    h = _hyper(hp, c["B"])
+    if seed % 2:
+        plan = plan.compact(hip.lib)           # resident form: host counts, per-chunk records when they pay
+    h = _hyper(hp, c["B"], step_form=1)
     Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
+    fused = [(tables_from_oracle(t, DeviceTables), _hyper(hp, c["B"], step_form=f)) for f in (2, 3)] \
+        if c["optimizer"] == "Adagrad" else []
     for _ in range(c["steps"]):
+        for ft, fh in fused:                   # the forms whose single-chunk ids are applied by the pass kernel itself
+            hip.step_adagrad(plan, ft, fh)
         if c["optimizer"] == "Adagrad":
             hip.step_adagrad(plan, a, h)
             hip.passes(plan, b, h)
@@ -448,6 +479,44 @@ def test_randomized_forms_agree_bitwise(hip, seed):
             assert torch.equal(a.s2[n], b.s2[n]), "slot2 " + n + " " + info
     assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step, info
     assert float(Ga.abs().max()) == 0.0 and float(Gb.abs().max()) == 0.0, info
+    if fused:        # the fused forms sum an id's pairs run by run instead of chunk by chunk: same bits among themselves
+        _assert_same_bits(fused[0][0], fused[1][0], "step_form 2 vs 3 " + info)
+        _assert_tables_agree(a, fused[0][0], 2e-5 * c["steps"], 2e-6 * c["steps"], "step_form 2 vs 1 " + info)
+
+
+@pytest.mark.parametrize("B,V,d,cap", STEP_CASES + [(4096, 4096, 64, 32), (9000, 20000, 300, 16), (30000, 300000, 128, 16),
+                                                    (50000, 3000, 64, 8), (20000, 5, 32, 8)])
+def test_step_forms_agree(hip, B, V, d, cap):
+    """glove_hyper.step_form.  The fused forms (ids whose chunks one lane group holds are applied by the pass kernel:
+    one-pass form with the new rows through the slots, three-launch form with the col side in place) give the same
+    bits as each other and are bitwise repeatable; against the two-launch step they differ only in the order the
+    pairs of a multi-chunk id are summed (fp32 rounding), and every form matches the float64 oracle."""
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B * 3 + d, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap).compact(hip.lib)
+    if plan.r_crec is None:                  # nearly empty chunks carry no records: the library then takes the two-launch form
+        plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=max(1, min(cap, 2))).compact(hip.lib)
+    runs = {}
+    for form in (1, 2, 3, 2, 3):
+        dt = tables_from_oracle(t, DeviceTables)
+        loss_out = torch.zeros(4, device="cuda:0")
+        for k in range(3):
+            hip.step_adagrad(plan, dt, _hyper(hp, B, step_form=form), loss_out)
+            if k == 0 and form not in runs:
+                t1 = t.copy()
+                want = ref.train_step(t1, row, col, w, y, hp)
+                np.testing.assert_allclose(loss_out.cpu().numpy()[:3], want, rtol=LOSS_RTOL)
+                assert_tables_close(dt, t1, PARAM_RTOL, PARAM_ATOL)
+        if form in runs:                     # second run of a fused form: bitwise repeatable
+            _assert_same_bits(runs[form][0], dt, "repeat of form %d" % form)
+            assert torch.equal(runs[form][1], loss_out)
+        runs[form] = (dt, loss_out)
+    _assert_same_bits(runs[2][0], runs[3][0], "forms 2 and 3")
+    assert torch.equal(runs[2][1], runs[3][1])
+    _assert_tables_agree(runs[1][0], runs[2][0], 5e-5, 5e-6, "forms 1 and 2")
+    np.testing.assert_allclose(runs[1][1].cpu().numpy(), runs[2][1].cpu().numpy(), rtol=1e-5)
 
 
 def test_step_is_bitwise_repeatable(hip):
@@ -667,7 +736,8 @@ def test_adagrad_edge_shapes(hip, B, V, d, cap):
     assert_tables_close(dt, t, 2e-5, 2e-6)
 
 
-@pytest.mark.parametrize("workload,B", [("text8_d64", 131072), ("zipf_v400k_d300", 1048576)])
+@pytest.mark.parametrize("workload,B", [("text8_d64", 131072), ("text8_v50k_d300", 131072), ("zipf_v400k_d300", 1048576),
+                                        ("zipf_v2m_d128", 1048576)])
 def test_full_size_spot_check_against_oracle(hip, workload, B):
     """BASELINE-size batches: a full float64 oracle step is out of reach (2.4 GB of gathers), so
     (1) the sparse and the dense (data-parallel) paths must agree bit for bit, (2) rows no pair touches must
@@ -681,13 +751,26 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
     b = DeviceTables(V, d, "Adagrad", seed=5)
     R0, C0, br0, bc0 = a.R.clone(), a.C.clone(), a.br.clone(), a.bc.clone()
     lr, l2, m = 0.05, 0.01, 2.0
-    h = make_hyper(learning_rate=lr, batch_size=B)
+    h = make_hyper(learning_rate=lr, batch_size=B, step_form=1)
     plan = hip.build_plan(row, col, w, y, V, chunk_cap=0, compact=True)
     hip.step_adagrad(plan, a, h)
     G = hip.dense_grad_buffer(b)
     hip.rowpass(plan, b, h); hip.colpass(plan, b, h); hip.dense_grad(plan, b, h, G); hip.dense_adagrad(b, h, G)
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(getattr(a, n), getattr(b, n)), n                       # (1)
+    del G
+    prev = None
+    for form in (0, 2, 3):                                   # (1b) the library's own choice and the fused forms of the step
+        for n, x0 in (("R", R0), ("C", C0), ("br", br0), ("bc", bc0)):
+            getattr(b, n).copy_(x0)
+            b.s1[n].fill_(0.1)
+        b.scalars.zero_(); b.scalars[1] = 0.1; b.step.zero_()
+        hip.step_adagrad(plan, b, make_hyper(learning_rate=lr, batch_size=B, step_form=form))
+        _assert_tables_agree(a, b, 2e-5, 2e-6, "step_form %d" % form)
+        if form == 3 and plan.r_crec is not None:            # the two fused forms sum in the same order
+            for n in ("R", "C", "br", "bc"):
+                assert torch.equal(getattr(b, n), prev[n]), n
+        prev = {n: getattr(b, n).clone() for n in ("R", "C", "br", "bc")} if form == 2 else prev
     touched = torch.zeros(V, dtype=torch.bool, device="cuda:0")
     touched[row.long()] = True
     assert torch.equal(a.R[~touched], R0[~touched])                               # (2)

@@ -102,6 +102,33 @@ def test_c_port_tracks_numpy_restatement(optimizer):
     assert not port.arr["G_R"].any() and not port.arr["mark_r"].any()
 
 
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+@pytest.mark.parametrize("chunk,threads", [(100000, 1), (16, 3), (7, 0)])
+def test_all_core_c_port_equals_the_scalar_port(optimizer, chunk, threads):
+    """oracle/glove_ref.c glove_ref_step_mt_f32 (the all-core CPU baseline of bench.py) against the scalar port:
+    when no id is cut into chunks an id's pairs are summed by one thread in batch order like the scalar port (only
+    the global bias differs in its last bits: sum e is reduced in double over threads); heavy ids summed chunk by
+    chunk agree within fp32 rounding."""
+    import glove_ref_c
+    B, V, d = 2000, 150, 20
+    hp = ref.Hyper(learning_rate=0.05 if optimizer == "Adagrad" else 0.002)
+    t = ref.Tables(V, d, optimizer, dtype=np.float32, seed=4)
+    a, b = glove_ref_c.CPort(t, B), glove_ref_c.CPort(t, B)
+    for s in range(4):
+        row, col, w, y = make_batch(70 + s, B, V)
+        la = a.step(row, col, w, y, hp)
+        lb = b.step_mt(glove_ref_c.BatchIndex(row, col, d, chunk=chunk), row, col, w, y, hp, threads=threads)
+        np.testing.assert_allclose(lb, la, rtol=1e-5)
+    for n in ("R", "C", "br", "bc", "S1_R", "S1_C", "S1_bc"):
+        if chunk >= B:
+            np.testing.assert_allclose(b.arr[n], a.arr[n], rtol=1e-6, atol=1e-9, err_msg=n)
+        else:
+            np.testing.assert_allclose(b.arr[n], a.arr[n], rtol=1e-4, atol=1e-6, err_msg=n)
+    np.testing.assert_allclose(b.g, a.g, rtol=1e-4, atol=1e-7)
+    assert a.st.step == b.st.step == 4 and not b.arr["G_R"].any() and not b.arr["G_bc"].any()
+    assert b.max_threads() >= 1
+
+
 @pytest.mark.parametrize("B,V,cap", [(1, 3, 4), (50, 7, 3), (1000, 31, 8), (300, 1000, 32)])
 def test_plan_partitions_the_batch(B, V, cap):
     row, col, _, _ = make_batch(B, B, V)
