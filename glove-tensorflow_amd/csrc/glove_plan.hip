@@ -23,7 +23,7 @@ int plan_build_small(const int32_t *row, const int32_t *col, const float *w, con
 // positions 0..n-1, and copies of the ids with anything outside [0, V) mapped to 0 — the id the reference's
 // vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) — so that no later kernel
 // can index outside the tables whatever the caller hands over; counts[5] reports how many were mapped
-__global__ void prepare_ids(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t n, int32_t V,
+__global__ void prepare_ids(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t n, int32_t Vr, int32_t V,
                             int32_t *__restrict__ iota, int32_t *__restrict__ row_clean,
                             int32_t *__restrict__ col_clean, int32_t *__restrict__ n_mapped)
 {
@@ -31,9 +31,9 @@ __global__ void prepare_ids(const int32_t *__restrict__ row, const int32_t *__re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)row[i], c = (uint32_t)col[i];
         iota[i] = (int32_t)i;
-        row_clean[i] = r < (uint32_t)V ? (int32_t)r : 0;
+        row_clean[i] = r < (uint32_t)Vr ? (int32_t)r : 0;
         col_clean[i] = c < (uint32_t)V ? (int32_t)c : 0;
-        bad += (r >= (uint32_t)V) + (c >= (uint32_t)V);
+        bad += (r >= (uint32_t)Vr) + (c >= (uint32_t)V);
     }
     if (bad) atomicAdd(n_mapped, bad);
 }
@@ -426,7 +426,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     size_t need = 0;
 
     // ---- row side: stable sort (row id, position)
-    hipLaunchKernelGGL(prepare_ids, dim3(nb), dim3(kBlock), 0, st, row, col, B, V, pw.iota, pw.row_clean, pw.col_clean,
+    hipLaunchKernelGGL(prepare_ids, dim3(nb), dim3(kBlock), 0, st, row, col, B, plan->V_row > 0 ? plan->V_row : V, V, pw.iota, pw.row_clean, pw.col_clean,
                        plan->counts + 5);
     HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
                                       (size_t)B, 0, bits, st));

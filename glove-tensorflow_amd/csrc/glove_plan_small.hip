@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         pos[e] = i;
         if (i < B) {
             uint32_t r = (uint32_t)row[i];
-            if (r >= (uint32_t)V) { r = 0; ++mapped; }
+            if (r >= (uint32_t)(plan.V_row > 0 ? plan.V_row : V)) { r = 0; ++mapped; }
             key[e] = r;
         }
     }

@@ -520,7 +520,8 @@ __device__ inline void sum_partials(const SideBufs &sb, const Slots &sl, int k0,
 //                                                   accumulator, Adam's m and v, or the dense gradient
 //                                                   row), requested together with the table row so the
 //                                                   latencies overlap
-//   fn.finish(is_row, id, G, Wv, Gb, bval, st)      G = summed gradient incl. the activity-L2 term
+//   fn.finish(is_row, id, q, G, Wv, Gb, bval, st)   G = summed gradient incl. the activity-L2 term; q = position of
+//                                                   the id among its side's distinct ids (plan order)
 // Returns true in the workgroup that should also do the once-per-step scalar work.
 template <int LPR, int NV, class F>
 __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const SideBufs &cs,
@@ -584,7 +585,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
 #pragma unroll
             for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
             Gb += k.kappa_b * cnt * bval;
-            fn.finish(is_row, id, G, Wv, Gb, bval, st);
+            fn.finish(is_row, id, code & 0x3fffffff, G, Wv, Gb, bval, st);
         }
         return false;
     }
@@ -635,7 +636,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
         Gb += k.kappa_b * cnt * bval;
         GLOVE_DRAIN(); GLOVE_STAMP(3);      // rows arrived
-        fn.finish(is_row, id, G, Wv, Gb, bval, st);
+        fn.finish(is_row, id, qq, G, Wv, Gb, bval, st);
         GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
     }
     GLOVE_STAMP(5);
@@ -693,7 +694,7 @@ struct AdagradApply {
         load_row<LPR, NV>(st.A, sb.S1, id, d4, lg);
         st.Ab = sb.S1b[id];
     }
-    __device__ void finish(bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         const SideBufs &sb = is_row ? rs : cs;
 #pragma unroll
@@ -747,7 +748,7 @@ struct DenseGradAdd {
         load_row<LPR, NV>(st.old, is_row ? G_R : G_C, id, d4, lg);
         st.oldb = (is_row ? G_br : G_bc)[id];
     }
-    __device__ void finish(bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         (void)Wv; (void)bval;
 #pragma unroll
@@ -774,6 +775,191 @@ __global__ __launch_bounds__(kBlock) void dense_grad_kernel(
             tail[2] += tot[1];   // sum |r|^2 + |c|^2
             tail[3] += tot[2];   // sum br^2 + bc^2
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Touched-rows exchange: instead of a dense [V,d] gradient buffer a rank hands over ONE packed list
+// of (id, summed gradient row) per step.  An entry is d + 4 floats, 16-B aligned:
+//     [ gradient row, d floats | bias gradient | id (int bits) | side (0 row, 1 col; int bits) | 0 ]
+// Entry 0 of a list is its header: [row entries, col entries (int bits) | sum e, sum w diff^2, sum |r|^2+|c|^2,
+// sum br^2+bc^2 | 0 ...]; the row-side entries follow in plan order (ascending id), then the col-side entries.
+// The receiving side adds the lists of all ranks into the dense buffer G_flat IN LIST ORDER (one launch per list: ids are
+// distinct within a list, launches are ordered, so the sum over ranks has a fixed order), the first list that touches an id
+// storing instead of adding (G_flat needs no zeroing) and leaving its tag in `mark`; then one launch applies Adagrad to
+// every touched id, each from the list that touched it first, and clears the marks.
+// ------------------------------------------------------------------------------------------
+constexpr int kPackExtra = 4;
+
+template <int LPR, int NV>
+struct PackGrad {
+    float *packed;
+    int d4, lg, row_entries;
+    struct State {};
+    __device__ void prefetch(bool, int32_t, State &) const {}
+    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &) const
+    {
+        (void)Wv; (void)bval;
+        const size_t stride4 = (size_t)d4 + 1;
+        f4 *e = reinterpret_cast<f4 *>(packed) + (size_t)(1 + (is_row ? q : row_entries + q)) * stride4;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            const int i4 = lg + kk * LPR;
+            if (i4 < d4) e[i4] = G[kk];
+        }
+        if (lg == 0) e[d4] = f4{Gb, __int_as_float(id), __int_as_float(is_row ? 0 : 1), 0.f};
+    }
+};
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void pack_grad_kernel(
+    IdWork wk, SideBufs rs, SideBufs cs, int d4, StepConsts k, float *__restrict__ packed,
+    const float *__restrict__ blockpart, int nblocks_rowpass)
+{
+    const int nu_r = wk.nu_r_host >= 0 ? wk.nu_r_host : wk.counts[1];
+    const int nu_c = wk.nu_c_host >= 0 ? wk.nu_c_host : wk.counts[3];
+    const int row_entries = (wk.sides & 1) ? nu_r : 0;
+    const bool scalar_duty = for_each_id<LPR, NV>(wk, rs, cs, d4, k,
+                                                  PackGrad<LPR, NV>{packed, d4, (int)(threadIdx.x % LPR), row_entries});
+    if (scalar_duty) {                      // the col side carries the loss partials (glove_hyper.sides)
+        float tot[kPartials];
+        sum_blockpart(blockpart, nblocks_rowpass, tot);
+        if (threadIdx.x == 0) {
+            f4 *h = reinterpret_cast<f4 *>(packed);
+            h[0] = f4{__int_as_float(row_entries), __int_as_float(nu_c), tot[3], tot[0]};
+            h[1] = f4{tot[1], tot[2], 0.f, 0.f};
+        }
+    } else if (!(wk.sides & 2) && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        f4 *h = reinterpret_cast<f4 *>(packed);            // row side only: no loss partials travel with it
+        h[0] = f4{__int_as_float(row_entries), __int_as_float(0), 0.f, 0.f};
+        h[1] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+struct PackedList {
+    const float *entries;       // first entry behind the header (or a bare array of entries)
+    const int32_t *ids;         // if not null: ids[i] replaces the id stored in entry i (owner-local indices)
+    const float *header;        // if not null: entry count = row entries + col entries of this header
+    int n_host;                 // else the entry count
+    int side;                   // -1: every entry names its side; 0 / 1: all entries are of that side
+};
+
+struct DenseViews { float *G_R, *G_br, *G_C, *G_bc; int32_t *mark; int V_row; };
+
+__device__ inline int packed_count(const PackedList &pl)
+{
+    if (!pl.header) return pl.n_host;
+    return __float_as_int(pl.header[0]) + __float_as_int(pl.header[1]);
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void combine_packed_kernel(PackedList pl, int tag, DenseViews dv, int d4)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int n = packed_count(pl);
+    const size_t stride4 = (size_t)d4 + 1;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const f4 *e = reinterpret_cast<const f4 *>(pl.entries) + (size_t)i * stride4;
+        const f4 x = e[d4];
+        const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x.y);
+        const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
+        int32_t *mk = dv.mark + (is_row ? 0 : dv.V_row) + id;
+        const int32_t seen = *mk;           // every lane of the group reads it before lane 0 rewrites it below
+        f4 g[NV];
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            const int i4 = lg + kk * LPR;
+            g[kk] = e[i4 < d4 ? i4 : d4 - 1];
+        }
+        float *Gt = is_row ? dv.G_R : dv.G_C;
+        float *Gb = is_row ? dv.G_br : dv.G_bc;
+        if (seen != 0) {                    // a list before this one touched the id: add behind it
+            f4 old[NV];
+            load_row<LPR, NV>(old, Gt, id, d4, lg);
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) g[kk] = old[kk] + g[kk];
+        }
+        store_row<LPR, NV>(Gt, (size_t)id, d4, lg, g);
+        if (lg == 0) {
+            Gb[id] = seen != 0 ? Gb[id] + x.x : x.x;
+            if (seen == 0) *mk = tag + 1;
+        }
+    }
+}
+
+struct PackedLists { PackedList l[8]; int n; };
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
+    PackedLists pls, DenseViews dv, SideBufs rs, SideBufs cs, int d4, StepConsts k, int first_tag,
+    const float *__restrict__ tail_in, float *__restrict__ scalars, float *__restrict__ loss_out, int do_scalars)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const size_t stride4 = (size_t)d4 + 1;
+    const PackedList &pl = pls.l[blockIdx.y];
+    const int tag = first_tag + blockIdx.y;
+    const int n = packed_count(pl);
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const f4 x = (reinterpret_cast<const f4 *>(pl.entries) + (size_t)i * stride4)[d4];
+        const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x.y);
+        const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
+        int32_t *mk = dv.mark + (is_row ? 0 : dv.V_row) + id;
+        if (*mk != tag + 1) continue;       // another list touched the id first: that list's entry applies it
+        const SideBufs &sb = is_row ? rs : cs;
+        f4 G[NV], Wv[NV], A[NV];
+        load_row<LPR, NV>(G, is_row ? dv.G_R : dv.G_C, id, d4, lg);
+        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
+        load_row<LPR, NV>(A, sb.S1, id, d4, lg);
+        float Gb = (is_row ? dv.G_br : dv.G_bc)[id], bval = sb.bias[id], Ab = sb.S1b[id];
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[kk], A[kk], G[kk], k.lr, k.eps);
+        store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
+        store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
+        if (lg == 0) {
+            adagrad_elem(bval, Ab, Gb, k.lr, k.eps);
+            sb.S1b[id] = Ab;
+            sb.bias[id] = bval;
+            *mk = 0;
+        }
+    }
+    if (do_scalars && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        // loss partials: given already summed over the ranks (tail_in), or summed here over the lists' headers in list order
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tail_in) {
+            t[0] = tail_in[0]; t[1] = tail_in[1]; t[2] = tail_in[2]; t[3] = tail_in[3];
+        } else {
+            for (int r = 0; r < pls.n; ++r) {
+                const float *h = pls.l[r].header;
+                if (h) { t[0] += h[2]; t[1] += h[3]; t[2] += h[4]; t[3] += h[5]; }
+            }
+        }
+        const float g = scalars[0];
+        const float tot[kPartials] = {t[1], t[2], t[3], t[0]};
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = t[0] + 2.0f * k.m * k.l2 * g;
+        adagrad_elem(scalars[0], scalars[1], dg, k.lr, k.eps);
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = t[0]; }
+    }
+}
+
+// rows[i] = W[ids[i]] (d floats each), biases[i] = bias[ids[i]]: what the owner of a table shard sends to the ranks
+// whose batches touch those rows
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(
+    const float *__restrict__ W, const float *__restrict__ bias, const int32_t *__restrict__ ids, int n, int d4,
+    float *__restrict__ rows, float *__restrict__ biases)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const int32_t id = ids[i];
+        f4 v[NV];
+        load_row<LPR, NV>(v, W, id, d4, lg);
+        store_row<LPR, NV>(rows, (size_t)i, d4, lg, v);
+        if (lg == 0) biases[i] = bias[id];
     }
 }
 
@@ -878,7 +1064,7 @@ struct AdamApply {
         st.Mb = sb.S1b[id];
         st.Vb = (is_row ? S2_br : S2_bc)[id];
     }
-    __device__ void finish(bool is_row, int32_t id, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         const SideBufs &sb = is_row ? rs : cs;
 #pragma unroll
@@ -1299,6 +1485,126 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dense_adam_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, (float)h->beta1, (float)h->beta2,
                        log((double)(float)h->beta1), log((double)(float)h->beta2), t->step, t->scalars, tail, loss_out, (sides & 2) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+size_t glove_packed_entry_floats(int32_t d) { return d > 0 ? (size_t)d + kPackExtra : 0; }
+
+int glove_pack_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                        float *packed, int64_t capacity_entries, void *stream)
+{
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    if (!packed) return GLOVE_E_BADARG;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    IdWork wk = id_work(p);
+    wk.sides = sides_of(h);
+    // header + every distinct id of the selected sides must fit (the plan's capacity bounds the counts not yet known here)
+    const int64_t nr = (wk.sides & 1) ? (p->host_counts[1] >= 0 ? p->host_counts[1] : p->cap_uniq) : 0;
+    const int64_t nc = (wk.sides & 2) ? (p->host_counts[3] >= 0 ? p->host_counts[3] : p->cap_uniq) : 0;
+    if (1 + nr + nc > capacity_entries) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
+    const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
+    const StepConsts k = make_consts(t, h);
+    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                       \
+    hipLaunchKernelGGL((pack_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4, k, packed, \
+                       w.blockpart, nb_row)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+static int packed_common(const glove_tables *t, float *G_flat, int32_t *mark, DenseViews &dv)
+{
+    if (!t || !G_flat || !mark || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    const int32_t Vr = v_row(t);
+    const GradLayout L = grad_layout(Vr, t->V, t->d);
+    dv = {G_flat + L.G_R, G_flat + L.G_br, G_flat + L.G_C, G_flat + L.G_bc, mark, (int)Vr};
+    return pick_row_shape(t->d / 4).lpr == 0 ? GLOVE_E_BADARG : 0;
+}
+
+static bool to_list(const glove_packed_list *in, PackedList &out)
+{
+    if (!in || !in->entries || (!in->header && in->n < 0) || in->side < -1 || in->side > 1) return false;
+    out = {in->entries, in->ids, in->header, (int)in->n, (int)in->side};
+    return true;
+}
+
+int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const glove_tables *t, float *G_flat,
+                             int32_t *mark, int64_t capacity_entries, void *stream)
+{
+    DenseViews dv;
+    if (int rc = packed_common(t, G_flat, mark, dv)) return rc;
+    PackedList pl;
+    if (!to_list(list, pl) || tag < 0 || capacity_entries < 0) return GLOVE_E_BADARG;
+    const int64_t n = pl.header ? capacity_entries : pl.n_host;
+    if (n == 0) return 0;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int nb = blocks_for(n, kBlock / shape.lpr);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV) hipLaunchKernelGGL((combine_packed_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, pl, (int)tag, dv, d4)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lists, const glove_tables *t,
+                                   const glove_hyper *h, float *G_flat, int32_t *mark, const float *tail,
+                                   float *loss_out, int64_t capacity_entries, void *stream)
+{
+    DenseViews dv;
+    if (int rc = packed_common(t, G_flat, mark, dv)) return rc;
+    if (!h || !lists || n_lists < 1 || capacity_entries < 0) return GLOVE_E_BADARG;
+    if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const StepConsts k = make_consts(t, h);
+    SideBufs rs = {nullptr, nullptr, nullptr, t->R, t->s1_R, t->br, t->s1_br};
+    SideBufs cs = {nullptr, nullptr, nullptr, t->C, t->s1_C, t->bc, t->s1_bc};
+    hipStream_t st = (hipStream_t)stream;
+    // the scalar work (global bias, loss) goes with the col side, like everywhere else; without an explicit tail it
+    // reads the headers of the first (up to eight) lists
+    const int do_scalars = (sides_of(h) & 2) ? 1 : 0;
+    if (!tail && n_lists > 8 && do_scalars) return GLOVE_E_BADARG;
+    for (int32_t first = 0; first < n_lists; first += 8) {
+        PackedLists pls;
+        pls.n = n_lists - first < 8 ? n_lists - first : 8;
+        int64_t n_max = 0;
+        for (int i = 0; i < pls.n; ++i) {
+            if (!to_list(lists + first + i, pls.l[i])) return GLOVE_E_BADARG;
+            const int64_t n = pls.l[i].header ? capacity_entries : pls.l[i].n_host;
+            n_max = n > n_max ? n : n_max;
+        }
+        const int nbx = blocks_for(n_max > 0 ? n_max : 1, kBlock / shape.lpr);
+        const int scal = first == 0 ? do_scalars : 0;
+#define CALL(LPR, NV)                                                                                               \
+        hipLaunchKernelGGL((apply_packed_adagrad_kernel<LPR, NV>), dim3(nbx, pls.n), dim3(kBlock), 0, st, pls, dv, rs, cs, \
+                           d4, k, (int)first, tail, t->scalars, loss_out, scal)
+        GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    }
+    return (int)hipGetLastError();
+}
+
+int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids, int32_t n, int32_t d, float *rows,
+                          float *biases, void *stream)
+{
+    if (n < 0 || d <= 0 || (d % 4) != 0) return GLOVE_E_BADARG;
+    if (n == 0) return 0;
+    if (!W || !bias || !ids || !rows || !biases) return GLOVE_E_BADARG;
+    const int d4 = d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    if (shape.lpr == 0) return GLOVE_E_BADARG;
+    const int nb = blocks_for(n, kBlock / shape.lpr);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV) hipLaunchKernelGGL((gather_rows_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, W, bias, ids, (int)n, d4, rows, biases)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
     return (int)hipGetLastError();
 }
 

@@ -69,6 +69,9 @@ FLAGS = (
     Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
                                      "nonzero to the rank that owns its row, instead of replicating all tables "
                                      "(BASELINE config 5; Adagrad only)"),
+    Flag("exchange", str, "auto", "multi-GPU gradient exchange: dense (all-reduce of the [V,d] gradient buffer), rows "
+                                  "(all-gather of the touched rows' summed gradients), auto (rows when that is the "
+                                  "shorter payload for the resident batches)"),
 )
 
 

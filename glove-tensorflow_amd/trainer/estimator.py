@@ -147,9 +147,14 @@ class Estimator:
                                         burst=min(log_every, 100))      # graphs of ~100 steps replay fastest (measured)
         elif self.row_sharded:
             from trainer.stepper import RowShardedStepper
-            stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
+            stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
+                                        exchange=p.get("exchange", "auto"))
+            stepper.prepare(stream.plans)           # collective: the ranks agree on the col-side exchange
         else:
-            stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist)
+            stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
+                              exchange=p.get("exchange", "auto"))
+            if self.world > 1:
+                stepper.prepare(stream.plans)       # collective: dense all-reduce or touched-rows all-gather
         fresh = self.ckpt.latest() is None
         if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
             flag = torch.tensor([1 if fresh else 0], device=self.device)

@@ -47,6 +47,8 @@ EXPORTED_SYMBOLS = (
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
+    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
+    "glove_gather_rows_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -70,12 +72,16 @@ class GloveHyper(C.Structure):
 class GlovePlan(C.Structure):
     _fields_ = [("B", C.c_int64), ("chunk_cap", C.c_int32), ("cap_chunks", C.c_int32),
                 ("cap_uniq", C.c_int32), ("heavy_chunks", C.c_int32), ("cap_heavy", C.c_int32),
-                ("reserved", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 8),
+                ("V_row", C.c_int32), ("counts", _fp), ("host_counts", C.c_int32 * 8),
                 ("r_partner", _fp), ("r_w", _fp), ("r_y", _fp), ("r_to_c", _fp),
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp),
                 ("r_crec", _fp), ("c_crec", _fp)]
+
+
+class GlovePackedList(C.Structure):
+    _fields_ = [("entries", _fp), ("ids", _fp), ("header", _fp), ("n", C.c_int32), ("side", C.c_int32)]
 
 
 class GloveHipError(RuntimeError):
@@ -117,6 +123,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_steps_adagrad_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
+        "glove_packed_entry_floats": (sz, [i32]),
+        "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
+        "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
+        "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
+        "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
@@ -154,18 +165,35 @@ def _require_cuda(*tensors):
             raise GloveHipError("device tensor expected (the HIP path has no CPU fallback)")
 
 
+def _require(t, dtype, n=None):
+    """The kernels read raw pointers: a wrong dtype (torch's default int64 ids), a strided view or a short buffer
+    would be silently misread."""
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise GloveHipError("device tensor expected (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise GloveHipError("expected a %s tensor, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise GloveHipError("expected a contiguous tensor")
+    if n is not None and t.numel() != n:
+        raise GloveHipError("expected %d elements, got %d" % (n, t.numel()))
+
+
 class DeviceTables:
     """The five variables + optimizer slots as device buffers (reference model_utils.py:31-39)."""
 
     NAMES = ("R", "C", "br", "bc")
 
     def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None,
-                 V_row: int | None = None):
+                 V_row: int | None = None, V_col: int | None = None):
         """`d`: --embedding-size, any positive int.  Rows are stored 16-byte aligned: `self.d` is the row
         stride (d rounded up to a multiple of 4, what the kernels and workspace queries take), `self.d_model`
         the reference's embedding size; the padding columns are zero and stay zero (glove_tables.d_model).
         `V_row` < V: this process holds only a shard of the row table (row ids handed to the kernels
-        are then local indices into the shard); the col table always has V rows."""
+        are then local indices into the shard).  `V_col` < V: it also holds only a shard of the col table
+        (trainer.stepper.ShardedStepper, which runs the passes against fetched col rows); such tables go through
+        TablesView, the plain kernels expect V col rows."""
         if d <= 0:
             raise ValueError("embedding size must be positive, got %d" % d)
         if optimizer not in ("Adagrad", "Adam"):
@@ -173,8 +201,9 @@ class DeviceTables:
         self.V, self.d_model, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
         self.d = (int(d) + 3) // 4 * 4
         self.V_row = int(V if V_row is None else V_row)
-        if not 0 < self.V_row <= self.V:
-            raise ValueError("V_row must be in (0, V]")
+        self.V_col = int(V if V_col is None else V_col)
+        if not 0 < self.V_row <= self.V or not 0 < self.V_col <= self.V:
+            raise ValueError("V_row and V_col must be in (0, V]")
         gen = torch.Generator(device="cpu")
         if seed is not None:
             gen.manual_seed(seed)
@@ -189,8 +218,8 @@ class DeviceTables:
             t[:, :self.d_model] = uni(rows, self.d_model)
             return t
 
-        self.R, self.C = table(self.V_row), table(V)
-        self.br, self.bc = uni(self.V_row), uni(V)
+        self.R, self.C = table(self.V_row), table(self.V_col)
+        self.br, self.bc = uni(self.V_row), uni(self.V_col)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.s1, self.s2 = {}, {}
@@ -297,6 +326,29 @@ class DeviceTables:
         return int(self.step.item())
 
 
+class TablesView:
+    """A glove_tables struct over buffers picked by the caller: the tables of `base` with some of them replaced
+    (a fetched block as the col table, a col shard standing on the row side, ...).  Offers what the wrappers use:
+    struct(), d, V, V_row, device, optimizer."""
+
+    def __init__(self, base: "DeviceTables", V: int, V_row: int, keep=(), **replace):
+        self.d, self.d_model, self.device, self.optimizer = base.d, base.d_model, base.device, base.optimizer
+        self.V, self.V_row = int(V), int(V_row)
+        self._keep = (base, keep, replace)                      # the struct holds raw pointers: keep the owners alive
+        src = base.struct()
+        s = GloveTables()
+        for name, _ in GloveTables._fields_:
+            setattr(s, name, getattr(src, name))
+        s.V, s.V_row = self.V, (0 if self.V_row == self.V else self.V_row)
+        for name, tensor in replace.items():
+            _require(tensor, torch.float32)
+            setattr(s, name, tensor.data_ptr())
+        self._struct = s
+
+    def struct(self) -> GloveTables:
+        return self._struct
+
+
 class Plan:
     """Device-resident dedup index of one batch (see glove_plan in include/glove_hip.h)."""
 
@@ -304,8 +356,8 @@ class Plan:
                   "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
-                 cap_uniq: int | None = None):
-        self.B, self.V, self.chunk_cap = int(B), int(V), int(chunk_cap)
+                 cap_uniq: int | None = None, V_row: int = 0):
+        self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
         self.cap_chunks = int(B if cap_chunks is None else cap_chunks)
         self.cap_uniq = int(min(B, V) if cap_uniq is None else cap_uniq)
         dev = torch.device(device)
@@ -339,7 +391,7 @@ class Plan:
             s = GlovePlan()
             s.r_crec, s.c_crec = _ptr(self.r_crec), _ptr(self.c_crec)
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
-            s.heavy_chunks, s.cap_heavy = self.heavy_chunks, self.cap_heavy
+            s.heavy_chunks, s.cap_heavy, s.V_row = self.heavy_chunks, self.cap_heavy, getattr(self, "V_row", 0)
             s.counts = _ptr(self.counts)
             for i in range(8):
                 s.host_counts[i] = self.host_counts[i]
@@ -358,7 +410,7 @@ class Plan:
         if n_mapped:
             logger.warning("%d ids outside [0, %d) were treated as id 0 (the unknown token)", n_mapped, self.V)
         out = Plan.__new__(Plan)
-        out.B, out.V, out.chunk_cap = self.B, self.V, self.chunk_cap
+        out.B, out.V, out.chunk_cap, out.V_row = self.B, self.V, self.chunk_cap, self.V_row
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
         out.counts = self.counts.clone()
         out.host_counts = [nc_r, nu_r, nc_c, nu_c, n_heavy, -1, -1, -1]
@@ -428,13 +480,16 @@ class GloveHip:
 
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
-                   into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None) -> Plan:
-        """Builds the dedup index of one batch on the device.  `into`: a full-capacity Plan of the same
+                   into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None,
+                   V_row: int = 0) -> Plan:
+        """Builds the dedup index of one batch on the device.  `V_row`: rows of this rank's row-table shard when the
+        row ids are shard-local (ids outside it count as id 0, like col ids outside [0, V)).  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
         allocations per step this way.  `ws`: scratch of glove_plan_workspace_bytes(B, V) bytes (default: one
         shared buffer, fine for builds issued on one stream)."""
-        _require_cuda(row, col, w, y)
         B = int(row.numel())
+        _require(row, torch.int32, B); _require(col, torch.int32, B)
+        _require(w, torch.float32, B); _require(y, torch.float32, B)
         if not chunk_cap:
             chunk_cap = auto_chunk_cap(B, V, d)
         if into is not None:
@@ -442,7 +497,7 @@ class GloveHip:
                 raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
             plan = into
         else:
-            plan = Plan(B, V, chunk_cap, row.device)
+            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row)
         if ws is None:      # builds that run concurrently on different streams each bring their own scratch
             ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
@@ -494,6 +549,57 @@ class GloveHip:
     def dense_grad_buffer(self, tables) -> torch.Tensor:
         return torch.zeros(self.grad_layout(tables)["total"], dtype=torch.float32, device=tables.device)
 
+    # ---- touched-rows exchange (include/glove_hip.h "touched-rows exchange")
+    def packed_list(self, buf: torch.Tensor, with_header=True, ids: torch.Tensor | None = None, n: int = -1,
+                    side: int = -1) -> GlovePackedList:
+        """One list inside `buf` ([entries, d + 4] float32, contiguous): header in entry 0 and the count read from it on
+        the device (with_header), or a bare run of `n` entries, optionally with explicit owner-local `ids`."""
+        _require(buf, torch.float32)
+        stride = buf.shape[-1]
+        lst = GlovePackedList()
+        lst.entries = buf.data_ptr() + (4 * stride if with_header else 0)
+        lst.header = buf.data_ptr() if with_header else None
+        if ids is not None:
+            _require(ids, torch.int32)
+            if ids.numel() < n:
+                raise GloveHipError("%d ids for %d entries" % (ids.numel(), n))
+        lst.ids = _ptr(ids)
+        lst.n, lst.side = n, side
+        return lst
+
+    def pack_grad(self, plan, tables, hyper, packed: torch.Tensor, ws=None):
+        """The plan's summed gradients (hyper.sides) as one packed list: packed is [capacity, d + 4] float32."""
+        _require(packed, torch.float32)
+        if packed.dim() != 2 or packed.shape[1] != tables.d + 4:
+            raise GloveHipError("packed buffer must be [entries, d + 4]")
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_pack_grad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
+                                            ws.numel(), _ptr(packed), packed.shape[0], _stream()), "glove_pack_grad_f32")
+
+    def combine_packed(self, lst: GlovePackedList, tag: int, tables, G_flat, mark, capacity: int):
+        _require(G_flat, torch.float32)
+        _require(mark, torch.int32)
+        if mark.numel() < tables.V_row + tables.V:
+            raise GloveHipError("mark needs V_row + V entries")
+        _check(self.lib.glove_combine_packed_f32(C.byref(lst), tag, C.byref(tables.struct()), _ptr(G_flat), _ptr(mark),
+                                                 capacity, _stream()), "glove_combine_packed_f32")
+
+    def apply_packed(self, lists, tables, hyper, G_flat, mark, tail=None, loss_out=None, capacity: int = 0):
+        arr = (GlovePackedList * len(lists))(*lists)
+        _check(self.lib.glove_apply_packed_adagrad_f32(arr, len(lists), C.byref(tables.struct()), C.byref(hyper),
+                                                       _ptr(G_flat), _ptr(mark), _ptr(tail), _ptr(loss_out), capacity,
+                                                       _stream()), "glove_apply_packed_adagrad_f32")
+
+    def gather_rows(self, W, bias, ids, rows, biases):
+        for x in (W, bias, rows, biases):
+            _require(x, torch.float32)
+        _require(ids, torch.int32)
+        n = int(ids.numel())
+        if rows.numel() < n * W.shape[1] or biases.numel() < n:
+            raise GloveHipError("gather_rows: output buffers too small")
+        _check(self.lib.glove_gather_rows_f32(_ptr(W), _ptr(bias), _ptr(ids), n, W.shape[1], _ptr(rows), _ptr(biases),
+                                              _stream()), "glove_gather_rows_f32")
+
     # ---- whole steps
     def step_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
@@ -530,7 +636,10 @@ class GloveHip:
 
     # ---- eval / predict
     def eval_sums(self, row, col, w, y, tables, sums=None) -> torch.Tensor:
-        _require_cuda(row, col, w, y)
+        n = int(row.numel())
+        _require(row, torch.int32, n); _require(col, torch.int32, n)
+        _require(w, torch.float32, n); _require(y, torch.float32, n)
+        _require(sums, torch.float64)
         if sums is None:
             sums = torch.zeros(4, dtype=torch.float64, device=tables.device)
         _check(self.lib.glove_eval_f32(_ptr(row), _ptr(col), _ptr(w), _ptr(y), int(row.numel()),
@@ -538,7 +647,10 @@ class GloveHip:
         return sums
 
     def eval_sums_logistic(self, row, col, pos, neg, tables, sums=None) -> torch.Tensor:
-        _require_cuda(row, col, pos, neg)
+        n = int(row.numel())
+        _require(row, torch.int32, n); _require(col, torch.int32, n)
+        _require(pos, torch.float32, n); _require(neg, torch.float32, n)
+        _require(sums, torch.float64)
         if sums is None:
             sums = torch.zeros(6, dtype=torch.float64, device=tables.device)
         _check(self.lib.glove_eval_logistic_f32(_ptr(row), _ptr(col), _ptr(pos), _ptr(neg), int(row.numel()),
@@ -547,7 +659,7 @@ class GloveHip:
         return sums
 
     def topk_cosine(self, R: torch.Tensor, query_ids: torch.Tensor, k: int):
-        _require_cuda(R, query_ids)
+        _require(R, torch.float32); _require(query_ids, torch.int32)
         V, d = R.shape
         n = int(query_ids.numel())
         sims = torch.empty(n, k, dtype=torch.float32, device=R.device)
@@ -561,7 +673,7 @@ class GloveHip:
     def cooccurrence(self, tokens: torch.Tensor, V: int, context: int, cap: int | None = None):
         """(row i32, col i32, count i64, value f64) sorted by (row, col): the symmetrised window
         co-occurrence table of reference src/data/text8.py:84-108 (one host sync for the size)."""
-        _require_cuda(tokens)
+        _require(tokens, torch.int32)
         n = int(tokens.numel())
         cap = int(cap if cap is not None else max(1, 2 * context * n))
         dev = tokens.device

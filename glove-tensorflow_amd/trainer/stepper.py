@@ -9,6 +9,12 @@ inv_batch = 1 / (world * B), adds the summed gradients into one flat dense buffe
 the backend is "nccl") and every rank applies the identical dense update.  The result equals a
 single-GPU step at batch size world * B up to fp32 summation order.
 
+Touched-rows exchange.  The dense buffer has 2 V (d+1) floats whatever the batch touches.  When the ranks' lists of
+(id, summed gradient row) are together shorter than that, every rank instead packs its list, the lists are
+all-gathered, and every rank adds them into the (never zeroed) dense buffer in rank order and applies Adagrad to the
+touched rows only: the same sum, then the same apply, with a payload that follows the batch and not the vocabulary
+(`exchange="auto"` decides once from the id counts of the resident plans of all ranks).
+
 `backend` is the kernel provider: `HipBackend` (below) is the only product implementation and
 drives libglove_hip.so; there is no CPU implementation in the product.  Tests inject their own
 provider to exercise the sharding / collective logic with gloo on CPU.
@@ -71,6 +77,73 @@ class HipBackend:
         """The contiguous [G_C | G_bc | tail] part of the flat buffer."""
         return G[self.hip.grad_layout(tables)["G_C"]:]
 
+    # ---- touched-rows exchange
+    def id_counts(self, plan):
+        """(distinct row ids, distinct col ids) of a resident plan."""
+        return plan.host_counts[1], plan.host_counts[3]
+
+    def exchange_buffers(self, tables, capacity: int, world: int):
+        """send [capacity, d + 4], recv [world, capacity, d + 4], mark int32 [V_row + V] (all zero between steps)."""
+        f32 = dict(dtype=torch.float32, device=tables.device)
+        return dict(send=torch.zeros(capacity, tables.d + 4, **f32), recv=torch.zeros(world, capacity, tables.d + 4, **f32),
+                    mark=torch.zeros(tables.V_row + tables.V, dtype=torch.int32, device=tables.device), capacity=capacity)
+
+    def pack_grad(self, plan, tables, hyper, send):
+        self.hip.pack_grad(plan, tables, hyper, send)
+
+    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out):
+        """Adds the ranks' lists into G in rank order, then Adagrad on every touched id (G needs no zeroing)."""
+        cap = bufs["capacity"]
+        lists = bufs.get("_lists")
+        if lists is None:
+            lists = bufs["_lists"] = [self.hip.packed_list(bufs["recv"][r]) for r in range(world)]
+        for r, lst in enumerate(lists):
+            self.hip.combine_packed(lst, r, tables, G, bufs["mark"], cap)
+        self.hip.apply_packed(lists, tables, hyper, G, bufs["mark"], None, loss_out, cap)
+
+    # ---- both tables sharded (ShardedStepper)
+    def gather_rows(self, tables, idx, rows, biases):
+        """rows[i] = C[idx[i]], biases[i] = bc[idx[i]] of this rank's col shard."""
+        self.hip.gather_rows(tables.C, tables.bc, idx, rows, biases)
+
+    def fetch_buffers(self, tables, capacity: int, serve_capacity: int):
+        f32 = dict(dtype=torch.float32, device=tables.device)
+        d = tables.d
+        return dict(C=torch.zeros(max(capacity, 1), d, **f32), bc=torch.zeros(max(capacity, 1), **f32),
+                    send_rows=torch.zeros(max(serve_capacity, 1), d, **f32), send_bias=torch.zeros(max(serve_capacity, 1), **f32),
+                    packed=torch.zeros(1 + capacity, d + 4, **f32), recv=torch.zeros(max(serve_capacity, 1), d + 4, **f32))
+
+    def col_view(self, tables, bufs, capacity: int):
+        """The tables the passes of one batch see: this rank's row shard and, as the col table, the fetched rows
+        (compact col ids index it); the col side's slots are never touched through this view."""
+        from trainer.hip_api import TablesView
+        return TablesView(tables, C=bufs["C"], bc=bufs["bc"], s1_C=bufs["C"], s1_bc=bufs["bc"],
+                          V=max(capacity, tables.V_row), V_row=tables.V_row)
+
+    def owner_apply(self, tables, state, recv, ids, counts, hyper, tail, loss_out):
+        """The owner's half of the col side: `recv` holds, rank after rank, the summed gradient rows the ranks computed
+        for this rank's col rows `ids` (owner-local indices); they are added in rank order and Adagrad is applied."""
+        from trainer.hip_api import TablesView
+        if "view" not in state:
+            f32 = dict(dtype=torch.float32, device=tables.device)
+            dummy, dummy_b = torch.zeros(4, tables.d, **f32), torch.zeros(4, **f32)
+            # the col shard sits on the ROW side of this view (entries of side 0); its col side is a 4-row dummy
+            view = TablesView(tables, R=tables.C, br=tables.bc, s1_R=tables.s1["C"], s1_br=tables.s1["bc"],
+                              C=dummy, bc=dummy_b, s1_C=dummy, s1_bc=dummy_b, V=4, V_row=tables.C.shape[0],
+                              keep=(dummy, dummy_b))
+            state.update(view=view, G=self.hip.dense_grad_buffer(view),
+                         mark=torch.zeros(view.V_row + view.V, dtype=torch.int32, device=tables.device))
+        view, G, mark = state["view"], state["G"], state["mark"]
+        lists, off = [], 0
+        for n in counts:
+            lists.append(self.hip.packed_list(recv[off:off + max(n, 1)], with_header=False, ids=ids[off:off + max(n, 1)],
+                                              n=n, side=0))
+            off += n
+        for r, lst in enumerate(lists):
+            if counts[r]:
+                self.hip.combine_packed(lst, r, view, G, mark, 0)
+        self.hip.apply_packed(lists, view, hyper, G, mark, tail, loss_out, 0)
+
     def eval_sums(self, row, col, w, y, tables, sums):
         return self.hip.eval_sums(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), tables, sums)
 
@@ -82,35 +155,88 @@ class HipBackend:
         return self.hip.topk_cosine(R, query_ids, k)
 
 
+def all_gather_rows(dist, recv, send):
+    """recv[r] = rank r's `send` (equal shapes)."""
+    try:
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+    except (RuntimeError, NotImplementedError):          # a transport without the flat form
+        dist.all_gather([recv[r] for r in range(recv.shape[0])], send)
+
+
 class Stepper:
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None):
+    """`exchange`: "dense" = all-reduce of the flat dense gradient buffer; "rows" = all-gather of packed touched-row
+    lists (Adagrad); "auto" = rows when `prepare(plans)` finds the ranks' lists together shorter than the dense
+    buffer, else dense."""
+
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None, exchange="auto"):
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
         if self.world > 1 and dist is None:
             raise ValueError("world > 1 needs an initialised torch.distributed module")
+        if exchange not in ("auto", "dense", "rows"):
+            raise ValueError("exchange must be auto, dense or rows")
+        if exchange == "rows" and tables.optimizer != "Adagrad":
+            raise ValueError("the touched-rows exchange is for Adagrad (Keras' Adam moves every row every step)")
         self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
         self.dense = self.world > 1 or tables.optimizer != "Adagrad"
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
+        self.exchange, self.rows, self.bufs = exchange, False, None
+        self.payload_floats = int(self.G.numel()) if self.G is not None else 0
+
+    def prepare(self, plans, force_world=None):
+        """Static stream: agree (collectively) on the exchange from the id counts of every rank's resident plans."""
+        world = self.world if force_world is None else force_world
+        if self.tables.optimizer != "Adagrad" or self.exchange == "dense" or (world == 1 and self.exchange != "rows"):
+            return
+        if self.G is None:
+            self.G, self.dense = self.backend.dense_grad_buffer(self.tables), True
+        most = max(sum(self.backend.id_counts(p)) for p in plans)
+        if self.world > 1:
+            t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            most = int(t.item())
+        capacity = 1 + most
+        listed = self.world * capacity * (self.tables.d + 4)
+        if self.exchange == "rows" or listed <= self.G.numel():
+            self.rows = True
+            self.bufs = self.backend.exchange_buffers(self.tables, capacity, self.world)
+            self.payload_floats = listed
+
+    def phases(self):
+        """The step as named pieces [(name, fn(plan))]: what step() runs, in order (bench.py times them apart)."""
+        b, t, h = self.backend, self.tables, self.hyper
+        if not self.dense:
+            return [("step", lambda p: b.step_sparse_adagrad(p, t, h, self.loss_out))]
+        if self.rows:
+            ph = [("passes", lambda p: b.passes(p, t, h)), ("pack_grad", lambda p: b.pack_grad(p, t, h, self.bufs["send"]))]
+            if self.world > 1:
+                ph.append(("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])))
+            else:
+                ph.append(("all_gather", lambda p: self.bufs["recv"][0].copy_(self.bufs["send"])))
+            ph.append(("combine_apply", lambda p: b.apply_gathered(self.bufs, self.world, t, h, self.G, self.loss_out)))
+            return ph
+        ph = [("passes", lambda p: b.passes(p, t, h)), ("dense_grad", lambda p: b.dense_grad(p, t, h, self.G))]
+        if self.world > 1:
+            ph.append(("all_reduce", lambda p: self.dist.all_reduce(self.G)))     # sum over ranks; the tail carries the loss partials
+        ph.append(("dense_apply", lambda p: b.apply_dense(t, h, self.G, self.loss_out)))
+        return ph
 
     def step(self, plan):
-        if not self.dense:
-            self.backend.step_sparse_adagrad(plan, self.tables, self.hyper, self.loss_out)
-            return
-        self.backend.local_dense_grad(plan, self.tables, self.hyper, self.G)
-        if self.world > 1:
-            self.dist.all_reduce(self.G)          # sum over ranks; the tail carries the loss partials
-        self.backend.apply_dense(self.tables, self.hyper, self.G, self.loss_out)
+        for _, fn in self.phases():
+            fn(plan)
 
     def step_many(self, plans):
         """Several consecutive steps; on one GPU they are issued by one C call."""
         if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
             self.backend.steps_sparse_adagrad(plans, self.tables, self.hyper, self.loss_out)
-        elif (self.world == 1 and self.tables.optimizer == "Adam" and hasattr(self.backend, "steps_dense_adam")):
+        elif (self.world == 1 and self.tables.optimizer == "Adam" and not self.rows and hasattr(self.backend, "steps_dense_adam")):
             self.backend.steps_dense_adam(plans, self.tables, self.hyper, self.G, self.loss_out)
         else:
+            ph = self.phases()
             for plan in plans:
-                self.step(plan)
+                for _, fn in ph:
+                    fn(plan)
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
@@ -154,35 +280,175 @@ class RowShardedStepper:
 
       * the row side is completely local: rowpass / colpass, then a sparse Adagrad apply restricted to the
         row side (hyper.sides = 1) — no communication;
-      * the col side is data parallel: the rank's summed col gradients (hyper.sides = 2) go into the
-        contiguous [G_C | G_bc | tail] half of the flat buffer, ONE all-reduce sums it over the ranks, and
-        every rank applies the identical dense update of C, bc and the global bias.
+      * the col side is data parallel: either the rank's summed col gradients (hyper.sides = 2) go into the
+        contiguous [G_C | G_bc | tail] half of the flat buffer, ONE all-reduce sums it over the ranks and every rank
+        applies the identical dense update of C, bc and the global bias (`exchange="dense"`); or the ranks all-gather
+        their packed lists of touched col rows and apply those ("rows": payload ~ distinct col ids of the batches
+        instead of V; "auto" picks it in `prepare(plans)` when the lists are the shorter payload).
 
     With inv_batch = 1 / (world * B) the result equals a single-GPU step on the union of the ranks'
-    batches (tests/test_dp_gloo.py)."""
+    batches (tests/test_dp_gloo.py).  On one rank nothing is exchanged and the step is the plain sparse one."""
 
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, dist):
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, dist, exchange="auto"):
         if tables.optimizer != "Adagrad":
             raise ValueError("the row-sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
+        if exchange not in ("auto", "dense", "rows"):
+            raise ValueError("exchange must be auto, dense or rows")
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
         gb = batch_size * self.world
+        self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
-        self.G = backend.dense_grad_buffer(tables)
+        self.G = backend.dense_grad_buffer(tables) if self.world > 1 else None
+        self.exchange, self.rows, self.bufs = exchange, False, None
+        self.payload_floats = int(backend.col_half(tables, self.G).numel()) if self.G is not None else 0
+
+    def prepare(self, plans):
+        """Static stream: agree (collectively) on the col-side exchange from the col id counts of all resident plans."""
+        if self.world == 1 or self.exchange == "dense":
+            return
+        most = max(self.backend.id_counts(p)[1] for p in plans)
+        t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        capacity = 1 + int(t.item())
+        listed = self.world * capacity * (self.tables.d + 4)
+        if self.exchange == "rows" or listed <= self.backend.col_half(self.tables, self.G).numel():
+            self.rows = True
+            self.bufs = self.backend.exchange_buffers(self.tables, capacity, self.world)
+            self.payload_floats = listed
+
+    def phases(self):
+        b, t = self.backend, self.tables
+        if self.world == 1:
+            return [("step", lambda p: b.step_sparse_adagrad(p, t, self.hyper, self.loss_out))]
+        ph = [("passes", lambda p: b.passes(p, t, self.hyper_cols))]
+        if self.rows:
+            ph += [("pack_grad_cols", lambda p: b.pack_grad(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before any update
+                   ("apply_adagrad_rows", lambda p: b.apply_sparse(p, t, self.hyper_rows)),                   # R, br: local
+                   ("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])),
+                   ("combine_apply_cols", lambda p: b.apply_gathered(self.bufs, self.world, t, self.hyper_cols, self.G,
+                                                                       self.loss_out))]
+        else:
+            ph += [("dense_grad_cols", lambda p: b.dense_grad(p, t, self.hyper_cols, self.G)),   # reads C (activity-L2 term): before any update
+                   ("apply_adagrad_rows", lambda p: b.apply_sparse(p, t, self.hyper_rows)),      # R, br: local, no communication
+                   ("all_reduce", lambda p: self.dist.all_reduce(b.col_half(t, self.G))),
+                   ("dense_adagrad_cols", lambda p: b.apply_dense(t, self.hyper_cols, self.G, self.loss_out))]
+        return ph
 
     def step(self, plan):
-        b, t = self.backend, self.tables
-        b.passes(plan, t, self.hyper_cols)
-        b.dense_grad(plan, t, self.hyper_cols, self.G)        # reads C (activity-L2 term): before any update
-        b.apply_sparse(plan, t, self.hyper_rows)              # R, br: local, no communication
-        if self.world > 1:
-            self.dist.all_reduce(b.col_half(t, self.G))
-        b.apply_dense(t, self.hyper_cols, self.G, self.loss_out)
+        for _, fn in self.phases():
+            fn(plan)
 
     def step_many(self, plans):
+        ph = self.phases()
         for plan in plans:
-            self.step(plan)
+            for _, fn in ph:
+                fn(plan)
+
+    def read_loss(self) -> dict:
+        loss, L, reg, _ = self.loss_out.tolist()
+        return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}
+
+
+class ShardedStepper:
+    """BASELINE config 5 with BOTH tables sharded ("row-embedding table sharded across 8 GPUs with all-to-all token-id
+    routing", SURVEY.md §8e): row u and col v live on ranks u % world and v % world at local index // world, with their
+    Adagrad accumulators; only the global bias is replicated.  Nonzeros are routed to the owners of their ROWS
+    (route_by_row_owner), so the row side of a step is local.  For the col side a rank
+
+      1. receives the col rows its batch touches from their owners (all-to-all; the owners gather them),
+      2. runs the passes against that fetched block — the batch's col ids are renumbered 0 .. n-1 in fetch order,
+      3. returns the summed gradient of every fetched row to its owner (all-to-all of the packed list),
+      4. and, as an owner, adds what the ranks returned for its rows in rank order and applies Adagrad to them.
+
+    Per step and rank that moves 2 x (distinct col ids of its batch) x (d+1) floats, instead of the 2 V (d+1) of the
+    dense all-reduce; the loss partials travel in one 4-float all-reduce.  The result equals a single-GPU step on the
+    union of the ranks' batches.  The stream is static: `add_batch` (collective) prepares a batch once — the fetch
+    lists, what this rank serves, the dedup index on the renumbered ids — and `step` replays it."""
+
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, rank: int, dist):
+        if tables.optimizer != "Adagrad":
+            raise ValueError("the sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
+        self.backend, self.tables, self.world, self.rank, self.dist = backend, tables, int(world), int(rank), dist
+        gb = batch_size * self.world
+        self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
+        self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
+        self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
+        self.batches, self.bufs, self.view, self.owner_state = [], None, None, {}
+
+    def add_batch(self, row, col, w, y, chunk_cap=0) -> int:
+        """row: this rank's LOCAL row indices; col: global col ids.  Collective; returns the batch's handle."""
+        W, dist = self.world, self.dist
+        uc = torch.unique(col.long())                                  # ascending
+        owner = uc % W
+        order = torch.argsort(owner, stable=True)                      # (owner, id) order = fetch order
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        compact = inv[torch.searchsorted(uc, col.long())].to(torch.int32)
+        want = torch.bincount(owner, minlength=W)
+        req = (uc[order] // W).to(torch.int32).contiguous()
+        serve = torch.empty_like(want)
+        if W > 1:
+            dist.all_to_all_single(serve, want)
+        else:
+            serve.copy_(want)
+        want_l, serve_l = [int(x) for x in want.tolist()], [int(x) for x in serve.tolist()]
+        serve_idx = torch.empty(sum(serve_l), dtype=torch.int32, device=req.device)
+        if W > 1:
+            dist.all_to_all_single(serve_idx, req, serve_l, want_l)
+        else:
+            serve_idx.copy_(req)
+        n_uc = int(uc.numel())
+        plan = self.backend.build_plan(row, compact, w, y, max(n_uc, self.tables.V_row), chunk_cap)
+        self.batches.append(dict(plan=plan, want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l)))
+        self.bufs = None                                                 # capacities may have grown
+        return len(self.batches) - 1
+
+    def _ready(self):
+        if self.bufs is None:
+            cap = max(b["n"] for b in self.batches)
+            self.bufs = self.backend.fetch_buffers(self.tables, cap, max(b["ns"] for b in self.batches))
+            self.view = self.backend.col_view(self.tables, self.bufs, cap)
+            self.payload_floats = 2 * cap * (self.tables.d + 1)
+
+    def phases(self):
+        """[(name, fn(batch handle))]."""
+        b, t, dist, W = self.backend, self.tables, self.dist, self.world
+        self._ready()
+        f, bt = self.bufs, self.batches
+
+        def a2a(out, inp, out_split, in_split):
+            if W > 1:
+                dist.all_to_all_single(out, inp, out_split, in_split)
+            else:
+                out.copy_(inp)
+
+        def fetch(i):
+            n, ns = bt[i]["n"], bt[i]["ns"]
+            a2a(f["C"][:n], f["send_rows"][:ns], bt[i]["want"], bt[i]["serve"])
+            a2a(f["bc"][:n], f["send_bias"][:ns], bt[i]["want"], bt[i]["serve"])
+
+        def push(i):
+            n, ns = bt[i]["n"], bt[i]["ns"]
+            a2a(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"], bt[i]["want"])
+            self.tail = f["packed"][0, 2:6].clone()
+            if W > 1:
+                dist.all_reduce(self.tail)
+
+        return [("serve_rows", lambda i: b.gather_rows(t, bt[i]["serve_idx"], f["send_rows"], f["send_bias"])),
+                ("fetch_all_to_all", fetch),
+                ("passes", lambda i: b.passes(bt[i]["plan"], self.view, self.hyper_cols)),
+                ("pack_grad_cols", lambda i: b.pack_grad(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
+                ("apply_adagrad_rows", lambda i: b.apply_sparse(bt[i]["plan"], self.view, self.hyper_rows)),
+                ("push_all_to_all", push),
+                ("owner_apply_cols", lambda i: b.owner_apply(t, self.owner_state, f["recv"], bt[i]["serve_idx"], bt[i]["serve"],
+                                                             self.hyper, self.tail, self.loss_out))]
+
+    def step(self, i: int):
+        for _, fn in self.phases():
+            fn(i)
 
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()

@@ -113,7 +113,8 @@ typedef struct glove_plan {
     int32_t cap_uniq;           /* capacity of the *_uniq_slot arrays minus one */
     int32_t heavy_chunks;       /* ids with more chunks than this go to the `heavy` list (default 8) */
     int32_t cap_heavy;          /* capacity of `heavy` (>= 2 B / (heavy_chunks * chunk_cap) + 2) */
-    int32_t reserved;
+    int32_t V_row;              /* 0, or the number of rows of a row-table shard (glove_tables.V_row): glove_plan_build
+                                 * then treats row ids outside [0, V_row) as id 0, like col ids outside [0, V) */
     int32_t *counts;            /* int32[8]: chunks_row, uniq_row, chunks_col, uniq_col, heavy,
                                  * ids outside [0,V) that were mapped to 0, 0, 0 */
     /* host copy of counts for plans whose build has completed (a resident plan of a static
@@ -207,6 +208,46 @@ int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *
                             float *loss_out, void *stream);
 int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,
                          float *loss_out, void *stream);
+
+/* ---- touched-rows exchange (multi-GPU forms; SURVEY.md §8e "touched-rows exchange") ----------------
+ * Instead of the dense [V,d] buffer a rank hands over ONE packed list per step.  An entry is
+ * glove_packed_entry_floats(d) = d + 4 floats: [summed gradient row, d | bias gradient | id (int bits) |
+ * side (0 row, 1 col; int bits) | 0].  Entry 0 of a list is its header [row entries, col entries (int bits), sum_e,
+ * sum w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, 0...]; the row-side entries follow in plan order (ascending id), then
+ * the col-side entries.  glove_pack_grad_f32 writes the list of one plan (hyper.sides selects the sides; needs
+ * 1 + distinct ids entries of capacity).  It replaces glove_dense_grad_f32 in the data-parallel step whenever the
+ * ranks' lists together are shorter than the dense buffer (an all-gather of lists instead of an all-reduce of
+ * 2 V (d+1) floats), and it is how a rank returns its col gradients to the owners of a sharded col table. */
+size_t glove_packed_entry_floats(int32_t d);
+int glove_pack_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                        void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
+/* One received list.  entries: the first entry behind the header (or a bare run of entries); ids: if not NULL,
+ * ids[i] replaces the id stored in entry i (an owner's local indices); header: if not NULL the entry count is read
+ * from it on the device, otherwise n is the count; side: -1 = every entry names its side, 0 / 1 = all of that side. */
+typedef struct glove_packed_list {
+    const float *entries;
+    const int32_t *ids;
+    const float *header;
+    int32_t n;
+    int32_t side;
+} glove_packed_list;
+/* Adds one list into G_flat (layout of glove_dense_grad_layout): the first list to touch an id stores its row and
+ * leaves tag + 1 in mark[id] (mark: int32[V_row + V], rows first, all zero between steps), later lists add behind
+ * it.  Call once per list, in rank order, on one stream: the sum over ranks then has a fixed order.  G_flat needs no
+ * zeroing.  capacity_entries bounds the entry count of a list whose count lives in its header. */
+int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const glove_tables *t, float *G_flat,
+                             int32_t *mark, int64_t capacity_entries, void *stream);
+/* Adagrad on every id the lists touched (lists[i] was combined with tag i): each id is applied from the list that
+ * touched it first, its mark is cleared.  tail: device float[4] {sum_e, sum w diff^2, sum |r|^2+|c|^2, sum b^2}
+ * already summed over the ranks, or NULL = summed here over the lists' headers in list order.  With the col side
+ * selected (hyper.sides) the call also updates the global bias and writes loss_out. */
+int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lists, const glove_tables *t,
+                                   const glove_hyper *h, float *G_flat, int32_t *mark, const float *tail,
+                                   float *loss_out, int64_t capacity_entries, void *stream);
+/* rows[i] = W[ids[i]] (d floats), biases[i] = bias[ids[i]]: what the owner of a table shard sends to the ranks whose
+ * batches touch those rows (BASELINE config 5 with the col table sharded as well). */
+int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids, int32_t n, int32_t d,
+                          float *rows, float *biases, void *stream);
 
 /* ---- whole step = session.run(train_op) (estimator.py:49-56) ------------------------------ */
 int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,

@@ -45,6 +45,8 @@ class OracleBackend:
 
     def passes(self, plan, tables, hyper):
         row, col, w, y = plan
+        if getattr(tables, "_base", None) is not None:      # a col_view: the global bias lives in the real tables
+            tables.t.g = tables._base.t.g
         self._gr = ref.gradients(tables.t, row, col, w, y, hyper["hp"], inv_batch=hyper["inv_batch"])
 
     def dense_grad(self, plan, tables, hyper, G):
@@ -88,3 +90,96 @@ class OracleBackend:
         row, col, w, y = plan
         loss, L, reg = ref.train_step(tables.t, row, col, w, y, hyper["hp"])
         loss_out[0], loss_out[1], loss_out[2] = loss, L, reg
+
+    # ---- touched-rows exchange (float64 lists; ids travel as float values)
+    def id_counts(self, plan):
+        return len(np.unique(plan[0])), len(np.unique(plan[1]))
+
+    def exchange_buffers(self, tables, capacity, world):
+        d = tables.t.d
+        return dict(send=torch.zeros(capacity, d + 4, dtype=torch.float64),
+                    recv=torch.zeros(world, capacity, d + 4, dtype=torch.float64), mark=None, capacity=capacity)
+
+    def pack_grad(self, plan, tables, hyper, send):
+        gr, d, out = self._gr, tables.t.d, send.numpy()
+        out[:] = 0
+        k = 1
+        n = [0, 0]
+        for side, bit, G, Gb, touched in ((0, 1, "G_R", "G_br", "touched_r"), (1, 2, "G_C", "G_bc", "touched_c")):
+            if not hyper["sides"] & bit:
+                continue
+            ids = np.flatnonzero(gr[touched])
+            n[side] = len(ids)
+            out[k:k + len(ids), :d] = gr[G][ids]
+            out[k:k + len(ids), d] = gr[Gb][ids]
+            out[k:k + len(ids), d + 1] = ids
+            out[k:k + len(ids), d + 2] = side
+            k += len(ids)
+        out[0, :2] = n
+        if hyper["sides"] & 2:
+            out[0, 2] = gr["sum_e"]
+            out[0, 3] = gr["L"] / hyper["inv_batch"]
+
+    def _apply_lists(self, t, hp, lists, sides, tail, loss_out, inv_batch):
+        """lists: [(entries [n, d+4], ids or None, fixed side or None)] in rank order: sum in that order, then apply."""
+        d = t.d
+        G = {0: {}, 1: {}}
+        for entries, ids, side in lists:
+            for i, e in enumerate(entries):
+                key = int(ids[i]) if ids is not None else int(e[d + 1])
+                sd = side if side is not None else int(e[d + 2])
+                if key in G[sd]:
+                    G[sd][key] = (G[sd][key][0] + e[:d], G[sd][key][1] + e[d])
+                else:
+                    G[sd][key] = (e[:d].copy(), e[d])
+        lr, eps = t.dtype(np.float32(hp.learning_rate)), t.dtype(np.float32(hp.epsilon))
+        for sd, W, A, b, Ab in ((0, t.R, t.A_R, t.br, t.A_br), (1, t.C, t.A_C, t.bc, t.A_bc)):
+            for key, (g, gb) in G[sd].items():
+                A[key] += g * g
+                W[key] -= lr * g / (np.sqrt(A[key]) + eps)
+                Ab[key] += gb * gb
+                b[key] -= lr * gb / (np.sqrt(Ab[key]) + eps)
+        if sides & 2:
+            dg = tail[0] + 2.0 * hp.reg_mult * hp.l2_reg * t.g
+            t.A_g = t.A_g + dg * dg
+            t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
+            loss_out[1] = tail[1] * inv_batch
+            t.step += 1
+
+    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out):
+        recv = bufs["recv"].numpy()
+        lists, tail = [], np.zeros(2)
+        for r in range(world):
+            n = int(recv[r, 0, 0] + recv[r, 0, 1])
+            lists.append((recv[r, 1:1 + n], None, None))
+            tail += recv[r, 0, 2:4]
+        self._apply_lists(tables.t, hyper["hp"], lists, hyper["sides"], tail, loss_out, hyper["inv_batch"])
+
+    # ---- both tables sharded
+    def gather_rows(self, tables, idx, rows, biases):
+        i = idx.numpy()
+        rows.numpy()[:len(i)] = tables.t.C[i]
+        biases.numpy()[:len(i)] = tables.t.bc[i]
+
+    def fetch_buffers(self, tables, capacity, serve_capacity):
+        d, f64 = tables.t.d, dict(dtype=torch.float64)
+        return dict(C=torch.zeros(max(capacity, 1), d, **f64), bc=torch.zeros(max(capacity, 1), **f64),
+                    send_rows=torch.zeros(max(serve_capacity, 1), d, **f64), send_bias=torch.zeros(max(serve_capacity, 1), **f64),
+                    packed=torch.zeros(1 + capacity, d + 4, **f64), recv=torch.zeros(max(serve_capacity, 1), d + 4, **f64))
+
+    def col_view(self, tables, bufs, capacity):
+        import copy
+        v = copy.copy(tables.t)                       # shares R, br and their accumulators with the real shard
+        v.C, v.bc = bufs["C"].numpy(), bufs["bc"].numpy()
+        view = OracleTables.__new__(OracleTables)
+        view.t, view.device, view.optimizer = v, tables.device, tables.optimizer
+        view.V, view.d, view.V_row = len(v.C), v.d, len(v.R)
+        view._base = tables
+        return view
+
+    def owner_apply(self, tables, state, recv, ids, counts, hyper, tail, loss_out):
+        r, i, lists, off = recv.numpy(), ids.numpy(), [], 0
+        for n in counts:
+            lists.append((r[off:off + n], i[off:off + n], 1))
+            off += n
+        self._apply_lists(tables.t, hyper["hp"], lists, 3, tail.numpy(), loss_out, hyper["inv_batch"])

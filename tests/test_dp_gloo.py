@@ -24,7 +24,7 @@ def _batches():
     return [[make_batch(100 * s + r, B, V) for r in range(WORLD)] for s in range(STEPS)]
 
 
-def _worker(rank, port, optimizer, out_dir):
+def _worker(rank, port, optimizer, out_dir, exchange="dense"):
     for p in (HERE.parent, HERE.parent / "oracle", HERE):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
@@ -34,21 +34,27 @@ def _worker(rank, port, optimizer, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     tables = OracleTables(ref.Tables(V, D, optimizer, dtype=np.float64, seed=3))
     backend = OracleBackend()
-    stepper = Stepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist)
+    stepper = Stepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist, exchange=exchange)
     assert stepper.dense and abs(stepper.hyper["inv_batch"] - 1.0 / (WORLD * B)) < 1e-15
-    for step_batches in _batches():
-        stepper.step(backend.build_plan(*step_batches[rank], V, 32))
+    plans = [backend.build_plan(*step_batches[rank], V, 32) for step_batches in _batches()]
+    stepper.prepare(plans)                       # collective: the ranks agree on the exchange
+    assert stepper.rows == (exchange == "rows") and [n for n, _ in stepper.phases()].count("all_gather") == int(stepper.rows)
+    if exchange == "auto":                       # 2 x ~80 ids x (d+4) floats against 2 V (d+1): dense is the shorter payload here
+        assert not stepper.rows
+    for plan in plans:
+        stepper.step(plan)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), R=tables.t.R, C=tables.t.C, br=tables.t.br,
              bc=tables.t.bc, g=tables.t.g, step=tables.t.step)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
-def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer):
+@pytest.mark.parametrize("optimizer,exchange", [("Adagrad", "dense"), ("Adam", "dense"), ("Adagrad", "rows"), ("Adagrad", "auto")])
+def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer, exchange):
+    """Dense all-reduce and touched-rows all-gather: either way two ranks == one rank on the joint batch."""
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 29500 + os.getpid() % 2000 + (0 if optimizer == "Adagrad" else 1)
-    mp.spawn(_worker, args=(port, optimizer, str(tmp_path)), nprocs=WORLD, join=True)
+    port = 29500 + os.getpid() % 2000 + ["dense", "rows", "auto"].index(exchange) * 2 + (0 if optimizer == "Adagrad" else 1)
+    mp.spawn(_worker, args=(port, optimizer, str(tmp_path), exchange), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, optimizer, dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
     for step_batches in _batches():
@@ -62,7 +68,7 @@ def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer):
 
 
 # ---- BASELINE config 5: row table sharded over the ranks, nonzeros routed to the owners of their rows
-def _sharded_worker(rank, port, out_dir):
+def _sharded_worker(rank, port, out_dir, exchange="dense"):
     for p in (HERE.parent, HERE.parent / "oracle", HERE):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
@@ -77,25 +83,31 @@ def _sharded_worker(rank, port, out_dir):
         setattr(shard, n, getattr(full, n)[rank::WORLD].copy())
     tables = OracleTables(shard)
     backend = OracleBackend()
-    stepper = RowShardedStepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist)
-    routed_sizes = []
+    stepper = RowShardedStepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist,
+                                exchange=exchange)
+    routed_sizes, plans = [], []
     for step_batches in _batches():
         mine = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in zip(("row", "col", "w", "y"), step_batches[rank])}
         routed = route_by_row_owner(mine, WORLD, rank, dist)
         routed_sizes.append(int(routed["row"].numel()))
         assert int(routed["row"].max()) < tables.V_row
-        stepper.step(backend.build_plan(routed["row"].numpy(), routed["col"].numpy(), routed["w"].numpy(),
+        plans.append(backend.build_plan(routed["row"].numpy(), routed["col"].numpy(), routed["w"].numpy(),
                                         routed["y"].numpy(), V, 32))
+    stepper.prepare(plans)
+    assert stepper.rows == (exchange == "rows")
+    for plan in plans:
+        stepper.step(plan)
     np.savez(os.path.join(out_dir, "shard%d.npz" % rank), R=shard.R, br=shard.br, C=shard.C, bc=shard.bc, g=shard.g,
              sizes=np.asarray(routed_sizes))
     dist.destroy_process_group()
 
 
-def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
+@pytest.mark.parametrize("exchange", ["dense", "rows"])
+def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path, exchange):
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 31500 + os.getpid() % 2000
-    mp.spawn(_sharded_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    port = 31500 + os.getpid() % 2000 + (exchange == "rows")
+    mp.spawn(_sharded_worker, args=(port, str(tmp_path), exchange), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
     for step_batches in _batches():
@@ -109,3 +121,48 @@ def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
         np.testing.assert_allclose(s["bc"], t.bc, rtol=1e-10, atol=1e-13)
         np.testing.assert_allclose(s["g"], t.g, rtol=1e-10)
     np.testing.assert_array_equal(shards[0]["C"], shards[1]["C"])
+
+
+# ---- BASELINE config 5, both tables sharded: col rows fetched from / returned to their owners by all-to-all
+def _fully_sharded_worker(rank, port, out_dir):
+    for p in (HERE.parent, HERE.parent / "oracle", HERE):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import glove_ref as ref
+    from oracle_backend import OracleBackend, OracleTables
+    from trainer.stepper import ShardedStepper, route_by_row_owner
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    full = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    shard = full.copy()
+    for n in ("R", "br", "A_R", "A_br", "C", "bc", "A_C", "A_bc"):     # rows AND cols: id % world == rank, local index id // world
+        setattr(shard, n, getattr(full, n)[rank::WORLD].copy())
+    tables = OracleTables(shard)
+    backend = OracleBackend()
+    stepper = ShardedStepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, rank, dist)
+    handles = []
+    for step_batches in _batches():
+        mine = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in zip(("row", "col", "w", "y"), step_batches[rank])}
+        routed = route_by_row_owner(mine, WORLD, rank, dist)
+        handles.append(stepper.add_batch(routed["row"], routed["col"], routed["w"], routed["y"], 32))
+    for h in handles:
+        stepper.step(h)
+    np.savez(os.path.join(out_dir, "full%d.npz" % rank), R=shard.R, br=shard.br, C=shard.C, bc=shard.bc, g=shard.g,
+             A_C=shard.A_C, step=shard.step)
+    dist.destroy_process_group()
+
+
+def test_fully_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
+    sys.path.insert(0, str(HERE.parent / "oracle"))
+    import glove_ref as ref
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_fully_sharded_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    hp = ref.Hyper(learning_rate=0.05)
+    for step_batches in _batches():
+        ref.train_step(t, *[np.concatenate([b[i] for b in step_batches]) for i in range(4)], hp)
+    shards = [np.load(tmp_path / ("full%d.npz" % r)) for r in range(WORLD)]
+    for r, s in enumerate(shards):
+        for n in ("R", "br", "C", "bc", "A_C"):
+            np.testing.assert_allclose(s[n], getattr(t, n)[r::WORLD], rtol=1e-10, atol=1e-13, err_msg=n)
+        np.testing.assert_allclose(s["g"], t.g, rtol=1e-10)
+        assert int(s["step"]) == STEPS
