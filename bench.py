@@ -3,24 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload text8_d64] [--batch-size B]
 
-A "step" is one optimizer step (the fused forward+gradient pass kernel + the sparse Adagrad apply kernel) over one
-batch of B synthetic co-occurrence nonzeros that are already resident in HBM together with
-their dedup index (DESIGN.md "Data layout"; the index of a static stream is built once at load
-time, `--dynamic` puts the index build of every batch inside the timed region instead).
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own shard of
-nonzeros, computes the summed gradients of its batch into a dense buffer, the buffers are
-all-reduced over RCCL and every rank applies the identical dense Adagrad update
-(global batch = N * B, weak scaling).
+A "step" is one optimizer step over one batch of B synthetic co-occurrence nonzeros that are already resident in HBM
+together with their dedup index (DESIGN.md "Data layout"; the index of a static stream is built once at load time,
+`--dynamic` puts the index build of every batch inside the timed region instead).
 
-Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is measured live
-with HIP events on the launch stream in a second, instrumented pass over the same batches;
-`cpu_baseline` times the scalar C port of the oracle (oracle/glove_ref.c) on a bounded sample.
+N = 1: the sparse Adagrad step (fused forward+gradient pass kernel(s) + apply kernel; glove_step_adagrad_f32 picks the
+form).  The headline is BASELINE.json's configs[1] (text8, d = 64, Adagrad); unless `--single` is given the same JSON
+line also carries `configs`: the HBM-bound workloads (V = 50 k and V = 400 k at d = 300, V = 2 M at d = 128) and the
+reference's default shape (Keras-legacy Adam, batch 1,024), each with its own roofline.
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child process; under a launcher it
+is a rank).  Every rank owns its own shard of nonzeros; per step the ranks exchange either the dense gradient buffer
+(all-reduce) or their packed lists of touched rows (all-gather), whichever is the shorter payload for the resident
+batches, and apply the identical update (global batch = N * B, weak scaling).  `configs` then carries the V = 400 k
+data-parallel run and the V = 2 M run with both tables sharded (all-to-all of the touched col rows).
+
+Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is measured live with HIP events on the
+launch stream in a second, instrumented pass over the same batches; `cpu_baseline` times the C port of the oracle
+(oracle/glove_ref.c: all cores with OpenMP, and one core) on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,39 +40,84 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+HBM_STREAM_GBS = 6290.0        # measured float4-copy ceiling of the same guide (BASELINE.md §3 asks for both)
+WORKLOADS = ["text8_d64", "text8_v50k_d300", "zipf_v400k_d300", "zipf_v2m_d128"]
+DATA_NOTE = {"text8_d64": "synthetic (text8-shaped Poisson model of the reference's data prep: 17 M-token Zipf corpus, "
+                          "window 5, count >= 10; no text8 on disk)",
+             "text8_v50k_d300": "synthetic (Zipf(1.0) ids over V = 50,000, SURVEY.md §8d generator)",
+             "zipf_v400k_d300": "synthetic (Zipf(1.0) ids over V = 400,000, 25 M nonzeros = one GPU's shard of config 4)",
+             "zipf_v2m_d128": "synthetic (Zipf(1.0) ids over V = 2,000,000, 25 M nonzeros = one GPU's shard of config 5)"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="text8_d64", choices=["text8_d64", "text8_v50k_d300", "zipf_v400k_d300", "zipf_v2m_d128"])
+    ap.add_argument("--workload", default="text8_d64", choices=WORKLOADS)
     ap.add_argument("--row-sharded", action="store_true",
-                    help="BASELINE config 5: row table sharded by id %% N, nonzeros routed to row owners (all-to-all at load), "
-                         "col side data parallel")
+                    help="BASELINE config 5: both tables sharded by id %% N, nonzeros routed to row owners (all-to-all at "
+                         "load), touched col rows fetched from / returned to their owners every step")
+    ap.add_argument("--cols-replicated", action="store_true",
+                    help="with --row-sharded: keep the col table replicated (RowShardedStepper: col side data parallel)")
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--chunk-cap", type=int, default=0, help="0 = auto (hip_api.auto_chunk_cap)")
-    ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form (dense gradient buffer + all-reduce) also on one GPU")
+    ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form also on one GPU")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "rows"],
+                    help="multi-rank gradient exchange: dense all-reduce, all-gather of touched-row lists, or the shorter payload")
     ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad", "Adam"],
                     help="Adam = Keras-legacy dense-decay Adam (config 1 of BASELINE.json), single GPU only")
     ap.add_argument("--learning-rate", type=float, default=0.05)
+    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches")
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
     ap.add_argument("--build-ahead", type=int, default=1,
                     help="with --dynamic: index builds in flight (each on its own stream and staging plan), the way an "
                          "input pipeline prefetches batches; 1 = build and step strictly alternate on one stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of all CPU legs together")
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
-    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches")
     ap.add_argument("--single", action="store_true", help="only the named workload (no configs[] array)")
+    ap.add_argument("--min-timed-ms", type=float, default=20.0,
+                    help="the timed region of --steps steps is repeated until this much time has been measured; the "
+                         "median repeat is reported")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="control-flow rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 and the "
                          "collectives go through gloo; its numbers mean nothing")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def launcher_argv(n: int, argv: list, port: int) -> list:
+    """The command that runs this file as n ranks of ONE node (the form the task contract names)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this process has not
+    touched the GPU and never will), relay rank 0's JSON line, return the child's exit code."""
+    proc = subprocess.run(launcher_argv(n, argv, free_port()), stdout=subprocess.PIPE, text=True, cwd=str(REPO))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print("expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return proc.returncode
+
+
+# ------------------------------------------------------------------------------------------------ figures
 def algorithmic_bytes_adam(B, V, d):
     """Keras-legacy Adam sweeps W, m, v (read + write) of both tables and bias vectors
     every step, independent of the batch, plus the nonzero stream."""
@@ -93,98 +146,126 @@ def measured_traffic(workload, B, cap):
     return None, None
 
 
-def cpu_baseline(workload, B, hp_kwargs, seconds, optimizer="Adagrad"):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def cpu_leg(wl, B, optimizer, lr, seconds, threads):
+    """oracle/glove_ref.c on a bounded sample of the SAME batches: `threads` = 1 is the scalar port, otherwise the
+    OpenMP form (ids grouped per batch at load like the GPU's resident index, outside the clock)."""
     sys.path.insert(0, str(REPO / "oracle"))
     import numpy as np
     import glove_ref as ref
     import glove_ref_c
-    t = ref.Tables(workload["V"], workload["d"], optimizer, dtype=np.float32, seed=1)
+    V, d = wl["V"], wl["d"]
+    t = ref.Tables(V, d, optimizer, dtype=np.float32, seed=1)
     port = glove_ref_c.CPort(t, B)
-    hp = ref.Hyper(**hp_kwargs)
-    row, col = workload["row"].cpu().numpy(), workload["col"].cpu().numpy()
-    w, y = workload["w"].cpu().numpy(), workload["y"].cpu().numpy()
-    nb = max(1, len(row) // B)
-    port.step(row[:B], col[:B], w[:B], y[:B], hp)            # warm
+    hp = ref.Hyper(learning_rate=lr)
+    nb = max(1, min(4, wl["row"].numel() // B))
+    host = {k: wl[k][:nb * B].cpu().numpy() for k in ("row", "col", "w", "y")}
+    bt = [tuple(host[k][b * B:(b + 1) * B] for k in ("row", "col", "w", "y")) for b in range(nb)]
+    mt = threads != 1
+    idx = [glove_ref_c.BatchIndex(b[0], b[1], d) for b in bt] if mt else None
+    n_threads = port.max_threads() if threads == 0 else threads
+
+    def one(i):
+        if mt:
+            port.step_mt(idx[i % nb], *bt[i % nb], hp, threads=n_threads)
+        else:
+            port.step(*bt[i % nb], hp)
+    one(0)                                                   # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        b = n % nb
-        s = slice(b * B, (b + 1) * B)
-        port.step(row[s], col[s], w[s], y[s], hp)
+        one(n)
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 2000:
+        if el >= seconds or n >= 5000:
             break
-    cpu_model = ""
+    return {"value": n * B / el, "unit": "nonzeros/s", "steps_per_s": n / el, "cores": n_threads if mt else 1, "kind": "port",
+            "sample": "%d %s steps of %d nonzeros in %.1f s (same batches; oracle/glove_ref.c, gcc -O2 fp32%s)" % (
+                n, optimizer, B, el, ", OpenMP" if mt else ", scalar")}
+
+
+def cpu_baseline(ctx, head_wl, head_B, lr, seconds):
+    """CPU-2 = Adagrad at the GPU run's batch size and (V, d), all cores; CPU-1 = config 1
+    (Adam dense-decay, batch 1,024, text8 shape), all cores; plus the one-core scalar figures for scale."""
+    legs = {}
+    budget = max(seconds, 0.9)
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": n * B / el, "unit": "nonzeros/s", "cores": 1, "kind": "port",
-            "sample": "%d %s steps of %d nonzeros (same batches, oracle/glove_ref.c, -O2 scalar fp32)" % (n, optimizer, B),
-            "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        legs["adagrad_at_gpu_batch"] = cpu_leg(head_wl, head_B, "Adagrad", lr, budget * 0.4, 0)
+        legs["adagrad_at_gpu_batch_one_core"] = cpu_leg(head_wl, head_B, "Adagrad", lr, budget * 0.2, 1)
+        c1 = ctx.workload("text8_d64")
+        legs["c1_adam_bs1024"] = cpu_leg(c1, 1024, "Adam", 0.001, budget * 0.3, 0)
+        legs["c1_adam_bs1024_one_core"] = cpu_leg(c1, 1024, "Adam", 0.001, budget * 0.1, 1)
+    except Exception as exc:                     # the baseline is a side measurement: never lose the bench line to it
+        legs["error"] = "%s: %s" % (type(exc).__name__, exc)
+    main = legs.get("adagrad_at_gpu_batch", {"value": None, "unit": "nonzeros/s", "cores": 0, "kind": "port", "sample": "failed"})
+    out = dict(main)
+    out.update(host_cpus=os.cpu_count(), cpu_model=cpu_model(), legs=legs,
+               label="CPU restatement of yxtay/glove-tensorflow estimator step (TF 2.11 unavailable offline)")
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    dense = world > 1 or args.force_dense or args.row_sharded
-    adam = args.optimizer == "Adam"
-    if adam and dense:
+# ------------------------------------------------------------------------------------------------ one configuration
+class Ctx:
+    def __init__(self, args, world, rank, dev, dist, hip):
+        self.args, self.world, self.rank, self.dev, self.dist, self.hip = args, world, rank, dev, dist, hip
+        self._wl = {}
+
+    def workload(self, name):
+        from trainer import synthetic
+        if name not in self._wl:
+            self._wl = {}                        # one resident workload at a time
+            self._wl[name] = synthetic.make_workload(name, seed=self.rank, device=self.dev, work_device=self.dev)
+        return self._wl[name]
+
+    def barrier(self):
+        if self.dist is not None and self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+
+def steps_per_graph(steps: int) -> int:
+    """Largest divisor of `steps` that is at most 64: the timed region is then a whole number of graph replays."""
+    for k in range(min(64, steps), 0, -1):
+        if steps % k == 0:
+            return k
+    return 1
+
+
+def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, warmup=20, lr=0.05, chunk_cap=0,
+               step_form=0, exchange="auto", dynamic=False, build_ahead=1, no_graph=False, max_batches=64,
+               min_timed_ms=20.0):
+    """mode: "auto" (single-GPU sparse step on one rank, data parallel on several), "dp" (data-parallel form also on
+    one rank), "sharded" (both tables sharded), "rowsharded" (row table sharded, col side data parallel)."""
+    from trainer.hip_api import FUSED_STEP_BYTES, DeviceTables, auto_chunk_cap, make_hyper
+    from trainer.stepper import HipBackend, RowShardedStepper, ShardedStepper, Stepper, owned_rows, route_by_row_owner
+    hip, dev, dist, world, rank = ctx.hip, ctx.dev, ctx.dist, ctx.world, ctx.rank
+    adam = optimizer == "Adam"
+    if mode == "auto":
+        mode = "dp" if world > 1 else "single"
+    if adam and mode != "single":
         raise SystemExit("--optimizer Adam is benchmarked on one GPU")
-    if dense:
-        import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:      # --force-dense on a single GPU without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    from trainer import hip_api, synthetic
-    if not hip_api.LIB_PATH.exists():
-        # sources arrived without the built library: the first local rank compiles it (hipcc is part of the image),
-        # the others wait for the file; a failing build ends the run
-        if local_rank == 0 or args.rehearse_on_one_gpu and rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        for _ in range(600):
-            if hip_api.LIB_PATH.exists():
-                break
-            time.sleep(1.0)
-    from trainer.hip_api import DeviceTables, GloveHip, make_hyper
-
-    hip = GloveHip(dev)
-    B = args.batch_size
-    wl = synthetic.make_workload(args.workload, seed=rank, device=dev, work_device=dev)
+    wl = ctx.workload(workload)
     V, d = wl["V"], wl["d"]
-    V_row = V
-    if args.row_sharded:
-        from trainer.stepper import owned_rows, route_by_row_owner
+    coo = {k: wl[k] for k in ("row", "col", "w", "y")}
+    V_row = V_col = V
+    if mode in ("sharded", "rowsharded"):
         V_row = owned_rows(V, world, rank)
-        wl.update(route_by_row_owner({k: wl[k] for k in ("row", "col", "w", "y")}, world, rank, dist))
-    from trainer.hip_api import auto_chunk_cap
-    cap = args.chunk_cap or auto_chunk_cap(B, V)
-    nnz = wl["row"].numel()
-    nb = min(max(1, nnz // B), args.max_batches)
+        V_col = V_row if mode == "sharded" else V
+        if world > 1:
+            coo = route_by_row_owner(coo, world, rank, dist)
+    cap = chunk_cap or auto_chunk_cap(B, V, (d + 3) // 4 * 4)
+    nnz = coo["row"].numel()
     if nnz < B:
         raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))
+    nb = min(max(1, nnz // B), max_batches)
     if dist is not None and world > 1:
         # every rank's shard has its own nonzero count: agree on the number of resident batches, so that all
         # ranks issue the same number of collectives in every loop below
@@ -192,35 +273,50 @@ def main():
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         nb = int(agreed.item())
 
+    tables = DeviceTables(V, d, optimizer, device=dev, seed=1, V_row=V_row, V_col=V_col)   # identical replicas on every rank
+    backend = HipBackend(dev)
+    backend.hip = hip
+    backend.row_floats = tables.d
+    hyper_kw = dict(learning_rate=lr, step_form=step_form)
+
     # ---- load time (untimed): resident batches + their dedup index
-    batches, plans = [], []
-    for b in range(nb):
-        s = slice(b * B, (b + 1) * B)
-        batches.append(tuple(wl[k][s].contiguous() for k in ("row", "col", "w", "y")))
+    batches = [tuple(coo[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")) for b in range(nb)]
     t0 = time.perf_counter()
-    for bt in batches:
-        plans.append(hip.build_plan(*bt, V, chunk_cap=cap, compact=True))
+    stepper = None
+    if mode == "sharded":
+        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist)
+        handles = [stepper.add_batch(*bt, cap) for bt in batches]
+        plans = [stepper.batches[h]["plan"] for h in handles]
+    else:
+        plans = [hip.build_plan(*bt, V, chunk_cap=cap, compact=True, d=tables.d, V_row=V_row if V_row < V else 0)
+                 for bt in batches]
+        handles = plans
     torch.cuda.synchronize()
     plan_build_ms = (time.perf_counter() - t0) * 1e3 / nb
-    counts = [p.counts.tolist() for p in plans]
+    counts = [p.host_counts for p in plans]
     n_heavy = sum(c[4] for c in counts) / nb
     u_row = sum(c[1] for c in counts) / nb
     u_col = sum(c[3] for c in counts) / nb
     chunks = sum(c[0] + c[2] for c in counts) / nb
+    if mode == "rowsharded":
+        stepper = RowShardedStepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange)
+        stepper.prepare(plans)
+    elif mode == "dp":
+        stepper = Stepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange)
+        if world == 1:
+            stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
+        stepper.prepare(plans)
 
-    tables = DeviceTables(V, d, args.optimizer, device=dev, seed=1, V_row=V_row)      # identical replicas on every rank
-    hyper = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, step_form=args.step_form)
-    ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, d) for p in plans) if not args.dynamic
-                     else hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
-    loss_out = torch.zeros(4, device=dev)
-    G = hip.dense_grad_buffer(tables) if dense or adam else None
-    if args.row_sharded:
-        hyper_rows = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, sides=1)
-        hyper_cols = make_hyper(learning_rate=args.learning_rate, batch_size=B * world, sides=2)
-        G_col_half = G[hip.grad_layout(tables)["G_C"]:]
+    hyper = make_hyper(batch_size=B * world, **hyper_kw)
+    loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, device=dev)
+    ws = None
+    G = hip.dense_grad_buffer(tables) if adam else None
+    if mode == "single":
+        ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, tables.d) for p in plans) if not dynamic
+                         else hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
 
-    staging = hip.build_plan(*batches[0], V, chunk_cap=cap) if args.dynamic else None   # refilled every step
-    ahead = max(1, args.build_ahead) if args.dynamic else 1
+    staging = hip.build_plan(*batches[0], V, chunk_cap=cap) if dynamic else None   # refilled every step
+    ahead = max(1, build_ahead) if dynamic else 1
     if ahead > 1:
         # a ring of staging plans, scratch buffers and streams: the index of batch i is built on stream i % ahead
         # while earlier steps run; it may start once step i - ahead, the previous reader of its staging plan, is done
@@ -253,41 +349,23 @@ def main():
                 launch_build(i + ahead)
 
     def step(i):
-        bt = batches[i % nb]
-        plan = hip.build_plan(*bt, V, chunk_cap=cap, into=staging) if args.dynamic else plans[i % nb]
+        if stepper is not None:
+            stepper.step(handles[i % nb])
+            return
+        plan = hip.build_plan(*batches[i % nb], V, chunk_cap=cap, into=staging) if dynamic else plans[i % nb]
         if adam:
             hip.step_adam(plan, tables, hyper, G, loss_out, ws)
-        elif not dense:
-            hip.step_adagrad(plan, tables, hyper, loss_out, ws)
-        elif args.row_sharded:
-            hip.passes(plan, tables, hyper, ws)
-            hip.dense_grad(plan, tables, hyper_cols, G, ws)
-            hip.apply_adagrad(plan, tables, hyper_rows, None, ws)
-            dist.all_reduce(G_col_half)
-            hip.dense_adagrad(tables, hyper_cols, G, loss_out)
         else:
-            hip.passes(plan, tables, hyper, ws)
-            hip.dense_grad(plan, tables, hyper, G, ws)
-            dist.all_reduce(G)
-            hip.dense_adagrad(tables, hyper, G, loss_out)
+            hip.step_adagrad(plan, tables, hyper, loss_out, ws)
 
-    def barrier():
-        if dense:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # One hipGraph holds whole sweeps over the resident batches (spg steps); it is replayed
-    # steps // spg times and the remainder runs eagerly, so exactly `steps` steps are timed.
-    use_graph = not dense and not args.no_graph
-    graph = None
-    spg = nb * ((16 + nb - 1) // nb)          # steps per graph: whole sweeps, at least 16 steps per replay
-    if args.dynamic and args.build_ahead > 1:
-        spg = nb * ((96 + nb - 1) // nb)      # the build pipeline fills and drains once per replay: longer graphs
+    # One hipGraph holds `spg` consecutive steps, a divisor of --steps: the timed region is a whole number of replays.
+    use_graph = mode == "single" and not no_graph
+    graph, spg = None, steps_per_graph(steps)
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for i in range(nb):
+            for i in range(min(nb, 4)):
                 step(i)                       # warm the launch path on the capture stream
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -308,55 +386,71 @@ def main():
         for i in range(done, n_steps):
             step(first + i)
 
-    run(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    run(warmup, 0)
+    # the timed region: exactly `steps` steps between barrier + synchronize on both sides, MAX over ranks; repeated
+    # until at least min_timed_ms have been measured (a single transient cannot swing the figure), median reported
+    elapsed_all, total = [], 0.0
+    while True:
+        ctx.barrier()
+        t0 = time.perf_counter()
+        run(steps, warmup)
+        ctx.barrier()
+        el = time.perf_counter() - t0
+        stop = torch.tensor([el, 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            el = float(stop[0].item())
+        elapsed_all.append(el)
+        total += el
+        if total * 1e3 >= min_timed_ms or len(elapsed_all) >= 50:       # every rank sees the same MAX: same decision
+            break
+    elapsed = statistics.median(elapsed_all)
     final_loss = float(loss_out[0].item())
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
 
     # ---- instrumented pass: HIP events (on the launch stream) around `reps` back-to-back launches of
-    # each kernel of the step over the same resident batches; per-launch time = span / reps (it includes
+    # each piece of the step over the same resident batches; per-launch time = span / reps (it includes
     # the ~1-2 us launch-to-launch gap that rocprofv3's per-kernel durations exclude)
-    kern = {}
-    reps = max(nb, min(200, args.steps))
-    calls = {"passes": lambda p: hip.passes(p, tables, hyper, ws)}      # row side + col side, one launch
-    adam_fused = adam and 2 * B <= V_row + V          # glove_step_adam_f32's own rule (include/glove_hip.h)
-    if adam_fused:
-        # passes (+ id marks) and ONE fused apply/decay kernel; the second kernel has no entry point of its own,
-        # so it is timed as the whole step minus the passes
-        calls["step_adam"] = lambda p: hip.step_adam(p, tables, hyper, G, loss_out, ws)
-    elif adam:
-        calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
-        calls["dense_adam"] = lambda p: hip.dense_adam(tables, hyper, G, loss_out)
-    elif not dense:
-        calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
+    reps = max(min(nb, 8), min(200, steps))
+    if stepper is not None:
+        calls = dict(stepper.phases())
+        items = handles
     else:
-        if args.row_sharded:
-            calls["dense_grad_cols"] = lambda p: hip.dense_grad(p, tables, hyper_cols, G, ws)
-            calls["apply_adagrad_rows"] = lambda p: hip.apply_adagrad(p, tables, hyper_rows, None, ws)
-            calls["all_reduce"] = lambda p: dist.all_reduce(G_col_half)    # RCCL over xGMI, broken out
-            calls["dense_adagrad_cols"] = lambda p: hip.dense_adagrad(tables, hyper_cols, G, loss_out)
+        items = plans
+        form = step_form
+        calls = {}
+        if adam:
+            adam_fused = 2 * B <= V_row + V          # glove_step_adam_f32's own rule (include/glove_hip.h)
+            calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)
+            if adam_fused:
+                # passes (+ id marks) and ONE fused apply/decay kernel; the second kernel has no entry point of its own,
+                # so it is timed as the whole step minus the passes
+                calls["step_adam"] = lambda p: hip.step_adam(p, tables, hyper, G, loss_out, ws)
+            else:
+                calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
+                calls["dense_adam"] = lambda p: hip.dense_adam(tables, hyper, G, loss_out)
         else:
-            calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
-            calls["all_reduce"] = lambda p: dist.all_reduce(G)             # RCCL over xGMI, broken out
-            calls["dense_adagrad"] = lambda p: hip.dense_adagrad(tables, hyper, G, loss_out)
+            fused_auto = plans[0].r_crec is not None and (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES
+            if form == 0:
+                form = 3 if fused_auto else 1
+            if form == 1 or plans[0].r_crec is None:
+                calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)      # row side + col side, one launch
+                calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
+            else:
+                # the fused forms have no entry points per launch: the step is timed whole (rocprofv3 splits it:
+                # profiles/*_kernel_stats.txt)
+                calls["step_fused_form_%d" % form] = lambda p: hip.step_adagrad(p, tables, hyper, loss_out, ws)
+    kern = {}
     for name, fn in calls.items():
-        for i in range(2 * nb):
-            fn(plans[i % nb])
+        for i in range(min(2 * nb, 8)):
+            fn(items[i % nb])
         torch.cuda.synchronize()
 
         def burst(fn=fn):
             for i in range(reps):
-                fn(plans[i % nb])
-        if not dense:                         # replayed from a hipGraph, so that a kernel shorter than the host's
+                fn(items[i % nb])
+        if mode == "single":                  # replayed from a hipGraph, so that a kernel shorter than the host's
             kg = torch.cuda.CUDAGraph()       # per-call cost (small batches) is still timed on the GPU's clock
             with torch.cuda.graph(kg):
                 burst()
@@ -371,15 +465,13 @@ def main():
             torch.cuda.synchronize()
             spans.append(a.elapsed_time(b) * 1e3 / reps)
         kern[name] = sorted(spans)[1]
-    if adam_fused:
+    if "step_adam" in kern:
         kern["adam_fused"] = kern.pop("step_adam") - kern["passes"]
-    if G is not None:
-        G.zero_()
-    # attribution of the algorithmic bytes to the two kernels of the sparse step: the pass kernel
-    # owns the nonzero stream and ONE read of every distinct row + bias; the apply kernel owns the accumulator
+    # attribution of the algorithmic bytes to the two kernels of the two-launch sparse step: the pass
+    # kernel owns the nonzero stream and ONE read of every distinct row + bias; the apply kernel owns the accumulator
     # read and the two writes
     per_kernel = None
-    if not dense and not adam:
+    if stepper is None and not adam and "apply_adagrad" in kern:
         attributed = {"passes": 16 * B + 4 * (d + 1) * (u_row + u_col), "apply_adagrad": 12 * (d + 1) * (u_row + u_col)}
         per_kernel = {k: {"algorithmic_bytes": attributed[k], "avg_us": kern[k],
                           "achieved_GBps": attributed[k] / (kern[k] * 1e-6) / 1e9,
@@ -387,40 +479,125 @@ def main():
     step_us = sum(kern.values())
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
+    traffic, traffic_src = measured_traffic(workload, B, cap) if mode == "single" else (None, None)
+    parallelism = {"single": "single GPU",
+                   "dp": "dp%d, %s" % (world, "touched-rows all-gather" if stepper is not None and stepper.rows else "dense-grad all-reduce"),
+                   "sharded": "both tables sharded x%d, touched col rows by all-to-all" % world,
+                   "rowsharded": "row table sharded x%d, col side %s" % (
+                       world, "touched-rows all-gather" if stepper is not None and getattr(stepper, "rows", False) else "dense all-reduce")}[mode]
+    out = {
+        "metric": "co-occurrence nonzeros/sec", "value": steps * B * world / elapsed, "unit": "nonzeros/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "repeats": len(elapsed_all), "ms_per_step_min_max": [min(elapsed_all) / steps * 1e3, max(elapsed_all) / steps * 1e3],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": DATA_NOTE.get(workload, "synthetic"),
+        "config": {"workload": workload, "V": V, "d": d, "optimizer": optimizer,
+                   "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz,
+                   "resident_batches": nb, "chunk_cap": cap,
+                   **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
+                      if ctx.args.rehearse_on_one_gpu else {}),
+                   "index": ("rebuilt every step, %d builds in flight" % ahead if ahead > 1 else
+                             "rebuilt every step") if dynamic else "static, built at load",
+                   "launch": "hipGraph replay, %d steps per graph" % spg if graph is not None else "eager",
+                   "parallelism": parallelism,
+                   **({"exchange_floats_per_rank_per_step": getattr(stepper, "payload_floats", None)} if stepper is not None else {})},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
+                     "stream_ceiling": HBM_STREAM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+                     "kernel": "one step = " + " + ".join(kern),
+                     "algorithmic_bytes_per_step": alg, "kernel_us": kern, "per_kernel": per_kernel,
+                     "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
+        "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
+    }
+    del tables, plans, handles, batches, stepper, graph
+    torch.cuda.empty_cache()
+    return out
 
-    traffic, traffic_src = measured_traffic(args.workload, B, cap) if not dense else (None, None)
 
+def brief(r: dict) -> dict:
+    """A configuration as it appears in the headline's `configs` array."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "repeats", "dtype", "data", "config", "roofline",
+            "final_loss")
+    return {k: r[k] for k in keep}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            # no launcher: be one.  Nothing has touched the GPU in this process (device_count() does not)
+            if not args.rehearse_on_one_gpu and torch.cuda.device_count() < args.gpus:
+                raise SystemExit("--gpus %d but %d visible" % (args.gpus, torch.cuda.device_count()))
+            raise SystemExit(launch_ranks(args.gpus, argv))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    mode = "auto"
+    if args.row_sharded:
+        mode = "rowsharded" if args.cols_replicated else "sharded"
+    elif args.force_dense:
+        mode = "dp"
+    if world > 1 or mode != "auto":
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:      # a multi-rank form on a single GPU without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    from trainer import hip_api
+    if not hip_api.LIB_PATH.exists():
+        # sources arrived without the built library: the first local rank compiles it (hipcc is part of the image),
+        # the others wait for the file; a failing build ends the run
+        if local_rank == 0 or args.rehearse_on_one_gpu and rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        for _ in range(600):
+            if hip_api.LIB_PATH.exists():
+                break
+            time.sleep(1.0)
+    hip = hip_api.GloveHip(dev)
+    ctx = Ctx(args, world, rank, dev, dist, hip)
+    common = dict(lr=args.learning_rate, chunk_cap=args.chunk_cap, step_form=args.step_form, exchange=args.exchange,
+                  no_graph=args.no_graph, max_batches=args.max_batches, min_timed_ms=args.min_timed_ms)
+    out = run_config(ctx, args.workload, args.batch_size, args.optimizer, mode, args.steps, args.warmup,
+                     dynamic=args.dynamic, build_ahead=args.build_ahead, **common)
+    plain = not (args.single or args.dynamic or args.optimizer != "Adagrad" or mode != "auto" or args.step_form or
+                 args.chunk_cap or args.rehearse_on_one_gpu)
+    if plain:
+        # the other configurations of BASELINE.json / BASELINE.md §3 in the same line: where HBM is the bound
+        extra = dict(lr=args.learning_rate, max_batches=8, min_timed_ms=args.min_timed_ms, exchange=args.exchange)
+        specs = ([("c3_text8_v50k_d300", dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
+                  ("c4_zipf_v400k_d300_one_gpu_shard", dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4)),
+                  ("c5_zipf_v2m_d128_one_gpu_shard", dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4)),
+                  ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001))]
+                 if world == 1 else
+                 [("c4_zipf_v400k_d300_data_parallel", dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3)),
+                  ("c5_zipf_v2m_d128_both_tables_sharded", dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
+        configs = []
+        for name, spec in specs:
+            kw = dict(extra)
+            kw.update({k: v for k, v in spec.items() if k not in ("workload", "B")})
+            r = brief(run_config(ctx, spec["workload"], spec["B"], **kw))
+            r["name"] = name
+            configs.append(r)
+        out["configs"] = configs
     if rank == 0:
-        out = {
-            "metric": "co-occurrence nonzeros/sec", "value": args.steps * B * world / elapsed, "unit": "nonzeros/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "V": V, "d": d, "optimizer": args.optimizer,
-                       "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz,
-                       "resident_batches": nb, "chunk_cap": cap,
-                       **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
-                          if args.rehearse_on_one_gpu else {}),
-                       "index": ("rebuilt every step, %d builds in flight" % ahead if ahead > 1 else
-                                 "rebuilt every step") if args.dynamic else "static, built at load",
-                       "launch": "hipGraph replay" if graph is not None else "eager",
-                       "parallelism": ("row-sharded x%d + col all-reduce" % world if args.row_sharded else
-                                       "dp%d dense-grad all-reduce" % world if dense else "single GPU")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "one step = " + " + ".join(kern),
-                         "algorithmic_bytes_per_step": alg, "kernel_us": kern, "per_kernel": per_kernel,
-                         "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
-            "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
-        }
-        if not args.no_cpu_baseline and world == 1 and not args.force_dense:
-            try:
-                out["cpu_baseline"] = cpu_baseline(wl, B, dict(learning_rate=args.learning_rate), args.cpu_seconds,
-                                                   args.optimizer)
-            except Exception as exc:                     # the baseline is a side measurement: never lose the bench line to it
-                out["cpu_baseline"] = {"value": None, "unit": "nonzeros/s", "cores": 1, "kind": "port",
-                                       "sample": "failed: %s: %s" % (type(exc).__name__, exc)}
+        if not args.no_cpu_baseline and world == 1 and mode == "auto":
+            out["cpu_baseline"] = cpu_baseline(ctx, ctx.workload(args.workload), args.batch_size, args.learning_rate, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if dense:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -708,6 +708,102 @@ def test_row_sharded_pieces_on_one_gpu(hip, B, V, d, W):
     assert torch.equal(a.scalars, b.scalars)
 
 
+@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2), (3000, 150, 50, 16),
+                                       (2000, 5000, 20, 8), (9000, 40000, 64, 16)])
+def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap):
+    """The packed-list exchange on one rank (pack -> combine -> apply) == dense gradient + dense apply == sparse
+    apply, bit for bit: all three sum the same partials in the same order; the dense buffer behind the lists is
+    never zeroed and the marks come back all zero."""
+    from trainer.hip_api import DeviceTables
+    from trainer.stepper import HipBackend, Stepper
+    row, col, w, y = make_batch(77, B, V)
+    t = oracle_tables(V, d, "Adagrad")
+    tabs = [tables_from_oracle(t, DeviceTables) for _ in range(3)]
+    backend = HipBackend("cuda:0")
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap, compact=True)
+    kw = dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05, step_form=1)
+    steppers = [Stepper(backend, tabs[0], kw, B, exchange="rows"), Stepper(backend, tabs[1], kw, B, exchange="dense"),
+                Stepper(backend, tabs[2], kw, B, exchange="dense")]
+    steppers[0].prepare([plan])
+    steppers[1].dense, steppers[1].G = True, backend.dense_grad_buffer(tabs[1])        # the data-parallel form on one rank
+    assert steppers[0].rows and [n for n, _ in steppers[0].phases()] == ["passes", "pack_grad", "all_gather", "combine_apply"]
+    assert [n for n, _ in steppers[1].phases()] == ["passes", "dense_grad", "dense_apply"] and not steppers[2].dense
+    steppers[0].G.fill_(float("nan"))                # whatever the buffer holds: first touches store, they do not add
+    for _ in range(3):
+        for st in steppers:
+            st.step(plan)
+    for other in tabs[1:]:
+        _assert_same_bits(tabs[0], other)
+    assert torch.equal(steppers[0].loss_out[:3], steppers[1].loss_out[:3])
+    np.testing.assert_allclose(steppers[0].loss_out.cpu().numpy(), steppers[2].loss_out.cpu().numpy(), rtol=1e-6)
+    assert int(steppers[0].bufs["mark"].abs().max()) == 0
+    n_r, n_c = plan.host_counts[1], plan.host_counts[3]
+    head = steppers[0].bufs["send"][0, :2].view(torch.int32).tolist()
+    assert head == [n_r, n_c]
+    ids = steppers[0].bufs["send"][1:1 + n_r + n_c, d + (-d) % 4 + 1].view(torch.int32).cpu().numpy()
+    np.testing.assert_array_equal(ids, np.r_[np.unique(row), np.unique(col)])
+
+
+@pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 5000, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8)])
+def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
+    """W virtual ranks on one GPU, each with its own batch: their packed lists combined in rank order == the dense
+    buffer they would have all-reduced (dense_grad of every plan into one G, in rank order), bit for bit, and both
+    match the float64 oracle on the joint batch."""
+    from trainer.hip_api import DeviceTables, make_hyper
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    batches = [make_batch(500 + r, B, V) for r in range(W)]
+    plans = [hip.build_plan(*to_dev(*bt), V, chunk_cap=16, compact=True) for bt in batches]
+    h = make_hyper(learning_rate=0.05, batch_size=W * B)
+    cap = 1 + max(p.host_counts[1] + p.host_counts[3] for p in plans)
+    recv = torch.zeros(W, cap, a.d + 4, device="cuda:0")
+    mark = torch.zeros(2 * V, dtype=torch.int32, device="cuda:0")
+    Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    for _ in range(2):
+        for r, p in enumerate(plans):
+            hip.passes(p, a, h)
+            hip.pack_grad(p, a, h, recv[r])
+        lists = [hip.packed_list(recv[r]) for r in range(W)]
+        for r, lst in enumerate(lists):
+            hip.combine_packed(lst, r, a, Ga, mark, cap)
+        hip.apply_packed(lists, a, h, Ga, mark, None, la, cap)
+        for p in plans:
+            hip.passes(p, b, h)
+            hip.dense_grad(p, b, h, Gb)
+        hip.dense_adagrad(b, h, Gb, lb)
+        # every rank's passes advanced global_step: one step happened
+        a.step.fill_(a.global_step - (W - 1)); b.step.fill_(b.global_step - (W - 1))
+        ref.train_step(t, *[np.concatenate([bt[i] for bt in batches]) for i in range(4)], ref.Hyper(learning_rate=0.05))
+    _assert_same_bits(a, b)
+    np.testing.assert_allclose(la.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-6)
+    assert int(mark.abs().max()) == 0
+    assert_tables_close(a, t, 2 * PARAM_RTOL, 2 * PARAM_ATOL)
+
+
+@pytest.mark.parametrize("B,V,d", [(3000, 101, 64), (2000, 5000, 52), (20000, 40000, 300)])
+def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
+    """trainer.stepper.ShardedStepper with world = 1 (every all-to-all is a copy): fetching the batch's col rows,
+    stepping on renumbered col ids, returning the packed col gradients and the owner-side apply give the bits of the
+    plain sparse step."""
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ShardedStepper
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    backend = HipBackend("cuda:0")
+    st = ShardedStepper(backend, a, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, 1, 0, None)
+    batches = [to_dev(*make_batch(900 + k, B, V)) for k in range(3)]
+    handles = [st.add_batch(*bt, 16) for bt in batches]
+    plans = [hip.build_plan(*bt, V, chunk_cap=16, compact=True) for bt in batches]
+    h = make_hyper(learning_rate=0.05, batch_size=B, step_form=1)
+    lb = torch.zeros(4, device="cuda:0")
+    for k in (0, 1, 2, 0, 1):
+        st.step(handles[k])
+        hip.step_adagrad(plans[k], b, h, lb)
+    _assert_same_bits(a, b)
+    np.testing.assert_allclose(st.loss_out.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-6)
+
+
 EDGE_CASES = [
     # (B, V, d, cap)  — degenerate shapes the reference's data can produce
     (1, 2, 4, 1), (5, 2, 4, 32), (64, 3, 4, 1), (1000, 7, 12, 1), (4096, 4096, 64, 32), (2000, 2, 64, 16),

@@ -211,6 +211,80 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
 
 
+def test_two_rank_trainer_with_touched_rows_exchange_on_one_gpu(hip, tmp_path):
+    """--exchange rows: the same run with the all-gather of packed touched-row lists instead of the dense all-reduce
+    gives the same tables as --exchange dense, bit for bit (two ranks: g0 + g1 either way), seeded."""
+    import torch.multiprocessing as mp
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    res = {}
+    for k, exchange in enumerate(("rows", "dense")):
+        out = tmp_path / exchange
+        out.mkdir()
+        argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(out / "job"), "--disable-datetime-path",
+                "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+                "--train-steps", "40", "--log-every", "20", "--seed", "5", "--exchange", exchange, "--skip-eval"]
+        mp.spawn(_two_rank_trainer, args=(29950 + os.getpid() % 200 + k, argv, str(out)), nprocs=2, join=True)
+        res[exchange] = [torch.load(out / ("rank%d.pt" % r)) for r in range(2)]
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(res["rows"][0][n], res["rows"][1][n]), n            # replicas identical
+        assert torch.equal(res["rows"][0][n], res["dense"][0][n]), n           # and equal to the dense exchange
+    assert res["rows"][0]["g"] == res["dense"][0]["g"] and res["rows"][0]["step"] == 40
+
+
+def _two_rank_sharded(rank, port, out_dir, V, d, B, steps):
+    """Two ranks on the one GPU over gloo, BOTH tables sharded (trainer.stepper.ShardedStepper)."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = Path(__file__).resolve().parent
+    for p in (here.parent, here.parent / "oracle", here):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+    from helpers import make_batch, to_dev
+    from trainer.hip_api import DeviceTables
+    from trainer.stepper import HipBackend, ShardedStepper, owned_rows, route_by_row_owner
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    whole = DeviceTables(V, d, "Adagrad", device="cuda:0", seed=7)
+    own = owned_rows(V, 2, rank)
+    shard = DeviceTables(V, d, "Adagrad", device="cuda:0", seed=0, V_row=own, V_col=own)
+    for n in ("R", "C", "br", "bc"):
+        getattr(shard, n).copy_(getattr(whole, n)[rank::2])
+    st = ShardedStepper(HipBackend("cuda:0"), shard, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, 2, rank, dist)
+    handles = []
+    for k in range(steps):
+        row, col, w, y = to_dev(*make_batch(4000 + 10 * k + rank, B, V))
+        got = route_by_row_owner(dict(row=row, col=col, w=w, y=y), 2, rank, dist)
+        handles.append(st.add_batch(got["row"], got["col"], got["w"], got["y"], 16))
+    for h in handles:
+        st.step(h)
+    torch.save({n: getattr(shard, n).cpu() for n in ("R", "C", "br", "bc")} | {"g": shard.global_bias, "loss": st.read_loss()},
+               os.path.join(out_dir, "shard%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_fully_sharded_step_on_one_gpu(hip, tmp_path):
+    """BASELINE config 5 with both tables sharded, two ranks sharing the box's GPU (gloo transport, HIP kernels):
+    equals the single-GPU step on the union of the ranks' batches within fp32 rounding of the sum over ranks."""
+    import torch.multiprocessing as mp
+    from helpers import make_batch, to_dev
+    from trainer.hip_api import DeviceTables, make_hyper
+    V, d, B, steps = 2001, 64, 3000, 4
+    mp.spawn(_two_rank_sharded, args=(30300 + os.getpid() % 200, str(tmp_path), V, d, B, steps), nprocs=2, join=True)
+    ref_t = DeviceTables(V, d, "Adagrad", device="cuda:0", seed=7)
+    h = make_hyper(learning_rate=0.05, batch_size=2 * B, step_form=1)
+    loss_out = torch.zeros(4, device="cuda:0")
+    for k in range(steps):
+        joint = [np.concatenate(x) for x in zip(*[make_batch(4000 + 10 * k + r, B, V) for r in range(2)])]
+        hip.step_adagrad(hip.build_plan(*to_dev(*joint), V, chunk_cap=16), ref_t, h, loss_out)
+    shards = [torch.load(tmp_path / ("shard%d.pt" % r)) for r in range(2)]
+    for r, s_ in enumerate(shards):
+        for n in ("R", "C", "br", "bc"):
+            np.testing.assert_allclose(s_[n].numpy(), getattr(ref_t, n)[r::2].cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=n)
+        np.testing.assert_allclose(s_["g"], ref_t.global_bias, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(s_["loss"]["loss"], loss_out[0].item(), rtol=1e-5)
+
+
 def test_logistic_matrix_factorisation_cli(hip, tmp_path):
     """`python -m trainer.logistic_matrix_factorisation` on the reference-made CSV (columns `value` / `neg_weight`):
     trains, logs a falling merged loss, evaluates both heads, and its first steps match the oracle."""

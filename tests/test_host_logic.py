@@ -150,3 +150,45 @@ def test_event_files_are_valid_tfrecords_of_event_protos(tmp_path):
     w.scalars(100, {"loss": 0.5, "note": "text is skipped"})
     w.scalars(200, {"loss": 0.25})
     assert [(s, sc) for _, s, sc in read_events(w.path)] == [(0, {}), (100, {"loss": 0.5}), (200, {"loss": 0.25})]
+
+
+def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher (how the driver calls it): bench.py starts N ranks as a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`, relays rank 0's one
+    JSON line and exits with the child's code — before anything touches the GPU in this process."""
+    import subprocess
+    import sys
+    import types
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return types.SimpleNamespace(returncode=0, stdout='rank 1 says hello\n{"metric": "co-occurrence nonzeros/sec", "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
+    with pytest.raises(SystemExit) as exc:
+        bench.main(["--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert exc.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    script = cmd.index(str(Path(bench.__file__).resolve()))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]           # the ranks get the same arguments
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "co-occurrence nonzeros/sec", "n_gpus": 4}' and "rank 1 says hello" in out.err
+    # a failing child fails the bench; more GPUs asked for than visible is refused before any launch
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: types.SimpleNamespace(returncode=3, stdout=""))
+    with pytest.raises(SystemExit) as exc:
+        bench.main(["--gpus", "2"])
+    assert exc.value.code == 3
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="visible"):
+        bench.main(["--gpus", "2"])
+    # under a launcher (WORLD_SIZE set) the process is a rank: no second launch
+    assert bench.steps_per_graph(20) == 20 and bench.steps_per_graph(200) == 50 and bench.steps_per_graph(97) == 1
