@@ -156,6 +156,25 @@ def cpu_model() -> str:
     return ""
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota (a GPU box gives a
+    one-GPU job a share of the host's cores; more OpenMP threads than that only queue behind each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_leg(wl, B, optimizer, lr, seconds, threads):
     """oracle/glove_ref.c on a bounded sample of the SAME batches: `threads` = 1 is the scalar port, otherwise the
     OpenMP form (ids grouped per batch at load like the GPU's resident index, outside the clock)."""
@@ -172,7 +191,7 @@ def cpu_leg(wl, B, optimizer, lr, seconds, threads):
     bt = [tuple(host[k][b * B:(b + 1) * B] for k in ("row", "col", "w", "y")) for b in range(nb)]
     mt = threads != 1
     idx = [glove_ref_c.BatchIndex(b[0], b[1], d) for b in bt] if mt else None
-    n_threads = port.max_threads() if threads == 0 else threads
+    n_threads = min(port.max_threads(), usable_cores()) if threads == 0 else threads
 
     def one(i):
         if mt:
@@ -207,7 +226,7 @@ def cpu_baseline(ctx, head_wl, head_B, lr, seconds):
         legs["error"] = "%s: %s" % (type(exc).__name__, exc)
     main = legs.get("adagrad_at_gpu_batch", {"value": None, "unit": "nonzeros/s", "cores": 0, "kind": "port", "sample": "failed"})
     out = dict(main)
-    out.update(host_cpus=os.cpu_count(), cpu_model=cpu_model(), legs=legs,
+    out.update(host_cpus=os.cpu_count(), usable_cores=usable_cores(), cpu_model=cpu_model(), legs=legs,
                label="CPU restatement of yxtay/glove-tensorflow estimator step (TF 2.11 unavailable offline)")
     return out
 
@@ -480,11 +499,12 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
     traffic, traffic_src = measured_traffic(workload, B, cap) if mode == "single" else (None, None)
+    rows = getattr(stepper, "rows", False)
     parallelism = {"single": "single GPU",
-                   "dp": "dp%d, %s" % (world, "touched-rows all-gather" if stepper is not None and stepper.rows else "dense-grad all-reduce"),
+                   "dp": "dp%d, %s" % (world, "touched-rows all-gather" if rows else "dense-grad all-reduce"),
                    "sharded": "both tables sharded x%d, touched col rows by all-to-all" % world,
                    "rowsharded": "row table sharded x%d, col side %s" % (
-                       world, "touched-rows all-gather" if stepper is not None and getattr(stepper, "rows", False) else "dense all-reduce")}[mode]
+                       world, "local (one rank)" if world == 1 else "touched-rows all-gather" if rows else "dense all-reduce")}[mode]
     out = {
         "metric": "co-occurrence nonzeros/sec", "value": steps * B * world / elapsed, "unit": "nonzeros/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,

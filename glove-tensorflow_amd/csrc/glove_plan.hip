@@ -322,7 +322,7 @@ __global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, i
 
 static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 {
-    const int capP = (plan->chunk_cap + 7) & ~7;      // a trip of the pass kernel reads up to 8 slots from q0
+    const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
     const int64_t work = (int64_t)plan->cap_chunks * (1 + 3 * capP / 4);
     const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                           {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},

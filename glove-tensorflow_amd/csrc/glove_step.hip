@@ -200,10 +200,11 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
-    static_assert(U % 4 == 0 && U <= 8, "fields are read back four pairs at a time; record fields are padded to 8 slots");
+    static_assert(U % 4 == 0 && U <= kRecPad && kRecPad % U == 0, "fields are read back four pairs at a time; record fields are padded to kRecPad slots");
     // [group][field][pair]: 0 partner, 1 w (REC) or w2 = 2 w inv_batch, 2 y.  With records the group's LDS image
     // is the record itself: header float4, then the three fields, each capP dwords
     constexpr int kRecStride = 4 + 3 * kChunkMax + 4;        // dwords; +16 B staggers the groups over the banks
+    static_assert(kChunkMax % kRecPad == 0 && 4 + 3 * kChunkMax <= kRecStride, "the largest record fits a group's LDS image");
     __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
     uint32_t(*fld)[3][kFieldStride] = reinterpret_cast<uint32_t(*)[3][kFieldStride]>(fld_raw);
     uint32_t *rec = fld_raw + grp_of(threadIdx.x, LPR) * kRecStride;
@@ -1313,7 +1314,7 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.n_host = p->host_counts[row ? 0 : 2];
     sd.count_index = row ? 0 : 2;
     sd.crec = row ? p->r_crec : p->c_crec;
-    sd.capP = (p->chunk_cap + 7) & ~7;
+    sd.capP = rec_cap(p->chunk_cap);
     sd.fuse = fuse;
     sd.own_out = row ? t->R : t->C;
     sd.own_bias_out = row ? t->br : t->bc;

@@ -196,6 +196,10 @@ STEP_CASES = [
     (20000, 2000, 64, 32), (1024, 12000, 64, 32), (777, 33, 96, 5), (900, 70, 384, 7),
     # embedding sizes that are not a multiple of 4: rows are padded to 16 B, the reference's d enters l2/d
     (1024, 300, 50, 32), (513, 40, 2, 8), (2048, 90, 150, 16), (700, 60, 301, 32), (640, 77, 1, 4),
+    # chunk caps below the 8 pair slots a trip of the d <= 32 shapes reads, with per-chunk records (B <= 4096):
+    # the record fields are padded to 8 slots (glove_common.h rec_cap); (3000, 40, 16, 2) above is the case that faulted
+    # while the records were being written
+    (1000, 40, 16, 7), (1000, 40, 32, 3), (2500, 30, 8, 1), (4096, 64, 24, 5),
 ]
 
 
