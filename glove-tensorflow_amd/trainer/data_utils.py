@@ -124,21 +124,29 @@ class NonzeroStream:
         # contiguous shard of a global permutation for this rank (DESIGN.md "Multi-GPU")
         n = len(coo["row"])
         perm = torch.randperm(n, generator=self.gen)
-        per = n // world
-        mine = perm[rank * per:(rank + 1) * per] if world > 1 else perm
+        # every nonzero belongs to exactly one rank: the first n % world ranks take one more
+        lo, hi = rank * (n // world) + min(rank, n % world), (rank + 1) * (n // world) + min(rank + 1, n % world)
+        mine = perm[lo:hi] if world > 1 else perm
         take = lambda a: torch.from_numpy(np.ascontiguousarray(a))[mine].to(self.device)
         self.row, self.col, self.w, self.y = take(coo["row"]), take(coo["col"]), take(coo["w"]), take(coo["y"])
         if route is not None:
             # row-sharded model: every nonzero moves to the rank that owns its row (one all-to-all at load), row ids
-            # become local; the ranks then agree on a common number of nonzeros, so that they run the same number of
-            # (collective) steps per epoch
+            # become local.  Every rank keeps ALL it received: the stream is endless (data_utils.py:12-21 num_epochs=None),
+            # each rank cycles through its own batches and the ranks simply run the same number of steps; a rank that
+            # owns heavier rows (ownership is id % world over Zipf-distributed ids) has more batches and revisits each
+            # of them less often, which the log line below quantifies.
             from trainer.stepper import route_by_row_owner
             dist = route
             got = route_by_row_owner(dict(row=self.row, col=self.col, w=self.w, y=self.y), world, rank, dist)
-            keep = torch.tensor([got["row"].numel()], dtype=torch.int64, device=self.device)
-            dist.all_reduce(keep, op=dist.ReduceOp.MIN)
-            keep = int(keep.item())
-            self.row, self.col, self.w, self.y = (got[k][:keep].contiguous() for k in ("row", "col", "w", "y"))
+            self.row, self.col, self.w, self.y = (got[k].contiguous() for k in ("row", "col", "w", "y"))
+            have = torch.tensor([self.row.numel(), -self.row.numel()], dtype=torch.int64, device=self.device)
+            dist.all_reduce(have, op=dist.ReduceOp.MAX)
+            most, least = int(have[0].item()), -int(have[1].item())
+            self.load_imbalance = most / max(least, 1)
+            (logger.warning if self.load_imbalance > 1.5 else logger.info)(
+                "row-sharded stream: %d nonzeros on this rank, most / least over the ranks = %d / %d (%.2fx): "
+                "the nonzeros of the lighter ranks are revisited that much more often", self.row.numel(), most, least,
+                self.load_imbalance)
         self.nnz = int(self.row.numel())
         if self.nnz < self.B:
             raise ValueError("batch size %d exceeds the %d nonzeros of this rank" % (self.B, self.nnz))

@@ -19,7 +19,7 @@ import torch
 
 from trainer.config_utils import parse_args
 from trainer.data_utils import NonzeroStream, file_lines, get_id_string_table, load_interaction_csv
-from trainer.model_utils import MatrixFactorisation, get_predictions, summary_values
+from trainer.model_utils import MatrixFactorisation, get_predictions, summary_histograms, summary_values
 from trainer.stepper import HipBackend, Stepper
 from trainer.train_utils import CheckpointManager, get_optimizer
 
@@ -107,7 +107,7 @@ class Estimator:
                                          route=self.dist if self.row_sharded else None)
         return self._stream
 
-    def _log(self, name, record):
+    def _log(self, name, record, histograms=None):
         """One line of <job_dir>/<name> (JSON) plus the same scalars as a TensorBoard event in that directory,
         where the reference's Estimator leaves its summaries (job_dir for training, job_dir/eval for eval)."""
         if self.rank != 0:
@@ -123,7 +123,7 @@ class Estimator:
         scalars = {k: v for k, v in record.items() if k != "global_step" and isinstance(v, (int, float))}
         if "steps_per_sec" in scalars:
             scalars["global_step/sec"] = scalars.pop("steps_per_sec")          # the Estimator's tag
-        self._events[logdir].scalars(record["global_step"], scalars)
+        self._events[logdir].scalars(record["global_step"], scalars, histograms)
 
     # ---- TRAIN
     def train(self, max_steps: int):
@@ -184,7 +184,8 @@ class Estimator:
                 rate = (step - s_last) / max(now - t_last, 1e-9)
                 rec.update(global_step=step, steps_per_sec=rate,
                            nonzeros_per_sec=rate * p["batch_size"] * self.world, **summary_values(self.model))
-                self._log("train_log.jsonl", rec)
+                # a row-sharded run logs the histogram of rank 0's row-bias shard (every world-th row)
+                self._log("train_log.jsonl", rec, summary_histograms(self.model) if self.rank == 0 else None)
                 logger.info("global_step %d: loss = %.6f (%.1f steps/s)", step, rec["loss"], rate)
                 t_last, s_last = now, step
             due = self.ckpt.due() or step == max_steps
@@ -211,16 +212,19 @@ class Estimator:
         RegressionHead metrics: average_loss = sum w l / sum w, loss = mean over batches of the
         batch-mean weighted loss, prediction/mean, label/mean."""
         tables, stream = self.model.tables, self.stream()
-        sums = torch.zeros(6 if self.logistic else 4, dtype=torch.float64, device=self.device)
+        k = 6 if self.logistic else 4
+        buf = torch.zeros(k + 1, dtype=torch.float64, device=self.device)       # the metric sums + this rank's nonzero count
+        sums = buf[:k]
+        buf[k] = stream.nnz
         for row, col, w, y in stream.eval_batches():
             if self.logistic:
                 self.backend.eval_sums_logistic(row, col, w, y, tables, sums)
             else:
                 self.backend.eval_sums(row, col, w, y, tables, sums)
         if self.world > 1:
-            self.dist.all_reduce(sums)
+            self.dist.all_reduce(buf)
         s = sums.tolist()
-        n = stream.nnz * self.world
+        n = int(buf[k].item())                  # every nonzero of the file, whatever the ranks' shares
         if self.logistic:
             # BinaryClassHead metrics of the two heads ("pos": label 1, "neg": label 0) and MultiHead's merged loss
             nf = self.params.get("neg_factor", 1.0)

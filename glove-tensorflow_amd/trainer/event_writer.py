@@ -7,7 +7,12 @@ few fields needed here are encoded by hand:
 
     record  = uint64 length | masked crc32c(length) | payload | masked crc32c(payload)        (little endian)
     Event   = 1: wall_time (double)  2: step (int64)  3: file_version (string)  5: summary (message)
-    Summary = 1: value (repeated message);  Value = 1: tag (string)  2: simple_value (float)
+    Summary = 1: value (repeated message);  Value = 1: tag (string)  2: simple_value (float)  5: histo (message)
+    HistogramProto = 1: min  2: max  3: num  4: sum  5: sum_squares (double)  6: bucket_limit  7: bucket (packed double)
+
+Histograms (the reference's `summary.histogram` of the row and col biases, src/models/model_utils.py:116-117) use
+TensorFlow's default bucket limits: +-1e-12 * 1.1^k up to 1e20, 0, and DBL_MAX at the ends; as TF's encoder does,
+runs of empty buckets are merged into one entry.
 """
 from __future__ import annotations
 
@@ -51,13 +56,65 @@ def _field(number: int, wire: int, payload: bytes) -> bytes:
     return head + (_varint(len(payload)) if wire == 2 else b"") + payload
 
 
-def encode_event(wall_time: float, step: int = 0, scalars: dict | None = None, file_version: str | None = None) -> bytes:
+_LIMITS = None
+
+
+def default_bucket_limits() -> list:
+    """tensorflow/core/lib/histogram/histogram.cc InitDefaultBucketsInner: 1e-12 * 1.1^k below 1e20 and DBL_MAX,
+    mirrored to the negative side around 0."""
+    global _LIMITS
+    if _LIMITS is None:
+        pos, v = [], 1e-12
+        while v < 1e20:
+            pos.append(v)
+            v *= 1.1
+        pos.append(1.7976931348623157e308)
+        _LIMITS = [-x for x in reversed(pos)] + [0.0] + pos
+    return _LIMITS
+
+
+def histogram_of(values) -> dict:
+    """HistogramProto fields of a 1-D tensor or array (any device): bucket i counts limit[i-1] <= x < limit[i]
+    (TF: upper_bound over the limits)."""
+    import torch
+    x = torch.as_tensor(values).detach().double().flatten()
+    limits = default_bucket_limits()
+    lim = torch.tensor(limits, dtype=torch.float64, device=x.device)
+    counts = torch.bincount(torch.bucketize(x, lim, right=True).clamp_(max=len(limits) - 1), minlength=len(limits)).tolist()
+    out_limits, out_counts = [], []
+    i = 0
+    while i < len(counts):                       # Histogram::EncodeToProto: a run of empty buckets becomes one entry
+        c, end = counts[i], limits[i]
+        i += 1
+        if c <= 0:
+            while i < len(counts) and counts[i] <= 0:
+                end = limits[i]
+                i += 1
+        out_limits.append(end)
+        out_counts.append(float(c))
+    n = x.numel()
+    return {"min": float(x.min()) if n else 0.0, "max": float(x.max()) if n else 0.0, "num": float(n),
+            "sum": float(x.sum()), "sum_squares": float((x * x).sum()), "bucket_limit": out_limits, "bucket": out_counts}
+
+
+def _histo(h: dict) -> bytes:
+    d = lambda v: struct.pack("<d", float(v))
+    packed = lambda vs: b"".join(d(v) for v in vs)
+    return (_field(1, 1, d(h["min"])) + _field(2, 1, d(h["max"])) + _field(3, 1, d(h["num"])) + _field(4, 1, d(h["sum"])) +
+            _field(5, 1, d(h["sum_squares"])) + _field(6, 2, packed(h["bucket_limit"])) + _field(7, 2, packed(h["bucket"])))
+
+
+def encode_event(wall_time: float, step: int = 0, scalars: dict | None = None, file_version: str | None = None,
+                 histograms: dict | None = None) -> bytes:
     event = _field(1, 1, struct.pack("<d", wall_time)) + _field(2, 0, _varint(step))
     if file_version is not None:
         event += _field(3, 2, file_version.encode())
-    if scalars:
-        values = b"".join(_field(1, 2, _field(1, 2, tag.encode()) + _field(2, 5, struct.pack("<f", float(v))))
-                          for tag, v in scalars.items())
+    values = b""
+    for tag, v in (scalars or {}).items():
+        values += _field(1, 2, _field(1, 2, tag.encode()) + _field(2, 5, struct.pack("<f", float(v))))
+    for tag, h in (histograms or {}).items():
+        values += _field(1, 2, _field(1, 2, tag.encode()) + _field(5, 2, _histo(h)))
+    if values:
         event += _field(5, 2, values)
     return event
 
@@ -75,12 +132,14 @@ class EventWriter:
         with open(self.path, "ab") as f:
             f.write(header + _masked(header) + payload + _masked(payload))
 
-    def scalars(self, step: int, values: dict):
-        self._write(encode_event(time.time(), step, {k: v for k, v in values.items() if isinstance(v, (int, float))}))
+    def scalars(self, step: int, values: dict, histograms: dict | None = None):
+        self._write(encode_event(time.time(), step, {k: v for k, v in values.items() if isinstance(v, (int, float))},
+                                 histograms=histograms))
 
 
 def read_events(path):
-    """Decodes a file written above (checks every checksum): yields (wall_time, step, {tag: value})."""
+    """Decodes a file written above (checks every checksum): yields (wall_time, step, {tag: value}); a histogram's
+    value is the dict of its HistogramProto fields."""
     def parse(buf):
         pos, out = 0, []
         while pos < len(buf):
@@ -133,5 +192,12 @@ def read_events(path):
             elif number == 5:
                 for _, value in parse(val):
                     fields = dict(parse(value))
-                    scalars[fields[1].decode()] = struct.unpack("<f", fields[2])[0]
+                    if 5 in fields:
+                        h = dict(parse(fields[5]))
+                        un = lambda b: list(struct.unpack("<%dd" % (len(b) // 8), b))
+                        names = {1: "min", 2: "max", 3: "num", 4: "sum", 5: "sum_squares"}
+                        scalars[fields[1].decode()] = {**{names[k]: struct.unpack("<d", h[k])[0] for k in names},
+                                                       "bucket_limit": un(h.get(6, b"")), "bucket": un(h.get(7, b""))}
+                    else:
+                        scalars[fields[1].decode()] = struct.unpack("<f", fields[2])[0]
         yield wall, step, scalars

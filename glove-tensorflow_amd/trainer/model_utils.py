@@ -49,8 +49,16 @@ def get_predictions(hip, model: MatrixFactorisation, input_ids: torch.Tensor, id
 
 
 def summary_values(model: MatrixFactorisation) -> dict:
-    """What add_summary logs (reference model_utils.py:113-118): global bias scalar and the two
-    bias histograms (here: min/mean/max/std)."""
+    """What add_summary logs (reference model_utils.py:113-118): global bias scalar and, for the log line, the
+    min/mean/max/std of the two bias vectors (their histograms go to the event file: summary_histograms)."""
     t = model.tables
     stat = lambda x: {"min": float(x.min()), "mean": float(x.mean()), "max": float(x.max()), "std": float(x.std())}
     return {"mf/global_bias": t.global_bias, "mf/row_biases": stat(t.br), "mf/col_biases": stat(t.bc)}
+
+
+def summary_histograms(model: MatrixFactorisation) -> dict:
+    """`summary.histogram("row_biases" / "col_biases")` of add_summary (reference model_utils.py:116-117) as
+    HistogramProto fields over TensorFlow's default buckets."""
+    from trainer.event_writer import histogram_of
+    t = model.tables
+    return {"mf/row_biases": histogram_of(t.br), "mf/col_biases": histogram_of(t.bc)}

@@ -166,3 +166,37 @@ def test_fully_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
             np.testing.assert_allclose(s[n], getattr(t, n)[r::WORLD], rtol=1e-10, atol=1e-13, err_msg=n)
         np.testing.assert_allclose(s["g"], t.g, rtol=1e-10)
         assert int(s["step"]) == STEPS
+
+
+# ---- the input side on several ranks: every nonzero of the file belongs to exactly one rank
+def _stream_worker(rank, port, out_dir, routed):
+    for p in (HERE.parent, HERE.parent / "oracle", HERE):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    from oracle_backend import OracleBackend
+    from trainer.data_utils import NonzeroStream
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    rng = np.random.default_rng(0)
+    n = 1001                                                   # odd: the data-parallel split has a remainder
+    row = (rng.zipf(1.3, n) % V).astype(np.int32)              # skewed: id % world ownership is unbalanced
+    coo = dict(row=row, col=rng.integers(0, V, n).astype(np.int32), w=np.arange(n, dtype=np.float32),
+               y=rng.normal(size=n).astype(np.float32))
+    st = NonzeroStream(coo, 50, V, OracleBackend(), "cpu", rank=rank, world=WORLD, seed=7, route=dist if routed else None)
+    seen = sum(int(b[0].numel()) for b in st.eval_batches())
+    assert seen == st.nnz and len(st.plans) == st.nnz // 50
+    np.savez(os.path.join(out_dir, "stream%d.npz" % rank), w=st.w.numpy(), row=st.row.numpy(), nnz=st.nnz)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("routed", [False, True])
+def test_every_nonzero_lands_on_exactly_one_rank(tmp_path, routed):
+    """Data-parallel shards (a contiguous slice of one permutation each, the remainder spread over the first ranks) and
+    row-owner routing (nothing truncated to the lightest rank's count): the ranks' streams partition the file."""
+    port = 35500 + os.getpid() % 2000 + int(routed)
+    mp.spawn(_stream_worker, args=(port, str(tmp_path), routed), nprocs=WORLD, join=True)
+    parts = [np.load(tmp_path / ("stream%d.npz" % r)) for r in range(WORLD)]
+    w = np.sort(np.concatenate([p["w"] for p in parts]))       # the weights are the nonzeros' serial numbers
+    np.testing.assert_array_equal(w, np.arange(1001, dtype=np.float32))
+    assert sum(int(p["nnz"]) for p in parts) == 1001
+    if routed:
+        assert int(parts[0]["nnz"]) != int(parts[1]["nnz"])    # unbalanced ownership, and still nothing dropped

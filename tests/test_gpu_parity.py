@@ -219,6 +219,32 @@ def test_adagrad_single_step(hip, B, V, d, cap):
     assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
 
 
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+@pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (3000, 40, 16, 2), (2048, 90, 150, 16)])
+def test_single_step_with_reg_multiplicity_one(hip, optimizer, B, V, d, cap):
+    """--reg-multiplicity 1 (TF 2.1's `get_losses_for`): the regulariser list enters the loss once —
+    kappa halves, loss = L + Reg — against the float64 oracle; and it is not the m = 2 result."""
+    from trainer.hip_api import DeviceTables
+    row, col, w, y = make_batch(B + d, B, V)
+    res = {}
+    for m in (1.0, 2.0):
+        hp = ref.Hyper(learning_rate=0.05 if optimizer == "Adagrad" else 0.001, reg_mult=m, l2_reg=0.1)
+        t = oracle_tables(V, d, optimizer)
+        dt = tables_from_oracle(t, DeviceTables)
+        plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+        loss_out = torch.zeros(4, device="cuda:0")
+        if optimizer == "Adagrad":
+            hip.step_adagrad(plan, dt, _hyper(hp, B), loss_out)
+        else:
+            hip.step_adam(plan, dt, _hyper(hp, B), hip.dense_grad_buffer(dt), loss_out)
+        loss, L, reg = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss_out.cpu().numpy()[:3], [loss, L, reg], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(loss, L + m * reg, rtol=1e-12)
+        assert_tables_close(dt, t, PARAM_RTOL, PARAM_ATOL)
+        res[m] = (dt.R.clone(), float(loss_out[0]))
+    assert not torch.equal(res[1.0][0], res[2.0][0]) and res[1.0][1] < res[2.0][1]
+
+
 def test_per_pair_error_coefficients(hip):
     """e_i = 2 w_i (p_i - y_i)/B straight out of the rowpass workspace (e_i rtol 1e-5, atol 1e-7)."""
     from trainer.hip_api import DeviceTables

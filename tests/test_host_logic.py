@@ -132,6 +132,12 @@ def test_event_files_are_valid_tfrecords_of_event_protos(tmp_path):
     val = fdp.message_type.add(name="Value")
     val.field.add(name="tag", number=1, type=9, label=1)
     val.field.add(name="simple_value", number=2, type=2, label=1)
+    val.field.add(name="histo", number=5, type=11, label=1, type_name=".t.HistogramProto")
+    hp = fdp.message_type.add(name="HistogramProto")
+    for i, n in enumerate(("min", "max", "num", "sum", "sum_squares"), 1):
+        hp.field.add(name=n, number=i, type=1, label=1)
+    hp.field.add(name="bucket_limit", number=6, type=1, label=3)
+    hp.field.add(name="bucket", number=7, type=1, label=3)
     fdp.message_type.add(name="Summary").field.add(name="value", number=1, type=11, label=3, type_name=".t.Value")
     ev = fdp.message_type.add(name="Event")
     ev.field.add(name="wall_time", number=1, type=1, label=1)
@@ -150,6 +156,26 @@ def test_event_files_are_valid_tfrecords_of_event_protos(tmp_path):
     w.scalars(100, {"loss": 0.5, "note": "text is skipped"})
     w.scalars(200, {"loss": 0.25})
     assert [(s, sc) for _, s, sc in read_events(w.path)] == [(0, {}), (100, {"loss": 0.5}), (200, {"loss": 0.25})]
+    # histograms (the reference's summary.histogram of the biases): HistogramProto over TensorFlow's default buckets
+    from trainer.event_writer import default_bucket_limits, histogram_of
+    lim = default_bucket_limits()
+    assert len(lim) == 2 * 775 + 1 and lim[len(lim) // 2] == 0.0 and lim[-1] == 1.7976931348623157e308 and lim[0] == -lim[-1]
+    assert abs(lim[len(lim) // 2 + 1] - 1e-12) < 1e-25 and abs(lim[len(lim) // 2 + 2] / lim[len(lim) // 2 + 1] - 1.1) < 1e-12
+    x = np.array([-0.03, -0.03, 0.0, 0.01, 0.0105, 0.04, 2.5], np.float32)
+    h = histogram_of(x)
+    assert h["num"] == 7 and abs(h["sum"] - float(x.astype(np.float64).sum())) < 1e-12 and h["min"] == float(x.min())
+    assert sum(h["bucket"]) == 7 and len(h["bucket"]) == len(h["bucket_limit"]) < 20       # empty runs are merged
+    edges = np.asarray(h["bucket_limit"])
+    for v in x.astype(np.float64):                       # every value lies in a bucket that counted it: limit[i-1] <= v < limit[i]
+        i = int(np.searchsorted(edges, v, side="right"))
+        assert h["bucket"][i] > 0 and (i == 0 or edges[i - 1] <= v) and v < edges[i]
+    msg.ParseFromString(encode_event(3.0, 7, {"loss": 1.0}, histograms={"mf/row_biases": h}))
+    got = msg.summary.value[1]
+    assert got.tag == "mf/row_biases" and got.histo.num == 7 and list(got.histo.bucket) == h["bucket"]
+    assert list(got.histo.bucket_limit) == h["bucket_limit"] and got.histo.sum_squares == h["sum_squares"]
+    w.scalars(300, {"loss": 0.1}, {"mf/col_biases": h})
+    last = list(read_events(w.path))[-1]
+    assert last[1] == 300 and last[2]["loss"] == np.float32(0.1) and last[2]["mf/col_biases"] == h
 
 
 def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
