@@ -68,7 +68,7 @@ def parse(argv=None):
     ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad", "Adam"],
                     help="Adam = Keras-legacy dense-decay Adam (config 1 of BASELINE.json), single GPU only")
     ap.add_argument("--learning-rate", type=float, default=0.05)
-    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches")
+    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table")
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
     ap.add_argument("--build-ahead", type=int, default=1,
                     help="with --dynamic: index builds in flight (each on its own stream and staging plan), the way an "
@@ -293,6 +293,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         nb = int(agreed.item())
 
     tables = DeviceTables(V, d, optimizer, device=dev, seed=1, V_row=V_row, V_col=V_col)   # identical replicas on every rank
+    if mode == "single" and step_form in (0, 4):
+        tables.maybe_enable_twin()
     backend = HipBackend(dev)
     backend.hip = hip
     backend.row_floats = tables.d
@@ -452,7 +454,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         else:
             fused_auto = plans[0].r_crec is not None and (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES
             if form == 0:
-                form = 3 if fused_auto else 1
+                form = (4 if tables.R_ver is not None else 3) if fused_auto else 1
             if form == 1 or plans[0].r_crec is None:
                 calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)      # row side + col side, one launch
                 calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)

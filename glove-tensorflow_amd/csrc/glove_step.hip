@@ -68,6 +68,49 @@ __device__ inline void store_row(float *table, size_t row_index, int d4, int lg,
     }
 }
 
+// Streaming variants (experiment switch GLOVE_STREAM, default 0 = plain): rows that are touched once per step — own
+// rows, accumulators, partial rows — marked so that they do not displace the partner rows the gathers want to find in L2.
+//   1: nontemporal builtins (global_load/store ... nt)      2: stores with sc1 (the line is dropped from L2), loads nt
+#ifndef GLOVE_STREAM
+#define GLOVE_STREAM 0
+#endif
+template <int LPR, int NV>
+__device__ inline void load_row_stream(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
+{
+#if GLOVE_STREAM == 0
+    load_row<LPR, NV>(dst, table, id, d4, lg);
+#else
+    const f4 *p = reinterpret_cast<const f4 *>(table) + (size_t)id * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        const f4 v = __builtin_nontemporal_load(&p[i4 < d4 ? i4 : d4 - 1]);
+        dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#endif
+}
+
+template <int LPR, int NV>
+__device__ inline void store_row_stream(float *table, size_t row_index, int d4, int lg, const f4 (&src)[NV])
+{
+#if GLOVE_STREAM == 0
+    store_row<LPR, NV>(table, row_index, d4, lg, src);
+#else
+    f4 *p = reinterpret_cast<f4 *>(table) + row_index * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        if (i4 < d4) {
+#if GLOVE_STREAM == 1
+            __builtin_nontemporal_store(src[k], &p[i4]);
+#else
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&p[i4]), "v"(src[k]) : "memory");
+#endif
+        }
+    }
+#endif
+}
+
 // ---- optimizer arithmetic (Keras-legacy forms) -------------------------
 // x / (sqrt(a) + eps) uses the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE
 // expansions: ~3 ulp on the update term, far inside the 1e-5 parity tolerance, and a third of the
@@ -176,12 +219,18 @@ struct PassSide {
     //   fuse == kFuseSlot     into the chunk's partial-row slot (gp / gb), from where the apply kernel copies it
     //                         into the table once every pass that gathers the old rows has finished
     // fuse == kFuseNone: every chunk stores its partial sums (the apply / dense-gradient kernels do the rest)
+    //   fuse == kFuseTwin     into the OTHER copy of a twinned table (glove_tables.R_ver: rows V_row .. 2 V_row - 1 are a
+    //                         second copy of the row table, own_ver[u] says which copy of row u is current): later passes
+    //                         of the step keep finding the old row in the current copy, the apply kernel only flips
+    //                         own_ver[u] — no slot round trip, no copy
     int fuse;
-    float *own_out, *own_bias_out; // this side's table / bias vector, written by kFuseInPlace
+    float *own_out, *own_bias_out; // this side's table / bias vector, written by kFuseInPlace / kFuseTwin
     float *S1, *S1b;               // this side's Adagrad accumulators
+    const uint8_t *own_ver, *other_ver;   // not null: that table is twinned, ver[id] != 0 = the current row is id + twin rows
+    int own_twin, other_twin;             // rows between the two copies (V_row)
 };
 
-constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2;
+constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2, kFuseTwin = 3;
 
 struct StepConsts {
     float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
     int j = FUSE ? (bid * GPB + grp) * per : bid * GPB + grp;
     const int j_end = FUSE ? (j + per < n_chunks ? j + per : n_chunks) : n_chunks;
     const int j_step = FUSE ? 1 : nblk * GPB;
-    int32_t cur_u = -1;
+    int32_t cur_u = -1, own_at = 0;
     int run_first = 0, run_pairs = 0;
     bool run_whole = false;
     f4 r[NV], acc[NV], A[NV];
@@ -279,6 +328,15 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
                 }
             }
         }
+        if (FUSE && have && sd.other_ver) {
+            // twinned partner table: the staged partner ids become the rows that are current.  One byte gather per pair,
+            // issued with the own-row load below (whose latency covers it), instead of a dependent hop in every trip
+            uint32_t *ids = REC ? rec + 4 : &fld[grp][0][0];
+            for (int t = lg; t < n; t += LPR) {
+                const uint32_t id = ids[t];
+                ids[t] = id + (sd.other_ver[id] ? (uint32_t)sd.other_twin : 0u);
+            }
+        }
         const bool new_run = !FUSE || !pending || u != cur_u;
         if (FUSE && pending && (!have || new_run)) {        // the run in registers is complete
             pending = false;
@@ -293,16 +351,18 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
                 Gb += kc.kappa_b * cnt * bval;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], acc[k], kc.lr, kc.eps);
-                store_row<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
-                const bool in_place = sd.fuse == kFuseInPlace;
-                store_row<LPR, NV>(in_place ? sd.own_out : sd.gp, in_place ? (size_t)cur_u : (size_t)run_first, d4, lg, r);
+                store_row_stream<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
+                const bool to_slot = sd.fuse == kFuseSlot;
+                // in place: the row itself; twin: the copy that is NOT current (own_at is the current one)
+                const size_t out_at = sd.fuse == kFuseTwin ? (size_t)(own_at == cur_u ? cur_u + sd.own_twin : cur_u) : (size_t)cur_u;
+                store_row_stream<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
                 if (lg == 0) {
                     adagrad_elem(bval, Ab, Gb, kc.lr, kc.eps);
                     sd.S1b[cur_u] = Ab;
-                    if (in_place) sd.own_bias_out[cur_u] = bval; else sd.gb[run_first] = bval;
+                    if (to_slot) sd.gb[run_first] = bval; else sd.own_bias_out[out_at] = bval;
                 }
             } else {
-                store_row<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
+                store_row_stream<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
                 if (lg == 0) {
                     sd.gb[run_first] = se;
                     if (sd.mark) sd.mark[cur_u] = 1.0f;
@@ -314,13 +374,15 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
             cur_u = u;
             run_first = j;
             run_pairs = 0;
-            load_row<LPR, NV>(r, sd.own, u, d4, lg);
-            own_b = sd.own_bias[u];
+            own_at = u;
+            if (FUSE && sd.own_ver) own_at = u + (sd.own_ver[u] ? sd.own_twin : 0);     // the current copy of a twinned table
+            if (FUSE) load_row_stream<LPR, NV>(r, sd.own, own_at, d4, lg); else load_row<LPR, NV>(r, sd.own, u, d4, lg);
+            own_b = sd.own_bias[own_at];
             bg = own_b + g;
             // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
             run_whole = FUSE && sd.fuse != kFuseNone && (hw >> 31) != 0 && j + (int)(hw & 0x7fffffffu) < j_end;
             if (FUSE && run_whole) {            // requested with the own row: arrives under the partner-row trips
-                load_row<LPR, NV>(A, sd.S1, u, d4, lg);
+                load_row_stream<LPR, NV>(A, sd.S1, u, d4, lg);
                 Ab = sd.S1b[u];
             }
 #pragma unroll
@@ -466,7 +528,29 @@ struct SideBufs {
     const int32_t *uniq_rec;
     const float *gp, *gb;
     float *W, *S1, *bias, *S1b;
+    uint8_t *ver;               // not null: W / bias are twinned (glove_tables.R_ver), ver[id] != 0 = current row is id + twin
+    int twin;
 };
+
+// field-wise choice between the two sides (a reference picked by a run-time condition would force both structs into
+// scratch memory)
+__device__ inline SideBufs pick_side(bool row, const SideBufs &r, const SideBufs &c)
+{
+    SideBufs s;
+    s.uniq_rec = row ? r.uniq_rec : c.uniq_rec;
+    s.gp = row ? r.gp : c.gp;
+    s.gb = row ? r.gb : c.gb;
+    s.W = row ? r.W : c.W;
+    s.S1 = row ? r.S1 : c.S1;
+    s.bias = row ? r.bias : c.bias;
+    s.S1b = row ? r.S1b : c.S1b;
+    s.ver = row ? r.ver : c.ver;
+    s.twin = row ? r.twin : c.twin;
+    return s;
+}
+
+// row of W / entry of bias that currently holds id (the slots S1 / S1b are never twinned)
+__device__ inline int32_t cur_row(const SideBufs &sb, int32_t id) { return sb.ver && sb.ver[id] ? id + sb.twin : id; }
 
 struct IdWork {
     const int32_t *counts;      // device counts[8]
@@ -521,7 +605,8 @@ __device__ inline void sum_partials(const SideBufs &sb, const Slots &sl, int k0,
 //                                                   accumulator, Adam's m and v, or the dense gradient
 //                                                   row), requested together with the table row so the
 //                                                   latencies overlap
-//   fn.finish(is_row, id, q, G, Wv, Gb, bval, st)   G = summed gradient incl. the activity-L2 term; q = position of
+//   fn.finish(is_row, id, wid, q, G, Wv, Gb, bval, st)   G = summed gradient incl. the activity-L2 term; wid = row of
+//                                                   the table that holds id (id itself unless the table is twinned); q = position of
 //                                                   the id among its side's distinct ids (plan order)
 // Returns true in the workgroup that should also do the once-per-step scalar work.
 template <int LPR, int NV, class F>
@@ -556,16 +641,18 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
                 store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
                 if (lg == 0) sb.bias[id] = bn;
             }
+            if (pre == kFuseTwin && threadIdx.x == 0) sb.ver[id] ^= 1;       // the other copy holds the new row
             return false;
         }
+        const int32_t wid = cur_row(sb, id);
         f4 G[NV], Wv[NV];
         typename F::State st;
         float Gb = 0.f, bval = 0.f;
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) G[kk] = f4{0.f, 0.f, 0.f, 0.f};
         if (grp == 0) {
-            load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
-            bval = sb.bias[id];
+            load_row<LPR, NV>(Wv, sb.W, wid, d4, lg);
+            bval = sb.bias[wid];
             fn.prefetch(is_row, id, st);
         }
         // a heavy id is the longest dependent chain of the launch (the head of a Zipf batch: ~50 rows per group):
@@ -586,7 +673,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
 #pragma unroll
             for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
             Gb += k.kappa_b * cnt * bval;
-            fn.finish(is_row, id, code & 0x3fffffff, G, Wv, Gb, bval, st);
+            fn.finish(is_row, id, wid, code & 0x3fffffff, G, Wv, Gb, bval, st);
         }
         return false;
     }
@@ -613,23 +700,25 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         if (pre != kFuseNone && sl.count == 1) {
             // one run held the whole id and the pass kernel already applied it (sidepass_kernel FUSE): in place ->
             // nothing left to do; into its slot -> move the finished row and bias into the table now that no pass
-            // reads the old ones
+            // reads the old ones; twin -> the other copy holds the new row: flip the version
             if (pre == kFuseSlot) {
                 f4 Wn[NV];
-                load_row<LPR, NV>(Wn, sb.gp, sl0, d4, lg);
+                load_row_stream<LPR, NV>(Wn, sb.gp, sl0, d4, lg);
                 const float bn = sb.gb[sl0];
-                store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
+                store_row_stream<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
                 if (lg == 0) sb.bias[id] = bn;
             }
+            if (pre == kFuseTwin && lg == 0) sb.ver[id] ^= 1;
             continue;
         }
+        const int32_t wid = cur_row(sb, id);
         const float cnt = (float)rec.w;
         f4 G[NV], Wv[NV];
         typename F::State st;
         load_row<LPR, NV>(G, sb.gp, sl0, d4, lg);
         float Gb = sb.gb[sl0];
-        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
-        const float bval = sb.bias[id];
+        load_row<LPR, NV>(Wv, sb.W, wid, d4, lg);
+        const float bval = sb.bias[wid];
         fn.prefetch(is_row, id, st);
         sum_partials<LPR, NV>(sb, sl, 1, 1, d4, lg, G, Gb);
         const float kc = k.kappa * cnt;
@@ -637,7 +726,7 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         for (int kk = 0; kk < NV; ++kk) G[kk] += kc * Wv[kk];
         Gb += k.kappa_b * cnt * bval;
         GLOVE_DRAIN(); GLOVE_STAMP(3);      // rows arrived
-        fn.finish(is_row, id, qq, G, Wv, Gb, bval, st);
+        fn.finish(is_row, id, wid, qq, G, Wv, Gb, bval, st);
         GLOVE_DRAIN(); GLOVE_STAMP(4);      // stores retired
     }
     GLOVE_STAMP(5);
@@ -695,17 +784,17 @@ struct AdagradApply {
         load_row<LPR, NV>(st.A, sb.S1, id, d4, lg);
         st.Ab = sb.S1b[id];
     }
-    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         const SideBufs &sb = is_row ? rs : cs;
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[kk], st.A[kk], G[kk], lr, eps);
         store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, st.A);
-        store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
+        store_row<LPR, NV>(sb.W, (size_t)wid, d4, lg, Wv);
         if (lg == 0) {
             adagrad_elem(bval, st.Ab, Gb, lr, eps);
             sb.S1b[id] = st.Ab;
-            sb.bias[id] = bval;
+            sb.bias[wid] = bval;
         }
     }
 };
@@ -749,7 +838,7 @@ struct DenseGradAdd {
         load_row<LPR, NV>(st.old, is_row ? G_R : G_C, id, d4, lg);
         st.oldb = (is_row ? G_br : G_bc)[id];
     }
-    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         (void)Wv; (void)bval;
 #pragma unroll
@@ -798,7 +887,7 @@ struct PackGrad {
     int d4, lg, row_entries;
     struct State {};
     __device__ void prefetch(bool, int32_t, State &) const {}
-    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &) const
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &) const
     {
         (void)Wv; (void)bval;
         const size_t stride4 = (size_t)d4 + 1;
@@ -946,6 +1035,23 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
     }
 }
 
+// Twinned row table back to its plain form: every row whose current copy is the second one is copied into the first,
+// all versions become 0.  Everything but the fused twin step expects this form.
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void canonicalize_kernel(float *__restrict__ R, float *__restrict__ br,
+                                                              uint8_t *__restrict__ ver, int V_row, int d4)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int u = blockIdx.x * GPB + grp; u < V_row; u += gridDim.x * GPB) {
+        if (!ver[u]) continue;
+        f4 v[NV];
+        load_row<LPR, NV>(v, R, u + V_row, d4, lg);
+        store_row<LPR, NV>(R, (size_t)u, d4, lg, v);
+        if (lg == 0) { br[u] = br[u + V_row]; ver[u] = 0; }
+    }
+}
+
 // rows[i] = W[ids[i]] (d floats each), biases[i] = bias[ids[i]]: what the owner of a table shard sends to the ranks
 // whose batches touch those rows
 template <int LPR, int NV>
@@ -1065,7 +1171,7 @@ struct AdamApply {
         st.Mb = sb.S1b[id];
         st.Vb = (is_row ? S2_br : S2_bc)[id];
     }
-    __device__ void finish(bool is_row, int32_t id, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         const SideBufs &sb = is_row ? rs : cs;
 #pragma unroll
@@ -1181,6 +1287,7 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
+    if (t->R_ver && 2ull * (uint64_t)(t->V_row > 0 ? t->V_row : t->V) * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;
     if (t->d_model < 0 || t->d_model > t->d) return GLOVE_E_BADARG;
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     if (h->head != GLOVE_HEAD_REGRESSION && h->head != GLOVE_HEAD_LOGISTIC) return GLOVE_E_BADARG;
@@ -1265,6 +1372,8 @@ static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tabl
     s.S1 = row ? t->s1_R : t->s1_C;
     s.bias = row ? t->br : t->bc;
     s.S1b = row ? t->s1_br : t->s1_bc;
+    s.ver = nullptr;            // set by the twin step alone: every other caller sees a canonical table
+    s.twin = 0;
     return s;
 }
 
@@ -1295,7 +1404,7 @@ size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *off
 }
 
 static PassSide pass_side(const glove_plan *p, const glove_tables *t, const StepWs &w, bool row, bool want_e = false,
-                          int fuse = kFuseNone)
+                          int fuse = kFuseNone, bool twin = false)
 {
     PassSide sd;
     sd.partner = row ? p->r_partner : p->c_partner;
@@ -1320,16 +1429,22 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.own_bias_out = row ? t->br : t->bc;
     sd.S1 = row ? t->s1_R : t->s1_C;
     sd.S1b = row ? t->s1_br : t->s1_bc;
+    // the row table is the one that may be twinned: own of the row side, partner of the col side
+    sd.own_ver = twin && row ? t->R_ver : nullptr;
+    sd.other_ver = twin && !row ? t->R_ver : nullptr;
+    sd.own_twin = sd.other_twin = v_row(t);
     return sd;
 }
 
 // which: 1 = row side, 2 = col side, 3 = both in one launch
 static int launch_passes(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                          void *stream, int which, float *mark_rows = nullptr, float *mark_cols = nullptr,
-                         bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone)
+                         bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone, bool twin = false)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
-    const bool fuse = fuse_r != kFuseNone || fuse_c != kFuseNone;
+    const bool fuse = fuse_r != kFuseNone || fuse_c != kFuseNone || twin;
+    if ((twin || fuse_r == kFuseTwin) && !t->R_ver) return GLOVE_E_BADARG;
+    if (fuse_c == kFuseTwin) return GLOVE_E_BADARG;          // only the row table has a twin
     if (fuse && (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc)) return GLOVE_E_BADARG;
     // in place is only legal for a side whose table no concurrent chunk gathers from: one side per launch
     if ((fuse_r == kFuseInPlace && (which & 2)) || (fuse_c == kFuseInPlace && (which & 1))) return GLOVE_E_BADARG;
@@ -1340,7 +1455,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     const int per = fuse ? fuse_per(p, shape.lpr) : 1;
     const int row_blocks = !(which & 1) ? 0 : fuse ? fusepass_blocks(p, shape.lpr, per, true) : rowpass_blocks(p, shape.lpr);
     const int nb = row_blocks + (!(which & 2) ? 0 : fuse ? fusepass_blocks(p, shape.lpr, per, false) : rowpass_blocks(p, shape.lpr));
-    PassSide rs = pass_side(p, t, w, true, want_e, fuse_r), cs = pass_side(p, t, w, false, false, fuse_c);
+    PassSide rs = pass_side(p, t, w, true, want_e, fuse_r, twin), cs = pass_side(p, t, w, false, false, fuse_c, twin);
     rs.mark = mark_rows;
     cs.mark = mark_cols;
     const StepConsts kc = make_consts(t, h);
@@ -1401,7 +1516,13 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
     // workgroups of the row-side pass, whose loss partials the scalar duty sums (the first launch of the step)
     const int nb_row = fused ? fusepass_blocks(p, pass_shape(d4).lpr, wk.per, true) : rowpass_blocks(p, pass_shape(d4).lpr);
     const StepConsts k = make_consts(t, h);
-    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    SideBufs rs = side_bufs(p, w, t, true);
+    const SideBufs cs = side_bufs(p, w, t, false);
+    if (pre_r == kFuseTwin) {
+        if (!t->R_ver) return GLOVE_E_BADARG;
+        rs.ver = t->R_ver;
+        rs.twin = v_row(t);
+    }
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                          \
     hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4,        \
@@ -1565,8 +1686,8 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
     const StepConsts k = make_consts(t, h);
-    SideBufs rs = {nullptr, nullptr, nullptr, t->R, t->s1_R, t->br, t->s1_br};
-    SideBufs cs = {nullptr, nullptr, nullptr, t->C, t->s1_C, t->bc, t->s1_bc};
+    SideBufs rs = {nullptr, nullptr, nullptr, t->R, t->s1_R, t->br, t->s1_br, nullptr, 0};
+    SideBufs cs = {nullptr, nullptr, nullptr, t->C, t->s1_C, t->bc, t->s1_bc, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     // the scalar work (global bias, loss) goes with the col side, like everywhere else; without an explicit tail it
     // reads the headers of the first (up to eight) lists
@@ -1619,7 +1740,8 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are only known on the host for a plan whose build has been synchronised (a resident plan)
     const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
-    return ids * t->d * 16 >= ((int64_t)128 << 20) ? GLOVE_STEP_FUSED_THREE_LAUNCH : GLOVE_STEP_TWO_LAUNCH;
+    if (ids * t->d * 16 < ((int64_t)128 << 20)) return GLOVE_STEP_TWO_LAUNCH;
+    return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 
 int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
@@ -1637,13 +1759,37 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
         if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, false, kFuseSlot, kFuseNone)) return rc;
         if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 2, nullptr, nullptr, false, kFuseNone, kFuseInPlace)) return rc;
         return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseSlot, kFuseInPlace);
+    case GLOVE_STEP_FUSED_TWIN:
+        // as the three-launch form, but the row side writes its new rows into the other copy of the twinned row table:
+        // the col side keeps gathering the old rows from the current copy, and the apply launch only flips versions
+        if (!t->R_ver) return GLOVE_E_BADARG;
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, false, kFuseTwin, kFuseNone, true)) return rc;
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 2, nullptr, nullptr, false, kFuseNone, kFuseInPlace, true)) return rc;
+        return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseTwin, kFuseInPlace);
     case GLOVE_STEP_TWO_LAUNCH:
         break;
     default:
         return GLOVE_E_BADARG;
     }
+    // (a twinned table must be canonical here: glove_canonicalize_f32)
     if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
     return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
+}
+
+int glove_canonicalize_f32(const glove_tables *t, void *stream)
+{
+    if (!t || !t->R || !t->br || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    if (!t->R_ver) return 0;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    if (shape.lpr == 0) return GLOVE_E_BADARG;
+    const int Vr = v_row(t);
+    const int nb = blocks_for(Vr, kBlock / shape.lpr);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV) hipLaunchKernelGGL((canonicalize_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, t->R, t->br, t->R_ver, Vr, d4)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
 }
 
 int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t, const glove_hyper *h,

@@ -18,9 +18,9 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 3
+GLOVE_ABI_VERSION = 4
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
-STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH = 0, 1, 2, 3      # glove_hyper.step_form
+STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
 RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
-    "glove_gather_rows_f32",
+    "glove_gather_rows_f32", "glove_canonicalize_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -59,7 +59,7 @@ class GloveTables(C.Structure):
                 ("R", _fp), ("C", _fp), ("br", _fp), ("bc", _fp),
                 ("s1_R", _fp), ("s1_C", _fp), ("s1_br", _fp), ("s1_bc", _fp),
                 ("s2_R", _fp), ("s2_C", _fp), ("s2_br", _fp), ("s2_bc", _fp),
-                ("scalars", _fp), ("step", _fp)]
+                ("scalars", _fp), ("step", _fp), ("R_ver", _fp)]
 
 
 class GloveHyper(C.Structure):
@@ -128,6 +128,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
         "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
+        "glove_canonicalize_f32": (C.c_int, [P(GloveTables), vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
@@ -136,9 +137,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_cooccurrence_i32": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, sz, vp]),
     }
     for name, (res, args) in protos.items():
+        if path and os.environ.get("GLOVE_AB_ANY_ABI") and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.glove_abi_version() != GLOVE_ABI_VERSION:
+    if lib.glove_abi_version() != GLOVE_ABI_VERSION and not (path and os.environ.get("GLOVE_AB_ANY_ABI")):   # A/B tools load old builds
         raise GloveHipError("ABI mismatch: library %d, binding %d" % (lib.glove_abi_version(), GLOVE_ABI_VERSION))
     if path is None:
         _lib = lib
@@ -218,8 +221,9 @@ class DeviceTables:
             t[:, :self.d_model] = uni(rows, self.d_model)
             return t
 
-        self.R, self.C = table(self.V_row), table(self.V_col)
-        self.br, self.bc = uni(self.V_row), uni(self.V_col)
+        self._R, self.C = table(self.V_row), table(self.V_col)
+        self._br, self.bc = uni(self.V_row), uni(self.V_col)
+        self.R_ver = None           # uint8[V_row] once enable_twin() has doubled R and br (glove_tables.R_ver)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.s1, self.s2 = {}, {}
@@ -234,16 +238,76 @@ class DeviceTables:
             self.scalars[1] = 0.1
         self._struct = None
 
-    def struct(self) -> GloveTables:
+    # ---- the row table may be twinned (glove_tables.R_ver): R / br are the plain views [V_row, ...]; reading them
+    # (or handing the tables to anything but the Adagrad step) first brings the table back to its plain form
+    @property
+    def R(self) -> torch.Tensor:
+        self.canonicalize()
+        return self._R[:self.V_row]
+
+    @R.setter
+    def R(self, value):                     # `tables.R += x` and `tables.R = tensor` write into the buffer the kernels see
+        view = self.R
+        if value.data_ptr() != view.data_ptr():
+            view.copy_(value)
+
+    @property
+    def br(self) -> torch.Tensor:
+        self.canonicalize()
+        return self._br[:self.V_row]
+
+    @br.setter
+    def br(self, value):
+        view = self.br
+        if value.data_ptr() != view.data_ptr():
+            view.copy_(value)
+
+    def enable_twin(self):
+        """Second copy of the row table + per-row version bytes: lets the fused step write a row's update beside the old
+        row instead of through a partial-row slot (GLOVE_STEP_FUSED_TWIN).  Costs V_row x d x 4 B of HBM."""
+        if self.R_ver is not None or self.optimizer != "Adagrad":
+            return
+        if 2 * self.V_row * self.d * 4 >= 1 << 32:
+            return                               # 32-bit row offsets: the table cannot be doubled
+        for name in ("_R", "_br"):
+            old = getattr(self, name)
+            new = torch.zeros((2 * old.shape[0],) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+            new[:old.shape[0]].copy_(old)
+            setattr(self, name, new)
+        self.R_ver = torch.zeros(self.V_row, dtype=torch.uint8, device=self.device)
+        self._struct = None
+
+    def maybe_enable_twin(self):
+        """The policy: tables far beyond the caches (the regime of the fused step, cf. auto_chunk_cap) with wide rows get
+        the twin.  Measured per step, three-launch form -> twin form: V = 400 k, d = 300: 730 -> 684 us (the apply launch
+        loses its row copies: 108 -> 51 us; the col pass pays 12 us for looking up which copy of a partner row is
+        current); V = 2 M, d = 128: 562 -> 578 us (512-B rows: the lookups cost more than the copies saved)."""
+        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (256 << 20) and self.d >= 256:
+            self.enable_twin()
+
+    def canonicalize(self):
+        """Versions back to 0 (a no-op without a twin; one sweep over V_row bytes plus the rows whose second copy was
+        current).  Called by every accessor except the Adagrad step's."""
+        if self.R_ver is not None and getattr(self, "_twin_dirty", False):
+            self._twin_dirty = False
+            _check(load_library().glove_canonicalize_f32(C.byref(self.struct(twin_ok=True)), _stream()),
+                   "glove_canonicalize_f32")
+
+    def struct(self, twin_ok=False) -> GloveTables:
+        """`twin_ok`: the caller is the Adagrad step, which understands (and from now on may leave) a twinned table."""
+        if twin_ok:
+            self._twin_dirty = self.R_ver is not None
+        else:
+            self.canonicalize()
         if self._struct is None:
             s = GloveTables()
             s.V, s.d, s.V_row = self.V, self.d, (0 if self.V_row == self.V else self.V_row)
             s.d_model = 0 if self.d_model == self.d else self.d_model
             for n in self.NAMES:
-                setattr(s, n, _ptr(getattr(self, n)))
+                setattr(s, n, _ptr(getattr(self, "_" + n, None) if n in ("R", "br") else getattr(self, n)))
                 setattr(s, "s1_" + n, _ptr(self.s1[n]))
                 setattr(s, "s2_" + n, _ptr(self.s2.get(n)))
-            s.scalars, s.step = _ptr(self.scalars), _ptr(self.step)
+            s.scalars, s.step, s.R_ver = _ptr(self.scalars), _ptr(self.step), _ptr(self.R_ver)
             self._struct = s
         return self._struct
 
@@ -340,6 +404,7 @@ class TablesView:
         for name, _ in GloveTables._fields_:
             setattr(s, name, getattr(src, name))
         s.V, s.V_row = self.V, (0 if self.V_row == self.V else self.V_row)
+        s.R_ver = None                                           # views are plain: base.struct() above made the table canonical
         for name, tensor in replace.items():
             _require(tensor, torch.float32)
             setattr(s, name, tensor.data_ptr())
@@ -456,6 +521,14 @@ def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, bet
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
     h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
     return h
+
+
+def _step_struct(tables):
+    """The tables as the Adagrad step may see them: a twinned row table stays twinned between steps."""
+    try:
+        return tables.struct(twin_ok=True)
+    except TypeError:                        # a TablesView: plain struct
+        return tables.struct()
 
 
 class GloveHip:
@@ -603,7 +676,7 @@ class GloveHip:
     # ---- whole steps
     def step_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
-        _check(self.lib.glove_step_adagrad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+        _check(self.lib.glove_step_adagrad_f32(C.byref(plan.struct()), C.byref(_step_struct(tables)), C.byref(hyper),
                                                _ptr(ws), ws.numel(), _ptr(loss_out), _stream()),
                "glove_step_adagrad_f32")
 
@@ -614,7 +687,7 @@ class GloveHip:
         big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
         ws = self.step_workspace(big, tables.d)
         arr = (C.POINTER(GlovePlan) * len(plans))(*[C.pointer(p.struct()) for p in plans])
-        _check(self.lib.glove_steps_adagrad_f32(arr, len(plans), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
+        _check(self.lib.glove_steps_adagrad_f32(arr, len(plans), C.byref(_step_struct(tables)), C.byref(hyper), _ptr(ws),
                                                 ws.numel(), _ptr(loss_out), _stream()), "glove_steps_adagrad_f32")
 
     def step_adam(self, plan, tables, hyper, G_flat, loss_out=None, ws=None):

@@ -180,6 +180,8 @@ class Stepper:
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
         self.dense = self.world > 1 or tables.optimizer != "Adagrad"
+        if not self.dense and hasattr(tables, "maybe_enable_twin"):
+            tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(self.G.numel()) if self.G is not None else 0

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 3
+#define GLOVE_ABI_VERSION 4
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -53,6 +53,13 @@ typedef struct glove_tables {
     /* global_step (estimator.py:45), int64[1].  glove_rowpass_f32 advances it by one (it is
      * the first kernel of a step and does not read it); the apply kernels read t = *step. */
     int64_t *step;
+    /* Optional twin of the row table (NULL = none).  With it R has 2 x V_row rows and br 2 x V_row entries: row
+     * V_row + u is a second copy of row u, and R_ver[u] (uint8[V_row]) says which copy is current (0 = row u).  The
+     * fused twin step (GLOVE_STEP_FUSED_TWIN) writes a row's update into the copy that is not current and flips the
+     * version once every pass of the step has read the old one, which saves the trip of the new row through a partial-row
+     * slot.  EVERY other entry point expects the plain form — all versions 0, rows 0 .. V_row-1 current — which
+     * glove_canonicalize_f32 restores. */
+    uint8_t *R_ver;
 } glove_tables;
 
 typedef struct glove_hyper {
@@ -85,7 +92,10 @@ typedef struct glove_hyper {
      *                                  partial-row slot; the apply launch moves those rows into the tables and
      *                                  handles the ids with several chunks
      *   GLOVE_STEP_FUSED_THREE_LAUNCH  row side as above, then the col side in a launch of its own, updating C and
-     *                                  bc in place (nothing reads them any more), then the apply launch */
+     *                                  bc in place (nothing reads them any more), then the apply launch
+     *   GLOVE_STEP_FUSED_TWIN          the three-launch form on a twinned row table (glove_tables.R_ver): the row side
+     *                                  writes its new rows into the other copy, the apply launch only flips versions
+     *                                  (AUTO picks it whenever R_ver is set and the fused form pays) */
     int32_t step_form;
 } glove_hyper;
 
@@ -96,6 +106,7 @@ typedef struct glove_hyper {
 #define GLOVE_STEP_TWO_LAUNCH 1
 #define GLOVE_STEP_FUSED_ONE_PASS 2
 #define GLOVE_STEP_FUSED_THREE_LAUNCH 3
+#define GLOVE_STEP_FUSED_TWIN 4
 
 /*
  * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,
@@ -252,6 +263,9 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
 /* ---- whole step = session.run(train_op) (estimator.py:49-56) ------------------------------ */
 int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                            void *ws, size_t ws_bytes, float *loss_out, void *stream);
+/* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
+ * cleared.  A no-op without a twin.  Call before anything but glove_step(s)_adagrad_f32 reads or writes R / br. */
+int glove_canonicalize_f32(const glove_tables *t, void *stream);
 /* n consecutive Adagrad steps, plans[i] in order, from ONE host call (the launch loop runs in C: a Python
  * host loop costs more per step than the two kernels of a 1,024-pair step take).  loss_out, if not NULL,
  * receives the scalars of the LAST step. */

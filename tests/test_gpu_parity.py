@@ -738,6 +738,45 @@ def test_row_sharded_pieces_on_one_gpu(hip, B, V, d, W):
     assert torch.equal(a.scalars, b.scalars)
 
 
+@pytest.mark.parametrize("B,V,d,cap", STEP_CASES[:14:2] + [(9000, 20000, 300, 16), (30000, 300000, 128, 16), (50000, 3000, 64, 8),
+                                                          (20000, 5, 32, 8), (700, 60, 301, 32)])
+def test_twinned_row_table_step_equals_the_three_launch_form_bitwise(hip, B, V, d, cap):
+    """GLOVE_STEP_FUSED_TWIN: the row side's new rows go into the other copy of a twinned row table and the apply launch
+    flips versions — the arithmetic of the three-launch form, so the tables agree bit for bit after every step, whatever
+    mixture of copies is current; reading R / br (or any other entry point) first restores the plain form."""
+    from trainer.hip_api import DeviceTables
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    b.enable_twin()
+    assert b.R_ver is not None and b._R.shape[0] == 2 * V and b.R.shape[0] == V
+    hp = ref.Hyper(learning_rate=0.05)
+    batches = [make_batch(B * 3 + d + k, B, V) for k in range(3)]
+    plans = []
+    for bt in batches:
+        pl = hip.build_plan(*to_dev(*bt), V, chunk_cap=cap).compact(hip.lib)
+        if pl.r_crec is None:
+            pl = hip.build_plan(*to_dev(*bt), V, chunk_cap=max(1, min(cap, 2))).compact(hip.lib)
+        plans.append(pl)
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    for k in (0, 1, 2, 1, 0, 2, 2):
+        hip.step_adagrad(plans[k], a, _hyper(hp, B, step_form=3), la)
+        hip.step_adagrad(plans[k], b, _hyper(hp, B, step_form=4), lb)
+        assert torch.equal(la, lb)
+        if k == 1:                            # look at the tables mid-run: canonicalises, stepping goes on from there
+            _assert_same_bits(a, b, "mid-run")
+    flipped = int(b.R_ver.sum())              # raw state: some rows live in the second copy ...
+    assert plans[0].r_crec is None or V < 8 or flipped > 0
+    _assert_same_bits(a, b)                   # ... reading R / br brings them home
+    assert int(b.R_ver.sum()) == 0
+    # an oracle step from here (state_dict of the twinned tables is the plain model)
+    sd = b.state_dict()
+    assert sd["R"].shape == (V, d) and torch.equal(sd["R"], a.state_dict()["R"])
+    # without a twin the form is refused, not silently replaced
+    from trainer.hip_api import GloveHipError
+    with pytest.raises(GloveHipError):
+        hip.step_adagrad(plans[0], a, _hyper(hp, B, step_form=4), la)
+
+
 @pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2), (3000, 150, 50, 16),
                                        (2000, 5000, 20, 8), (9000, 40000, 64, 16)])
 def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--caps", default="32,16")
     ap.add_argument("--libs", default="", help="comma-separated builds of libglove_hip.so to compare (default: the shipped one)")
+    ap.add_argument("--step-form", type=int, default=0)
+    ap.add_argument("--only", default="", help="comma-separated subset of rowpass,colpass,passes,apply,step")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=40)
     args = ap.parse_args()
@@ -31,12 +33,12 @@ def main():
     V, d, B = wl["V"], wl["d"], args.batch_size
     nb = min(8, wl["row"].numel() // B)
     tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
-    hyper = make_hyper(learning_rate=0.05, batch_size=B)
+    hyper = make_hyper(learning_rate=0.05, batch_size=B, step_form=args.step_form)
     loss = torch.zeros(4, device=dev)
     configs = []
     for cap in [int(c) for c in args.caps.split(",")]:
         plans = [hip.build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
-                                chunk_cap=cap, compact=True) for b in range(nb)]
+                                chunk_cap=cap, compact=True, d=(d + 3) // 4 * 4) for b in range(nb)]
         for v in range(len(hips)):
             configs.append((cap, v, plans))
     ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
@@ -45,7 +47,7 @@ def main():
     for rnd in range(args.rounds + 1):
         for cap, v, plans in configs:
             hip = hips[v]
-            for name in ("rowpass", "colpass", "passes", "apply", "step"):
+            for name in [n for n in ("rowpass", "colpass", "passes", "apply", "step") if not args.only or n in args.only.split(",")]:
                 fn = {"rowpass": lambda p: hip.rowpass(p, tables, hyper, ws),
                       "passes": lambda p: hip.passes(p, tables, hyper, ws),
                       "colpass": lambda p: hip.colpass(p, tables, hyper, ws),
@@ -64,7 +66,7 @@ def main():
     print("%s B=%d d=%d  (us per launch incl. launch gaps; median / min over %d rounds)" % (args.workload, B, d, args.rounds))
     for (cap, v), r in res.items():
         print("cap=%-3d lib=%s  " % (cap, libs[v] or "shipped") + "  ".join(
-            "%s %.2f/%.2f" % (k, statistics.median(x), min(x)) for k, x in r.items()))
+            "%s %.2f/%.2f" % (k, statistics.median(x), min(x)) for k, x in r.items() if x))
 
 
 if __name__ == "__main__":
