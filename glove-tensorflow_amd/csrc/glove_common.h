@@ -97,6 +97,7 @@ struct StepWs {
     float *gb_r;     // [cap_chunks]   row-side chunk partial bias gradients (sum e)
     float *gb_c;     // [cap_chunks]
     float *blockpart;  // [kMaxBlocks*kPartials]
+    int32_t *work;     // [4 + 2*cap_chunks] fused step forms: count + positions of the ids the apply launch still has to do
     size_t bytes;
 };
 
@@ -116,6 +117,7 @@ inline StepWs carve_step_ws(void *ws, int64_t B, int32_t cap_chunks, int32_t d)
     s.gb_r = take((size_t)cap_chunks);
     s.gb_c = take((size_t)cap_chunks);
     s.blockpart = take((size_t)kMaxBlocks * kPartials);
+    s.work = (int32_t *)take((size_t)4 + 2 * (size_t)cap_chunks);
     s.bytes = off;
     return s;
 }

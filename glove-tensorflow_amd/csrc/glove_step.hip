@@ -244,7 +244,7 @@ template <int LPR, int NV, bool FULL, bool REC, bool FUSE>
 __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
-    float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per)
+    float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
 {
     constexpr int GPB = kBlock / LPR;
     constexpr int U = PassUnroll<NV>::value;
@@ -266,7 +266,10 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
     GLOVE_STAMP(0);
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
-    if (is_row && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;   // global_step (see glove_hip.h)
+    if (is_row && blockIdx.x == 0 && threadIdx.x == 0) {
+        *step += 1;                         // global_step (see glove_hip.h)
+        if (FUSE && work) work[0] = 0;      // the apply side's work list starts empty (triage_kernel)
+    }
 
     // loss partials (row side only): [0] sum e diff (= 2 inv_batch sum w diff^2), [1] sum |r|^2+|c|^2,
     // [2] sum b^2, [3] sum e
@@ -561,6 +564,8 @@ struct IdWork {
     int sides;                  // 1 = rows only, 2 = cols only, 3 = both
     int pre_r, pre_c;           // what a FUSE pass already did for the ids one run held completely (kFuse*), per side
     int per;                    // consecutive chunks per group of that FUSE pass
+    const int32_t *work;        // not null: triage_kernel listed the light ids that still need this launch: work[0] = their
+                                // number, work[4 ...] = their positions q (row ids first, col ids behind nu_r)
 };
 
 // The partial rows of one id.  Classic passes: one per chunk, slots f .. f+n-1 (per == 1).  FUSE passes: one per run, a
@@ -686,7 +691,10 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
     // the last workgroup of the grid only does the once-per-step scalar work, beside everyone else
     if ((int)blockIdx.x == nblocks - 1) return (wk.sides & 2) != 0;
     const int lb = blockIdx.x - wk.heavy_blocks, nlb = nblocks - wk.heavy_blocks - 1;
-    for (int q = q_begin + lb * GPB + grp; q < total; q += nlb * GPB) {
+    // behind a FUSE pass triage_kernel has listed the few ids that still need work: walk that list instead of all ids
+    const int n_items = wk.work ? wk.work[0] : total - q_begin;
+    for (int it = lb * GPB + grp; it < n_items; it += nlb * GPB) {
+        const int q = wk.work ? wk.work[4 + it] : q_begin + it;
         const bool is_row = q < nu_r;
         const SideBufs &sb = is_row ? rs : cs;
         const int qq = is_row ? q : q - nu_r;
@@ -770,6 +778,31 @@ __device__ inline void loss_from_partials(const float (&tot)[kPartials], const S
     L = tot[0] * k.inv_batch;
     reg = k.l2 * k.inv_d * k.inv_batch * tot[1] + k.l2 * k.inv_batch * tot[2] + k.l2 * g * g;
     loss = L + k.m * reg;
+}
+
+// Behind a FUSE pass most ids are finished: the launch that applies the rest spent its time on one dependent record load
+// per id, 20 ids per lane group in a row (V = 400 k: 57 us for 24 MB of traffic).  One THREAD per distinct id sorts
+// them out first: finished ids of a twinned row table get their version flipped right here, finished ids of the
+// in-place side need nothing, and the positions of the light ids that still need work — a copy out of a slot, or the
+// sum of several runs — go onto a list (work[0] counts them; the row pass zeroed it).  The list's order varies from
+// run to run, the work items are independent: results do not depend on it.  Heavy ids keep their own workgroups.
+__global__ __launch_bounds__(kBlock) void triage_kernel(IdWork wk, SideBufs rs, SideBufs cs, int32_t *__restrict__ work)
+{
+    const int nu_r = wk.nu_r_host >= 0 ? wk.nu_r_host : wk.counts[1];
+    const int nu_c = wk.nu_c_host >= 0 ? wk.nu_c_host : wk.counts[3];
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nu_r + nu_c) return;
+    const bool is_row = q < nu_r;
+    const int4 rec = is_row ? reinterpret_cast<const int4 *>(rs.uniq_rec)[q] : reinterpret_cast<const int4 *>(cs.uniq_rec)[q - nu_r];
+    if (rec.z > wk.heavy_chunks) return;
+    const int pre = is_row ? wk.pre_r : wk.pre_c;
+    const bool whole = pre != kFuseNone && Slots(rec.y, rec.z, wk.per).count == 1;
+    if (whole && pre == kFuseInPlace) return;
+    if (whole && pre == kFuseTwin) {
+        rs.ver[rec.x] ^= 1;                 // ids are distinct: one thread per byte
+        return;
+    }
+    work[4 + atomicAdd(work, 1)] = q;
 }
 
 template <int LPR, int NV>
@@ -1324,6 +1357,7 @@ static IdWork id_work(const glove_plan *p)
     w.sides = 3;
     w.pre_r = w.pre_c = kFuseNone;
     w.per = 1;
+    w.work = nullptr;
     return w;
 }
 
@@ -1460,7 +1494,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     cs.mark = mark_cols;
     const StepConsts kc = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per
+#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;
 #define LAUNCH(LPR, NV, FULL, REC, FUSE) \
     hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
@@ -1524,6 +1558,16 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
         rs.twin = v_row(t);
     }
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_triage = getenv("GLOVE_NO_TRIAGE") != nullptr;        // experiments
+    if (pre_r == kFuseTwin && pre_c == kFuseInPlace && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0 && wk.sides == 3 && !no_triage) {
+        // sort the ids out first (triage_kernel, a thread per id): the launch below then walks the list of those that
+        // still need it.  Only where that list is short — the twin form, whose finished ids need a version flip at most
+        // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage).  Behind the slot form every row id still needs its
+        // copy, nearly all ids go onto the list and its one counter becomes the bottleneck (V = 2 M: 51 us of triage)
+        wk.work = w.work;
+        const int nbt = (int)(((int64_t)wk.nu_r_host + wk.nu_c_host + kBlock - 1) / kBlock);
+        if (nbt > 0) hipLaunchKernelGGL(triage_kernel, dim3(nbt), dim3(kBlock), 0, st, wk, rs, cs, w.work);
+    }
 #define CALL(LPR, NV)                                                                                          \
     hipLaunchKernelGGL((apply_adagrad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4,        \
                        k, t->scalars, w.blockpart, nb_row, loss_out)

@@ -478,7 +478,11 @@ class Plan:
         out.B, out.V, out.chunk_cap, out.V_row = self.B, self.V, self.chunk_cap, self.V_row
         out.cap_chunks, out.cap_uniq = max(nc_r, nc_c), max(nu_r, nu_c)
         out.counts = self.counts.clone()
-        out.host_counts = [nc_r, nu_r, nc_c, nu_c, n_heavy, -1, -1, -1]
+        most = 0                 # the most chunks of one id (uniq_rec = {id, first chunk, chunks, pairs}); same sync as above
+        if self.B > 0:
+            most = int(max(self.r_uniq_rec[2:4 * nu_r:4].max().item() if nu_r else 0,
+                           self.c_uniq_rec[2:4 * nu_c:4].max().item() if nu_c else 0))
+        out.host_counts = [nc_r, nu_r, nc_c, nu_c, n_heavy, -1, most, -1]
         out.heavy_chunks, out.cap_heavy = self.heavy_chunks, max(n_heavy, 1)
         out.heavy = self.heavy[:max(n_heavy, 1)].clone()
         out.r_partner, out.r_w, out.r_y, out.r_to_c = self.r_partner, self.r_w, self.r_y, self.r_to_c

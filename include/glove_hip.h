@@ -129,7 +129,9 @@ typedef struct glove_plan {
     int32_t *counts;            /* int32[8]: chunks_row, uniq_row, chunks_col, uniq_col, heavy,
                                  * ids outside [0,V) that were mapped to 0, 0, 0 */
     /* host copy of counts for plans whose build has completed (a resident plan of a static
-     * stream): saves the kernels one dependent load.  -1 = unknown, read `counts` on the device. */
+     * stream): saves the kernels one dependent load.  -1 = unknown, read `counts` on the device.
+     * [6] (host only) = the most chunks any one id of the batch has, or -1: sizes the grid that pre-sums the partial
+     * rows of the heaviest ids in the fused step forms. */
     int32_t host_counts[8];
     /* row side: position k = k-th pair in (row id, original order) order */
     int32_t *r_partner;         /* [B] col id of pair k */

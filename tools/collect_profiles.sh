@@ -28,6 +28,9 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
   grep '"metric"' $raw/stats.log
   echo
   python3 tools/prof_summary.py $raw/stats 12
+  echo
+  echo "# the fused step's launches apart (rocprofv3 --kernel-trace CSV of the same run, tools/kt_triples.py):"
+  python3 tools/kt_triples.py $raw/stats
 } > $out/${tag}_${name}_kernel_stats.txt
 cap=$(grep -o '"chunk_cap": [0-9]*' $raw/stats.log | head -1 | grep -o '[0-9]*$')
 python3 tools/pmc_traffic.py $raw/fetch $raw/write $out/${tag}_${name}_traffic.json workload=$wl batch=$batch chunk_cap=$cap \

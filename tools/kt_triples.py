@@ -16,17 +16,26 @@ def kind(r):
     n = r["Kernel_Name"].split("(")[0]
     if "sidepass" in n:
         return "pass_fused" if n.rstrip().endswith("true>") else "pass"
-    return "apply" if "apply_adagrad" in n else "other"
+    return "apply" if "apply_adagrad" in n else "triage" if "triage" in n else "other"
 
 
 seq = [(kind(r), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Start_Timestamp"]) / 1e3, int(r["End_Timestamp"]) / 1e3) for r in rows]
-tri = [(seq[i], seq[i + 1], seq[i + 2]) for i in range(len(seq) - 2)
-       if seq[i][0] == "pass_fused" and seq[i + 1][0] == "pass_fused" and seq[i + 2][0] == "apply"][5:]
+tri = []
+for i in range(len(seq) - 2):
+    if seq[i][0] == "pass_fused" and seq[i + 1][0] == "pass_fused":
+        j = i + 2
+        red = None
+        if seq[j][0] == "triage" and j + 1 < len(seq):
+            red, j = seq[j], j + 1
+        if seq[j][0] == "apply":
+            tri.append((seq[i], seq[i + 1], seq[j], red))
+tri = tri[5:]
 if tri:
     med = lambda xs: st.median(xs)
-    print("%s: %d fused steps: row pass %.1f us, col pass %.1f us, apply %.1f us, gaps %.1f + %.1f us, step %.1f us" % (
-        sys.argv[1], len(tri), med([t[0][1] for t in tri]), med([t[1][1] for t in tri]), med([t[2][1] for t in tri]),
-        med([t[1][2] - t[0][3] for t in tri]), med([t[2][2] - t[1][3] for t in tri]), med([t[2][3] - t[0][2] for t in tri])))
+    reds = [t[3][1] for t in tri if t[3] is not None]
+    print("%s: %d fused steps: row pass %.1f us, col pass %.1f us, id triage %s us, apply %.1f us, step (first start to last end) %.1f us" % (
+        sys.argv[1], len(tri), med([t[0][1] for t in tri]), med([t[1][1] for t in tri]),
+        ("%.1f" % med(reds)) if reds else "-", med([t[2][1] for t in tri]), med([t[2][3] - t[0][2] for t in tri])))
 cl = [(seq[i][1], seq[i + 1][1]) for i in range(len(seq) - 1) if seq[i][0] == "pass" and seq[i + 1][0] == "apply"]
 if cl:
     print("%s: %d two-launch steps: passes %.1f us, apply %.1f us" % (sys.argv[1], len(cl), st.median(c[0] for c in cl), st.median(c[1] for c in cl)))

@@ -11,17 +11,20 @@ import sys
 from collections import defaultdict
 
 
-def per_kernel(d, counter):
+def per_kernel(d, counter, totals=None):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and "glove::" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0].replace("void glove::", "")].append(float(r["Counter_Value"]))
+    if totals is not None:
+        totals.update({k: (sum(v), len(v)) for k, v in acc.items()})
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
 def main():
-    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    ftot, wtot = {}, {}
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", ftot), per_kernel(sys.argv[2], "WRITE_SIZE", wtot)
     meta = dict(kv.split("=", 1) for kv in sys.argv[4:])
     out = {"meta": meta, "kernels": {}}
     step = ("sidepass", "rowpass", "colpass", "apply_adagrad")          # the kernels of one sparse-Adagrad step
@@ -29,9 +32,13 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         rd, wr = 2.0 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
         out["kernels"][k] = {"FETCH_SIZE_KiB_raw": fetch.get(k), "WRITE_SIZE_KiB_raw": write.get(k),
-                             "read_bytes_corrected": rd, "write_bytes": wr}
-        if any(k.startswith(x) for x in step):
-            total += rd + wr
+                             "read_bytes_corrected": rd, "write_bytes": wr, "dispatches": ftot.get(k, (0, 0))[1]}
+    # a step = every launch of the step's kernels between two apply launches (the fused forms launch the pass kernel
+    # twice): all their bytes over all dispatches, divided by the number of steps = apply launches
+    def per_step(tot, scale):
+        steps = sum(n for k, (_, n) in tot.items() if k.startswith("apply_adagrad"))
+        return scale * 1024 * sum(s_ for k, (s_, _) in tot.items() if any(k.startswith(x) for x in step)) / max(steps, 1)
+    total = per_step(ftot, 2.0) + per_step(wtot, 1.0)
     out["traffic_bytes_per_step"] = total
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["traffic_bytes_per_step"]))
