@@ -293,7 +293,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         nb = int(agreed.item())
 
     tables = DeviceTables(V, d, optimizer, device=dev, seed=1, V_row=V_row, V_col=V_col)   # identical replicas on every rank
-    if mode == "single" and step_form in (0, 4):
+    if mode == "single" and step_form == 4:
+        tables.enable_twin()
+    elif mode == "single" and step_form == 0:
         tables.maybe_enable_twin()
     backend = HipBackend(dev)
     backend.hip = hip

@@ -1784,7 +1784,8 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are only known on the host for a plan whose build has been synchronised (a resident plan)
     const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
-    if (ids * t->d * 16 < ((int64_t)128 << 20)) return GLOVE_STEP_TWO_LAUNCH;
+    // (V = 50 k, d = 300, 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches 104 us, fused 109)
+    if (ids * t->d * 16 < ((int64_t)512 << 20)) return GLOVE_STEP_TWO_LAUNCH;
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 

@@ -26,7 +26,7 @@ RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk record
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
-FUSED_STEP_BYTES = 128 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
+FUSED_STEP_BYTES = 512 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -278,11 +278,11 @@ class DeviceTables:
         self._struct = None
 
     def maybe_enable_twin(self):
-        """The policy: tables far beyond the caches (the regime of the fused step, cf. auto_chunk_cap) with wide rows get
-        the twin.  Measured per step, three-launch form -> twin form: V = 400 k, d = 300: 730 -> 684 us (the apply launch
-        loses its row copies: 108 -> 51 us; the col pass pays 12 us for looking up which copy of a partner row is
-        current); V = 2 M, d = 128: 562 -> 578 us (512-B rows: the lookups cost more than the copies saved)."""
-        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (256 << 20) and self.d >= 256:
+        """The policy: tables far beyond the caches (the regime of the fused step, cf. auto_chunk_cap) get the twin.
+        Measured per step, three-launch form -> twin form with its id triage: V = 400 k, d = 300: 678 -> 627 us;
+        V = 2 M, d = 128: 578 -> 539 us (the passes pay ~20 us each for looking up which copy of a row is current, the
+        apply launch shrinks from 95 to 15 us); V = 50 k, d = 300 (Infinity-Cache resident): no gain, not enabled."""
+        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (256 << 20):
             self.enable_twin()
 
     def canonicalize(self):
