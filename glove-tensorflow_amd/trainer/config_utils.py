@@ -69,6 +69,8 @@ FLAGS = (
     Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
                                      "nonzero to the rank that owns its row, instead of replicating all tables "
                                      "(BASELINE config 5; Adagrad only)"),
+    Flag("step-form", int, 0, "form of the single-GPU sparse Adagrad step (glove_hyper.step_form): 0 the library chooses, "
+                              "1 two launches, 2 / 3 fused forms, 4 fused on a twinned row table"),
     Flag("exchange", str, "auto", "multi-GPU gradient exchange: dense (all-reduce of the [V,d] gradient buffer), rows "
                                   "(all-gather of the touched rows' summed gradients), auto (rows when that is the "
                                   "shorter payload for the resident batches)"),

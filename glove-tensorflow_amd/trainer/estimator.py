@@ -136,6 +136,10 @@ class Estimator:
         stream = self.stream()
         hyper_kwargs = dict(l2_reg=p["l2_reg"], reg_mult=p.get("reg_multiplicity", 2.0),
                             learning_rate=p["learning_rate"])
+        if p.get("step_form"):
+            hyper_kwargs["step_form"] = int(p["step_form"])
+            if int(p["step_form"]) == 4 and self.world == 1:
+                tables.enable_twin()        # the form needs the second copy of the row table
         if self.logistic:       # logistic_matrix_factorisation.py:50-54: the stream's (w, y) are (pos, neg) weights
             hyper_kwargs.update(head=1, neg_factor=p.get("neg_factor", 1.0))
         log_every = max(1, int(p.get("log_every", 100)))

@@ -164,6 +164,34 @@ def test_whole_pipeline_recovers_planted_topics(hip, tmp_path):
     assert total >= topics * words_per * 9 and same / total > 0.6, (same, total)       # chance level: 0.12; 0.76 observed
 
 
+def test_cli_on_a_twinned_row_table_equals_the_three_launch_form(hip, tmp_path):
+    """--step-form 4 end to end: training on a twinned row table (new rows written beside the old ones, versions
+    flipped per step), with logging, eval, checkpoints, resume and export in between — every reader first brings the
+    table back to its plain form — gives the tables of --step-form 3, bit for bit (the forms share their arithmetic)."""
+    from trainer import estimator, export_embeddings
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    state = {}
+    for form in (3, 4):
+        job = tmp_path / ("job%d" % form)
+        argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+                "--embedding-size", "50", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
+                "--step-form", str(form), "--chunk-cap", "2", "--train-steps", "45", "--log-every", "15", "--seed", "7"]
+        estimator.main(argv)
+        estimator.main(argv[:-6] + ["--train-steps", "90", "--log-every", "15", "--seed", "7"])      # resume from the checkpoint
+        state[form] = torch.load(job / "model.ckpt-90.pt")
+        out = tmp_path / ("emb%d.json" % form)
+        export_embeddings.main(job_dir=str(job), embeddings_json=str(out))
+        state[str(form)] = out.read_text()
+        log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+        assert log[-1]["global_step"] == 90 and log[-1]["loss"] < log[0]["loss"]
+    tensors = 0
+    for k, v in state[3]["tables"].items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, state[4]["tables"][k]), k
+            tensors += 1
+    assert tensors >= 9 and state["3"] == state["4"]
+
+
 def _two_rank_trainer(rank, port, argv, out_dir):
     """One rank of `python -m trainer.estimator` under a launcher, both ranks on the box's one GPU: the HIP
     kernels are the product's, only the transport of the collectives is gloo instead of RCCL."""
