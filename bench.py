@@ -607,7 +607,10 @@ def main(argv=None):
                   ("c5_zipf_v2m_d128_one_gpu_shard", dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4)),
                   ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001))]
                  if world == 1 else
+                 # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), the same workload
+                 # with both tables sharded (traffic follows the batch, not the vocabulary), and config 5
                  [("c4_zipf_v400k_d300_data_parallel", dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3)),
+                  ("c4_zipf_v400k_d300_both_tables_sharded", dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="sharded")),
                   ("c5_zipf_v2m_d128_both_tables_sharded", dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
         configs = []
         for name, spec in specs:
