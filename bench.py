@@ -78,6 +78,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of all CPU legs together")
     ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
     ap.add_argument("--single", action="store_true", help="only the named workload (no configs[] array)")
+    ap.add_argument("--with-configs", action="store_true", help="the configs[] array also under --rehearse-on-one-gpu")
     ap.add_argument("--min-timed-ms", type=float, default=20.0,
                     help="the timed region of --steps steps is repeated until this much time has been measured; the "
                          "median repeat is reported")
@@ -598,7 +599,7 @@ def main(argv=None):
     out = run_config(ctx, args.workload, args.batch_size, args.optimizer, mode, args.steps, args.warmup,
                      dynamic=args.dynamic, build_ahead=args.build_ahead, **common)
     plain = not (args.single or args.dynamic or args.optimizer != "Adagrad" or mode != "auto" or args.step_form or
-                 args.chunk_cap or args.rehearse_on_one_gpu)
+                 args.chunk_cap or (args.rehearse_on_one_gpu and not args.with_configs))
     if plain:
         # the other configurations of BASELINE.json / BASELINE.md §3 in the same line: where HBM is the bound
         extra = dict(lr=args.learning_rate, max_batches=8, min_timed_ms=args.min_timed_ms, exchange=args.exchange)
