@@ -606,7 +606,10 @@ def main(argv=None):
         specs = ([("c3_text8_v50k_d300", dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
                   ("c4_zipf_v400k_d300_one_gpu_shard", dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4)),
                   ("c5_zipf_v2m_d128_one_gpu_shard", dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4)),
-                  ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001))]
+                  ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
+                  # the headline workload at the reference's batch size and at (nearly) the whole stream per step
+                  ("text8_d64_bs1024", dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
+                  ("text8_d64_bs1048576", dict(workload="text8_d64", B=1048576, steps=100, warmup=10))]
                  if world == 1 else
                  # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), the same workload
                  # with both tables sharded (traffic follows the batch, not the vocabulary), and config 5
