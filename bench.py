@@ -131,16 +131,19 @@ def algorithmic_bytes(B, d, u_row, u_col):
     return 16 * B + 16 * (d + 1) * (u_row + u_col)
 
 
-def measured_traffic(workload, B, cap):
+def measured_traffic(workload, B, cap, fused):
     """HBM-side bytes per step from the committed PMC summary of this exact configuration
     (profiles/*_traffic.json, produced by tools/pmc_traffic.py from separate `rocprofv3 --pmc`
-    passes of this bench); None when no summary matches."""
+    passes of this bench); None when no summary matches.  `fused`: the step ran in a fused form — a summary counts
+    when its pass kernel is of the same kind (last template argument of `sidepass_kernel<...>`)."""
     import glob
     for f in sorted(glob.glob(str(REPO / "profiles" / "*_traffic.json")), reverse=True):
         try:
             j = json.load(open(f))
             m = j.get("meta", {})
-            if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap:
+            prof_fused = any(k.startswith("sidepass_kernel") and k.rstrip().endswith("true>") for k in j.get("kernels", {}))
+            if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap \
+                    and prof_fused == bool(fused):
                 return float(j["traffic_bytes_per_step"]), os.path.basename(f)
         except (OSError, ValueError, KeyError):
             continue
@@ -296,8 +299,6 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     tables = DeviceTables(V, d, optimizer, device=dev, seed=1, V_row=V_row, V_col=V_col)   # identical replicas on every rank
     if mode == "single" and step_form == 4:
         tables.enable_twin()
-    elif mode == "single" and step_form == 0:
-        tables.maybe_enable_twin()
     backend = HipBackend(dev)
     backend.hip = hip
     backend.row_floats = tables.d
@@ -331,6 +332,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
         stepper.prepare(plans)
 
+    if mode == "single" and step_form == 0 and not adam and plans[0].r_crec is not None and \
+            (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES:
+        tables.maybe_enable_twin()          # the library will take a fused form: give it the twinned row table (as Stepper does)
     hyper = make_hyper(batch_size=B * world, **hyper_kw)
     loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, device=dev)
     ws = None
@@ -411,6 +415,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             step(first + i)
 
     run(warmup, 0)
+    if graph is not None and warmup < spg:
+        graph.replay()                       # the graph's first replay carries its one-time upload: never inside the clock
     # the timed region: exactly `steps` steps between barrier + synchronize on both sides, MAX over ranks; repeated
     # until at least min_timed_ms have been measured (a single transient cannot swing the figure), median reported
     elapsed_all, total = [], 0.0
@@ -503,7 +509,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     step_us = sum(kern.values())
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (step_us * 1e-6) / 1e9
-    traffic, traffic_src = measured_traffic(workload, B, cap) if mode == "single" else (None, None)
+    traffic, traffic_src = measured_traffic(workload, B, cap, any(k.startswith("step_fused") for k in kern)) \
+        if mode == "single" and not adam else (None, None)
     rows = getattr(stepper, "rows", False)
     parallelism = {"single": "single GPU",
                    "dp": "dp%d, %s" % (world, "touched-rows all-gather" if rows else "dense-grad all-reduce"),

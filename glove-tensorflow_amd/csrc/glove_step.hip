@@ -1378,17 +1378,22 @@ static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
 
 static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_for(p->cap_chunks, kBlock / lpr); }
 
-// FUSE passes: consecutive chunks per lane group.  At least 4 (a heavy id then leaves one partial row per 4 chunks
-// instead of one per chunk, and an id of up to 4 chunks is usually applied by the pass itself; 1 ... 8 measured alike at
-// V = 400 k, d = 300, 16 and 32 slower: fewer, longer-running groups), more when the plan has more chunks than
-// kMaxBlocks workgroups of such groups cover (the loss partials are kept per workgroup).  GLOVE_FUSE_PER overrides
-// the minimum (experiments).
+// FUSE passes: consecutive chunks per lane group.  Up to 4 (a heavy id then leaves one partial row per 4 chunks instead of
+// one per chunk, and an id of up to 4 chunks is usually applied by the pass itself; 1 ... 8 measured alike at V = 400 k,
+// d = 300, B = 1 M, 16 and 32 slower: fewer, longer-running groups), fewer when the side has too few chunks to fill the
+// chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 / 103 / 106), more
+// when the plan has more chunks than kMaxBlocks workgroups of such groups cover (the loss partials are kept per
+// workgroup).  GLOVE_FUSE_PER overrides the choice below the last rule (experiments).
 static int fuse_per(const glove_plan *p, int lpr)
 {
-    static const int floor_ = [] { const char *e = getenv("GLOVE_FUSE_PER"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    static const int forced = [] { const char *e = getenv("GLOVE_FUSE_PER"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int64_t side = p->host_counts[0] >= 0 && p->host_counts[2] >= 0
+                             ? (p->host_counts[0] > p->host_counts[2] ? p->host_counts[0] : p->host_counts[2]) : p->cap_chunks;
+    int per = forced ? forced : (int)(side / 16384);
+    if (!forced) per = per < 1 ? 1 : per > 4 ? 4 : per;
     const int64_t groups = (int64_t)kMaxBlocks * (kBlock / lpr);
     const int need = (int)((p->cap_chunks + groups - 1) / groups);
-    return need > floor_ ? need : floor_;
+    return need > per ? need : per;
 }
 static inline int fusepass_blocks(const glove_plan *p, int lpr, int per, bool row)
 {
@@ -1784,8 +1789,9 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are only known on the host for a plan whose build has been synchronised (a resident plan)
     const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
-    // (V = 50 k, d = 300, 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches 104 us, fused 109)
-    if (ids * t->d * 16 < ((int64_t)512 << 20)) return GLOVE_STEP_TWO_LAUNCH;
+    // (V = 50 k, d = 300, B = 131,072: 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches
+    // 106 us, fused 103 - 111; V = 400 k at B = 131,072, 336 MB: 172 against 156; V = 50 k at B = 1 M, 432 MB: 378 against 314)
+    if (ids * t->d * 16 < ((int64_t)256 << 20)) return GLOVE_STEP_TWO_LAUNCH;
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 

@@ -26,7 +26,7 @@ RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk record
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
-FUSED_STEP_BYTES = 512 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
+FUSED_STEP_BYTES = 256 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -278,26 +278,26 @@ class DeviceTables:
         self._struct = None
 
     def maybe_enable_twin(self):
-        """The policy: tables far beyond the caches (the regime of the fused step, cf. auto_chunk_cap) get the twin.
+        """The policy: row tables of 32 MB and more — the ones whose batches can reach the fused step's regime — get the twin.
         Measured per step, three-launch form -> twin form with its id triage: V = 400 k, d = 300: 678 -> 627 us;
         V = 2 M, d = 128: 578 -> 539 us (the passes pay ~20 us each for looking up which copy of a row is current, the
         apply launch shrinks from 95 to 15 us); V = 50 k, d = 300 (Infinity-Cache resident): no gain, not enabled."""
-        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (256 << 20):
+        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (32 << 20):
             self.enable_twin()
 
     def canonicalize(self):
         """Versions back to 0 (a no-op without a twin; one sweep over V_row bytes plus the rows whose second copy was
         current).  Called by every accessor except the Adagrad step's."""
+        # `_twin_dirty` is sticky: once a step that may flip versions has been issued (possibly inside a captured graph
+        # that is replayed without any further Python call), every reader pays this one small launch
         if self.R_ver is not None and getattr(self, "_twin_dirty", False):
-            self._twin_dirty = False
             _check(load_library().glove_canonicalize_f32(C.byref(self.struct(twin_ok=True)), _stream()),
                    "glove_canonicalize_f32")
 
     def struct(self, twin_ok=False) -> GloveTables:
-        """`twin_ok`: the caller is the Adagrad step, which understands (and from now on may leave) a twinned table."""
-        if twin_ok:
-            self._twin_dirty = self.R_ver is not None
-        else:
+        """`twin_ok`: the caller is the Adagrad step, which understands a twinned table (and says so through
+        `_twin_dirty` when it may leave one behind: GloveHip.step_adagrad)."""
+        if not twin_ok:
             self.canonicalize()
         if self._struct is None:
             s = GloveTables()
@@ -527,12 +527,20 @@ def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, bet
     return h
 
 
-def _step_struct(tables):
-    """The tables as the Adagrad step may see them: a twinned row table stays twinned between steps."""
-    try:
-        return tables.struct(twin_ok=True)
-    except TypeError:                        # a TablesView: plain struct
+def _step_struct(tables, plans, hyper):
+    """The tables as the Adagrad step may see them: a twinned row table stays twinned between steps.  Marks the tables
+    as possibly twinned when one of the plans can take the twin form (the rule of glove_step.hip pick_step_form), so
+    that the next reader of R / br brings them home first."""
+    if getattr(tables, "R_ver", None) is None:
         return tables.struct()
+    form = hyper.step_form
+    for plan in plans:
+        hc = plan.host_counts
+        fused = plan.r_crec is not None and hc[1] >= 0 and (hc[1] + hc[3]) * tables.d * 16 >= FUSED_STEP_BYTES
+        if form == STEP_FUSED_TWIN or (form == STEP_AUTO and fused):
+            tables._twin_dirty = True
+            break
+    return tables.struct(twin_ok=True)
 
 
 class GloveHip:
@@ -680,7 +688,7 @@ class GloveHip:
     # ---- whole steps
     def step_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
-        _check(self.lib.glove_step_adagrad_f32(C.byref(plan.struct()), C.byref(_step_struct(tables)), C.byref(hyper),
+        _check(self.lib.glove_step_adagrad_f32(C.byref(plan.struct()), C.byref(_step_struct(tables, (plan,), hyper)), C.byref(hyper),
                                                _ptr(ws), ws.numel(), _ptr(loss_out), _stream()),
                "glove_step_adagrad_f32")
 
@@ -691,7 +699,7 @@ class GloveHip:
         big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
         ws = self.step_workspace(big, tables.d)
         arr = (C.POINTER(GlovePlan) * len(plans))(*[C.pointer(p.struct()) for p in plans])
-        _check(self.lib.glove_steps_adagrad_f32(arr, len(plans), C.byref(_step_struct(tables)), C.byref(hyper), _ptr(ws),
+        _check(self.lib.glove_steps_adagrad_f32(arr, len(plans), C.byref(_step_struct(tables, plans, hyper)), C.byref(hyper), _ptr(ws),
                                                 ws.numel(), _ptr(loss_out), _stream()), "glove_steps_adagrad_f32")
 
     def step_adam(self, plan, tables, hyper, G_flat, loss_out=None, ws=None):

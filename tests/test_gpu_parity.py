@@ -777,6 +777,41 @@ def test_twinned_row_table_step_equals_the_three_launch_form_bitwise(hip, B, V, 
         hip.step_adagrad(plans[0], a, _hyper(hp, B, step_form=4), la)
 
 
+def test_twin_steps_replayed_from_a_hipgraph_stay_readable(hip):
+    """A captured burst of twin-form steps is replayed without any Python call per step, so the host cannot know which
+    copies are current: once such a step has been issued every reader of R / br canonicalises first — reading the
+    tables between replays, and stepping on from there, gives exactly what eager three-launch steps give."""
+    from trainer.hip_api import DeviceTables
+    B, V, d, cap = 9000, 20000, 64, 8
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    b.enable_twin()
+    hp = ref.Hyper(learning_rate=0.05)
+    plans = [hip.build_plan(*to_dev(*make_batch(40 + k, B, V)), V, chunk_cap=cap).compact(hip.lib) for k in range(3)]
+    assert plans[0].r_crec is not None
+    h3, h4 = _hyper(hp, B, step_form=3), _hyper(hp, B, step_form=4)
+    ws = hip.step_workspace(plans[0], b.d)
+    ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, b.d) for p in plans), dtype=torch.uint8, device="cuda:0")
+    lb = torch.zeros(4, device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip.step_adagrad(plans[0], b, h4, lb, ws)            # warm the launch path outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    hip.step_adagrad(plans[0], a, h3)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for p in plans:
+            hip.step_adagrad(p, b, h4, lb, ws)
+    for rnd in range(3):
+        g.replay()
+        for p in plans:
+            hip.step_adagrad(p, a, h3)
+        _assert_same_bits(a, b, "after replay %d" % rnd)       # reads R, br of the twinned tables: canonicalises
+        assert int(b.R_ver.sum()) == 0
+
+
 @pytest.mark.parametrize("B,V,d,cap", [(1024, 300, 64, 32), (6000, 80, 300, 4), (4096, 64, 128, 2), (3000, 150, 50, 16),
                                        (2000, 5000, 20, 8), (9000, 40000, 64, 16)])
 def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap):
