@@ -535,23 +535,6 @@ struct SideBufs {
     int twin;
 };
 
-// field-wise choice between the two sides (a reference picked by a run-time condition would force both structs into
-// scratch memory)
-__device__ inline SideBufs pick_side(bool row, const SideBufs &r, const SideBufs &c)
-{
-    SideBufs s;
-    s.uniq_rec = row ? r.uniq_rec : c.uniq_rec;
-    s.gp = row ? r.gp : c.gp;
-    s.gb = row ? r.gb : c.gb;
-    s.W = row ? r.W : c.W;
-    s.S1 = row ? r.S1 : c.S1;
-    s.bias = row ? r.bias : c.bias;
-    s.S1b = row ? r.S1b : c.S1b;
-    s.ver = row ? r.ver : c.ver;
-    s.twin = row ? r.twin : c.twin;
-    return s;
-}
-
 // row of W / entry of bias that currently holds id (the slots S1 / S1b are never twinned)
 __device__ inline int32_t cur_row(const SideBufs &sb, int32_t id) { return sb.ver && sb.ver[id] ? id + sb.twin : id; }
 

@@ -51,14 +51,18 @@ def test_struct_layout_matches_the_c_header(tmp_path):
                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(glove_tables), sizeof(glove_hyper), '
                    'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
                    'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, c_crec));\n'
-                   'printf("%zu %zu %zu\\n", offsetof(glove_tables, R), offsetof(glove_hyper, sides), offsetof(glove_tables, d_model));\n'
+                   'printf("%zu %zu %zu ", offsetof(glove_tables, R), offsetof(glove_hyper, sides), offsetof(glove_tables, d_model));\n'
+                   'printf("%zu %zu %zu %zu %zu\\n", offsetof(glove_tables, R_ver), offsetof(glove_hyper, step_form), '
+                   'offsetof(glove_plan, V_row), sizeof(glove_packed_list), offsetof(glove_packed_list, n));\n'
                    'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     T, H, P = hip_api.GloveTables, hip_api.GloveHyper, hip_api.GlovePlan
     assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
-                   P.host_counts.offset, P.r_to_c.offset, P.c_crec.offset, T.R.offset, H.sides.offset, T.d_model.offset]
+                   P.host_counts.offset, P.r_to_c.offset, P.c_crec.offset, T.R.offset, H.sides.offset, T.d_model.offset,
+                   T.R_ver.offset, H.step_form.offset, P.V_row.offset, C.sizeof(hip_api.GlovePackedList),
+                   hip_api.GlovePackedList.n.offset]
 
 
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):
