@@ -486,8 +486,10 @@ def test_randomized_forms_agree_bitwise(hip, seed):
         plan = plan.compact(hip.lib)           # resident form: host counts, per-chunk records when they pay
     h = _hyper(hp, c["B"], step_form=1)
     Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
-    fused = [(tables_from_oracle(t, DeviceTables), _hyper(hp, c["B"], step_form=f)) for f in (2, 3)] \
+    fused = [(tables_from_oracle(t, DeviceTables), _hyper(hp, c["B"], step_form=f)) for f in (2, 3, 4)] \
         if c["optimizer"] == "Adagrad" else []
+    if fused:
+        fused[2][0].enable_twin()              # form 4 steps on a twinned row table
     for _ in range(c["steps"]):
         for ft, fh in fused:                   # the forms whose single-chunk ids are applied by the pass kernel itself
             hip.step_adagrad(plan, ft, fh)
@@ -511,6 +513,7 @@ def test_randomized_forms_agree_bitwise(hip, seed):
     assert float(Ga.abs().max()) == 0.0 and float(Gb.abs().max()) == 0.0, info
     if fused:        # the fused forms sum an id's pairs run by run instead of chunk by chunk: same bits among themselves
         _assert_same_bits(fused[0][0], fused[1][0], "step_form 2 vs 3 " + info)
+        _assert_same_bits(fused[0][0], fused[2][0], "step_form 2 vs 4 " + info)
         _assert_tables_agree(a, fused[0][0], 2e-5 * c["steps"], 2e-6 * c["steps"], "step_form 2 vs 1 " + info)
 
 
