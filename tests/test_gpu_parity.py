@@ -741,6 +741,74 @@ def test_row_sharded_pieces_on_one_gpu(hip, B, V, d, W):
     assert torch.equal(a.scalars, b.scalars)
 
 
+@pytest.mark.parametrize("exchange", ["dense", "rows"])
+def test_full_size_row_sharded_two_virtual_ranks(hip, exchange):
+    """BASELINE config 5 at its workload (V = 2 M, d = 128, 1 M nonzeros per step) as two virtual ranks on one GPU:
+    each holds half of the row table (V_row = 1 M < V, local row ids: the union batch routed by row owner) and a
+    replica of the col table; the col side is exchanged by hand where the collective would run — the summed dense
+    halves, or the two packed lists combined in rank order.  Result == the single-GPU step on the union batch
+    (itself checked against the float64 restatement in test_full_size_spot_check_against_oracle) within the fp32
+    rounding of summing two ranks' col gradients."""
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, make_hyper
+    W, B = 2, 1048576
+    wl = synthetic.make_workload("zipf_v2m_d128", seed=4, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    row, col, w, y = (wl[k][:B].contiguous() for k in ("row", "col", "w", "y"))
+    full = DeviceTables(V, d, "Adagrad", seed=6)
+    kw = dict(learning_rate=0.05, batch_size=B)
+    ranks = []
+    for r in range(W):
+        dt = DeviceTables(V, d, "Adagrad", seed=0, V_row=V // W)
+        dt.R.copy_(full.R[r::W]); dt.br.copy_(full.br[r::W])
+        dt.C.copy_(full.C); dt.bc.copy_(full.bc)
+        mine = row % W == r
+        plan = hip.build_plan((row[mine] // W).contiguous(), col[mine].contiguous(), w[mine].contiguous(), y[mine].contiguous(),
+                              V, chunk_cap=0, compact=True, V_row=V // W)
+        assert int(plan.counts[5]) == 0                                       # no local row id outside the shard
+        ranks.append((dt, plan))
+    loss_out = torch.zeros(4, device="cuda:0")
+    if exchange == "dense":
+        Gs = []
+        for dt, plan in ranks:                   # (the virtual ranks share one step workspace: a rank's passes and their
+            G = hip.dense_grad_buffer(dt)        # consumers run back to back)
+            hip.passes(plan, dt, make_hyper(**kw))
+            hip.dense_grad(plan, dt, make_hyper(sides=2, **kw), G)
+            hip.apply_adagrad(plan, dt, make_hyper(sides=1, **kw))
+            Gs.append(G)
+        off = hip.grad_layout(ranks[0][0])["G_C"]
+        total = Gs[0][off:] + Gs[1][off:]
+        for (dt, _), G in zip(ranks, Gs):
+            G[off:] = total
+            hip.dense_adagrad(dt, make_hyper(sides=2, **kw), G, loss_out)
+    else:
+        cap = 1 + max(p.host_counts[3] for _, p in ranks)
+        lists = torch.zeros(W, cap, d + 4, device="cuda:0")
+        for r, (dt, plan) in enumerate(ranks):
+            hip.passes(plan, dt, make_hyper(**kw))
+            hip.pack_grad(plan, dt, make_hyper(sides=2, **kw), lists[r])
+            hip.apply_adagrad(plan, dt, make_hyper(sides=1, **kw))
+        for dt, _ in ranks:
+            G, mark = hip.dense_grad_buffer(dt), torch.zeros(dt.V_row + V, dtype=torch.int32, device="cuda:0")
+            G.fill_(float("nan"))                                              # never read before it is written
+            pl = [hip.packed_list(lists[r]) for r in range(W)]
+            for r in range(W):
+                hip.combine_packed(pl[r], r, dt, G, mark, cap)
+            hip.apply_packed(pl, dt, make_hyper(sides=2, **kw), G, mark, None, loss_out, cap)
+            assert int(mark.abs().max()) == 0
+            del G, mark
+    plan = hip.build_plan(row, col, w, y, V, chunk_cap=0, compact=True)
+    want_loss = torch.zeros(4, device="cuda:0")
+    hip.step_adagrad(plan, full, make_hyper(step_form=1, **kw), want_loss)
+    np.testing.assert_allclose(loss_out.cpu().numpy()[:3], want_loss.cpu().numpy()[:3], rtol=2e-5)
+    for r, (dt, _) in enumerate(ranks):
+        assert torch.allclose(dt.R, full.R[r::W], rtol=2e-5, atol=2e-6) and torch.allclose(dt.br, full.br[r::W], rtol=2e-5, atol=2e-6)
+        assert torch.equal(dt.R, full.R[r::W])                                # the row side has no cross-rank sum: same bits
+        assert torch.allclose(dt.C, full.C, rtol=2e-5, atol=2e-6) and torch.allclose(dt.bc, full.bc, rtol=2e-5, atol=2e-6)
+        assert abs(dt.global_bias - full.global_bias) <= 2e-5 * abs(full.global_bias) + 1e-7
+    assert torch.equal(ranks[0][0].C, ranks[1][0].C)
+
+
 @pytest.mark.parametrize("B,V,d,cap", STEP_CASES[:14:2] + [(9000, 20000, 300, 16), (30000, 300000, 128, 16), (50000, 3000, 64, 8),
                                                           (20000, 5, 32, 8), (700, 60, 301, 32)])
 def test_twinned_row_table_step_equals_the_three_launch_form_bitwise(hip, B, V, d, cap):
