@@ -788,6 +788,21 @@ __global__ __launch_bounds__(kBlock) void triage_kernel(IdWork wk, SideBufs rs, 
     work[4 + atomicAdd(work, 1)] = q;
 }
 
+// The loss partials of a row pass with `nblocks` workgroups, folded into entry 0 (the rest zeroed): any later reader that
+// sums entries 0 .. n-1 for its own idea of n >= 1 (the classic row pass's grid) finds the same totals.
+__global__ __launch_bounds__(kBlock) void fold_blockpart_kernel(float *__restrict__ blockpart, int nblocks)
+{
+    float tot[kPartials];
+    sum_blockpart(blockpart, nblocks, tot);
+    __shared__ float keep[kPartials];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kPartials; ++i) keep[i] = tot[i];
+    }
+    __syncthreads();                        // everybody has read its share before anything is overwritten
+    for (int i = threadIdx.x; i < kMaxBlocks * kPartials; i += kBlock) blockpart[i] = i < kPartials ? keep[i] : 0.f;
+}
+
 template <int LPR, int NV>
 struct AdagradApply {
     SideBufs rs, cs;
@@ -1808,6 +1823,25 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
     // (a twinned table must be canonical here: glove_canonicalize_f32)
     if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
     return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
+}
+
+int glove_rowside_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                                   void *stream)
+{
+    if (!p || !t || !h || sides_of(h) != 1) return GLOVE_E_BADARG;          // hyper.sides = 1: this is the row side's step
+    if (t->R_ver) return GLOVE_E_BADARG;                                  // plain tables only
+    if (!p->r_crec || !p->c_crec) {
+        // no chunk records: the row pass stores its partial rows, the apply launch does every row id
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1)) return rc;
+        return launch_apply_adagrad(p, t, h, ws, ws_bytes, nullptr, stream, kFuseNone, kFuseNone);
+    }
+    if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, false, kFuseInPlace, kFuseNone)) return rc;
+    if (int rc = launch_apply_adagrad(p, t, h, ws, ws_bytes, nullptr, stream, kFuseInPlace, kFuseNone)) return rc;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    const int lpr = pass_shape(t->d / 4).lpr;
+    const int nb_fused = fusepass_blocks(p, lpr, fuse_per(p, lpr), true);
+    hipLaunchKernelGGL(fold_blockpart_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, w.blockpart, nb_fused);
+    return (int)hipGetLastError();
 }
 
 int glove_canonicalize_f32(const glove_tables *t, void *stream)

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
-    "glove_gather_rows_f32", "glove_canonicalize_f32",
+    "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -129,6 +129,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
         "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
         "glove_canonicalize_f32": (C.c_int, [P(GloveTables), vp]),
+        "glove_rowside_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
@@ -605,6 +606,13 @@ class GloveHip:
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
         _check(self.lib.glove_colpass_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
                                           _ptr(ws), ws.numel(), _stream()), "glove_colpass_f32")
+
+    def rowside_step(self, plan, tables, hyper, ws=None):
+        """The row side of a step, applied in place where a lane group holds an id completely (hyper.sides = 1); the
+        col pass of the step must have run already: it gathers the old rows."""
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_rowside_step_adagrad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+                                                       _ptr(ws), ws.numel(), _stream()), "glove_rowside_step_adagrad_f32")
 
     def apply_adagrad(self, plan, tables, hyper, loss_out=None, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws

@@ -70,6 +70,12 @@ class HipBackend:
     def apply_sparse(self, plan, tables, hyper):
         self.hip.apply_adagrad(plan, tables, hyper)
 
+    def colpass(self, plan, tables, hyper):
+        self.hip.colpass(plan, tables, hyper)
+
+    def rowside_step(self, plan, tables, hyper):
+        self.hip.rowside_step(plan, tables, hyper)
+
     def dense_grad(self, plan, tables, hyper, G):
         self.hip.dense_grad(plan, tables, hyper, G)
 
@@ -360,7 +366,8 @@ class ShardedStepper:
     (route_by_row_owner), so the row side of a step is local.  For the col side a rank
 
       1. receives the col rows its batch touches from their owners (all-to-all; the owners gather them),
-      2. runs the passes against that fetched block — the batch's col ids are renumbered 0 .. n-1 in fetch order,
+      2. runs the col pass against that fetched block — the batch's col ids are renumbered 0 .. n-1 in fetch order —
+         and then the whole row side (pass + Adagrad, in place where a lane group holds an id completely),
       3. returns the summed gradient of every fetched row to its owner (all-to-all of the packed list),
       4. and, as an owner, adds what the ranks returned for its rows in rank order and applies Adagrad to them.
 
@@ -441,9 +448,10 @@ class ShardedStepper:
 
         return [("serve_rows", lambda i: b.gather_rows(t, bt[i]["serve_idx"], f["send_rows"], f["send_bias"])),
                 ("fetch_all_to_all", fetch),
-                ("passes", lambda i: b.passes(bt[i]["plan"], self.view, self.hyper_cols)),
+                # the col pass first: it gathers the OLD rows of R, which the row side then updates in place
+                ("colpass", lambda i: b.colpass(bt[i]["plan"], self.view, self.hyper_cols)),
+                ("rowside_step", lambda i: b.rowside_step(bt[i]["plan"], self.view, self.hyper_rows)),
                 ("pack_grad_cols", lambda i: b.pack_grad(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
-                ("apply_adagrad_rows", lambda i: b.apply_sparse(bt[i]["plan"], self.view, self.hyper_rows)),
                 ("push_all_to_all", push),
                 ("owner_apply_cols", lambda i: b.owner_apply(t, self.owner_state, f["recv"], bt[i]["serve_idx"], bt[i]["serve"],
                                                              self.hyper, self.tail, self.loss_out))]

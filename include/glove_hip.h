@@ -265,6 +265,14 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
 /* ---- whole step = session.run(train_op) (estimator.py:49-56) ------------------------------ */
 int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                            void *ws, size_t ws_bytes, float *loss_out, void *stream);
+/* The ROW side of a step done completely, for callers that exchange the col side themselves (both tables sharded,
+ * trainer/stepper.py ShardedStepper): a pass over the row side in which every id one lane group holds completely is
+ * applied in place (R, br, their accumulators), then the apply of the remaining row ids; the row pass's loss partials
+ * are left where glove_pack_grad_f32 / glove_dense_grad_f32 look for them.  hyper.sides must be 1.
+ * PRECONDITION: nothing else reads R / br later in this step — run glove_colpass_f32 (which gathers the old rows)
+ * BEFORE this call.  Without chunk records it falls back to glove_rowpass_f32 + glove_apply_adagrad_f32. */
+int glove_rowside_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                                   void *ws, size_t ws_bytes, void *stream);
 /* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
  * cleared.  A no-op without a twin.  Call before anything but glove_step(s)_adagrad_f32 reads or writes R / br. */
 int glove_canonicalize_f32(const glove_tables *t, void *stream);

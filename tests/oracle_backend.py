@@ -49,6 +49,12 @@ class OracleBackend:
             tables.t.g = tables._base.t.g
         self._gr = ref.gradients(tables.t, row, col, w, y, hyper["hp"], inv_batch=hyper["inv_batch"])
 
+    def colpass(self, plan, tables, hyper):
+        self.passes(plan, tables, hyper)             # the oracle forms every gradient at once, from the pre-step tables
+
+    def rowside_step(self, plan, tables, hyper):
+        self.apply_sparse(plan, tables, hyper)
+
     def dense_grad(self, plan, tables, hyper, G):
         gr = self._gr
         G_R, G_br, G_C, G_bc, tail = self._views(tables, G)

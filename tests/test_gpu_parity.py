@@ -959,8 +959,10 @@ def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
 @pytest.mark.parametrize("B,V,d", [(3000, 101, 64), (2000, 5000, 52), (20000, 40000, 300)])
 def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
     """trainer.stepper.ShardedStepper with world = 1 (every all-to-all is a copy): fetching the batch's col rows,
-    stepping on renumbered col ids, returning the packed col gradients and the owner-side apply give the bits of the
-    plain sparse step."""
+    stepping on renumbered col ids (col pass, then the row side applied in place), returning the packed col gradients
+    and the owner-side apply give the plain sparse step — bit for bit where the batches have no chunk records (the
+    row side then runs pass + apply as the plain step does), within the fp32 rounding of the fused row side's
+    pair-by-pair sums where they have."""
     from trainer.hip_api import DeviceTables, make_hyper
     from trainer.stepper import HipBackend, ShardedStepper
     t = oracle_tables(V, d, "Adagrad")
@@ -975,8 +977,11 @@ def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
     for k in (0, 1, 2, 0, 1):
         st.step(handles[k])
         hip.step_adagrad(plans[k], b, h, lb)
-    _assert_same_bits(a, b)
-    np.testing.assert_allclose(st.loss_out.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-6)
+    if all(st.batches[h_]["plan"].r_crec is None for h_ in handles):
+        _assert_same_bits(a, b)
+    else:
+        _assert_tables_agree(a, b, 5e-5, 5e-6)
+    np.testing.assert_allclose(st.loss_out.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-5)
 
 
 EDGE_CASES = [
