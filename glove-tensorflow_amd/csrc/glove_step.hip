@@ -1381,14 +1381,13 @@ static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_f
 // d = 300, B = 1 M, 16 and 32 slower: fewer, longer-running groups), fewer when the side has too few chunks to fill the
 // chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 / 103 / 106), more
 // when the plan has more chunks than kMaxBlocks workgroups of such groups cover (the loss partials are kept per
-// workgroup).  GLOVE_FUSE_PER overrides the choice below the last rule (experiments).
+// workgroup).  (Measured with a build that read the number from the environment; the library itself reads no environment.)
 static int fuse_per(const glove_plan *p, int lpr)
 {
-    static const int forced = [] { const char *e = getenv("GLOVE_FUSE_PER"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
     const int64_t side = p->host_counts[0] >= 0 && p->host_counts[2] >= 0
                              ? (p->host_counts[0] > p->host_counts[2] ? p->host_counts[0] : p->host_counts[2]) : p->cap_chunks;
-    int per = forced ? forced : (int)(side / 16384);
-    if (!forced) per = per < 1 ? 1 : per > 4 ? 4 : per;
+    int per = (int)(side / 16384);
+    per = per < 1 ? 1 : per > 4 ? 4 : per;
     const int64_t groups = (int64_t)kMaxBlocks * (kBlock / lpr);
     const int need = (int)((p->cap_chunks + groups - 1) / groups);
     return need > per ? need : per;
@@ -1561,8 +1560,7 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
         rs.twin = v_row(t);
     }
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_triage = getenv("GLOVE_NO_TRIAGE") != nullptr;        // experiments
-    if (pre_r == kFuseTwin && pre_c == kFuseInPlace && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0 && wk.sides == 3 && !no_triage) {
+    if (pre_r == kFuseTwin && pre_c == kFuseInPlace && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0 && wk.sides == 3) {
         // sort the ids out first (triage_kernel, a thread per id): the launch below then walks the list of those that
         // still need it.  Only where that list is short — the twin form, whose finished ids need a version flip at most
         // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage).  Behind the slot form every row id still needs its

@@ -26,12 +26,18 @@ pd.DataFrame({"row_token": tok[row.numpy()], "col_token": tok[col.numpy()], "glo
 runs = (("Adagrad", "0.05", "1024", estimator.main, steps), ("Adam", "0.001", "1024", estimator.main, steps),
         ("Adagrad", "0.05", "131072", estimator.main, steps // 20),
         ("Adagrad", "0.05", "1024", logistic_matrix_factorisation.main, steps // 4),
-        ("Adagrad", "0.05", "1024", "full", steps), ("Adam", "0.001", "4096", "full", steps // 4))
+        ("Adagrad", "0.05", "1024", "full", steps), ("Adam", "0.001", "4096", "full", steps // 4),
+        # the fused step forms forced on (the library would take two launches at this scale): slots and twinned row table,
+        # with the checkpoints and eval passes of the loop reading the tables in between
+        ("Adagrad", "0.05", "131072", "form3", steps // 20), ("Adagrad", "0.05", "131072", "form4", steps // 20),
+        ("Adagrad", "0.05", "4096", "form4", steps // 4))
 for opt, lr, bs, entry, n in runs:
     extra = []
+    if isinstance(entry, str) and entry.startswith("form"):
+        entry, extra = estimator.main, ["--step-form", entry[4:]]
     if entry == "full":                   # a new permutation every epoch, indexes prefetched, bursts from cached graphs
         entry, extra = estimator.main, ["--epoch-shuffle", "full"]
-    job = tmp / ("job_%s_%s_%s%s" % (opt, bs, entry.__module__.split(".")[-1], "_full" if extra else ""))
+    job = tmp / ("job_%s_%s_%s%s" % (opt, bs, entry.__module__.split(".")[-1], "_".join([""] + extra).replace("-", "")))
     torch.cuda.reset_peak_memory_stats()
     entry(["--train-csv", str(tmp / "interaction.csv"), "--vocab-txt", str(tmp / "vocab.txt"), "--job-dir", str(job),
            "--disable-datetime-path", "--optimizer", opt, "--learning-rate", lr, "--batch-size", bs, "--train-steps", str(n),
@@ -40,5 +46,5 @@ for opt, lr, bs, entry, n in runs:
     losses = [r["loss"] for r in log]
     assert all(np.isfinite(losses)), losses
     print("%s%s %s bs=%s: %d steps, loss %.5f -> %.5f (min %.5f), %d checkpoints, %d evals, peak device memory %.0f MB" % (
-        entry.__module__, " --epoch-shuffle full" if extra else "", opt, bs, n, losses[0], losses[-1], min(losses), len(list(job.glob("model.ckpt-*.pt"))),
+        entry.__module__, " " + " ".join(extra) if extra else "", opt, bs, n, losses[0], losses[-1], min(losses), len(list(job.glob("model.ckpt-*.pt"))),
         len((job / "eval" / "eval_log.jsonl").read_text().splitlines()), torch.cuda.max_memory_allocated() / 1e6), flush=True)
