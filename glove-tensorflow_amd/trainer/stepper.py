@@ -330,16 +330,17 @@ class RowShardedStepper:
         b, t = self.backend, self.tables
         if self.world == 1:
             return [("step", lambda p: b.step_sparse_adagrad(p, t, self.hyper, self.loss_out))]
-        ph = [("passes", lambda p: b.passes(p, t, self.hyper_cols))]
+        # the col pass first (it gathers the old rows of R), then the whole row side, applied in place by its pass where a
+        # lane group holds an id completely: R, br are local, nothing else reads them in this step
+        ph = [("colpass", lambda p: b.colpass(p, t, self.hyper_cols)),
+              ("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows))]
         if self.rows:
-            ph += [("pack_grad_cols", lambda p: b.pack_grad(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before any update
-                   ("apply_adagrad_rows", lambda p: b.apply_sparse(p, t, self.hyper_rows)),                   # R, br: local
+            ph += [("pack_grad_cols", lambda p: b.pack_grad(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before its update
                    ("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])),
                    ("combine_apply_cols", lambda p: b.apply_gathered(self.bufs, self.world, t, self.hyper_cols, self.G,
                                                                        self.loss_out))]
         else:
-            ph += [("dense_grad_cols", lambda p: b.dense_grad(p, t, self.hyper_cols, self.G)),   # reads C (activity-L2 term): before any update
-                   ("apply_adagrad_rows", lambda p: b.apply_sparse(p, t, self.hyper_rows)),      # R, br: local, no communication
+            ph += [("dense_grad_cols", lambda p: b.dense_grad(p, t, self.hyper_cols, self.G)),   # reads C (activity-L2 term): before its update
                    ("all_reduce", lambda p: self.dist.all_reduce(b.col_half(t, self.G))),
                    ("dense_adagrad_cols", lambda p: b.apply_dense(t, self.hyper_cols, self.G, self.loss_out))]
         return ph
