@@ -141,13 +141,15 @@ class HipBackend:
                          mark=torch.zeros(view.V_row + view.V, dtype=torch.int32, device=tables.device))
         view, G, mark = state["view"], state["G"], state["mark"]
         lists, off = [], 0
-        for n in counts:
-            lists.append(self.hip.packed_list(recv[off:off + max(n, 1)], with_header=False, ids=ids[off:off + max(n, 1)],
-                                              n=n, side=0))
+        for n in counts:                      # a rank whose batch touches none of this owner's rows sends nothing
+            if n:
+                lists.append(self.hip.packed_list(recv[off:off + n], with_header=False, ids=ids[off:off + n], n=n, side=0))
             off += n
-        for r, lst in enumerate(lists):
-            if counts[r]:
-                self.hip.combine_packed(lst, r, view, G, mark, 0)
+        if not lists:                         # nothing to apply: the scalar work (global bias, loss) still has to happen
+            lists = [self.hip.packed_list(recv[0:1], with_header=False, ids=None, n=0, side=0)]
+        for k, lst in enumerate(lists):       # tag = position among the non-empty lists, in rank order
+            if lst.n:
+                self.hip.combine_packed(lst, k, view, G, mark, 0)
         self.hip.apply_packed(lists, view, hyper, G, mark, tail, loss_out, 0)
 
     def eval_sums(self, row, col, w, y, tables, sums):

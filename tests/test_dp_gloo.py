@@ -124,6 +124,22 @@ def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path, exchan
 
 
 # ---- BASELINE config 5, both tables sharded: col rows fetched from / returned to their owners by all-to-all
+def _fully_sharded_batches():
+    """The common batches, plus two steps whose col ids all belong to ONE owner (even ids: rank 0; then odd ids):
+    the other rank serves nothing and receives no gradients in that step, and still takes part in every collective."""
+    out = _batches()
+    for parity in (0, 1):
+        step = []
+        for r in range(WORLD):
+            row, col, w, y = _batches()[parity][r]
+            col = (col // 2 * 2 + parity) % V
+            clash = col == row
+            col[clash] = (col[clash] + 2) % V
+            step.append((row, col.astype(np.int32), w, y))
+        out.append(step)
+    return out
+
+
 def _fully_sharded_worker(rank, port, out_dir):
     for p in (HERE.parent, HERE.parent / "oracle", HERE):
         sys.path.insert(0, str(p))
@@ -140,7 +156,7 @@ def _fully_sharded_worker(rank, port, out_dir):
     backend = OracleBackend()
     stepper = ShardedStepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, rank, dist)
     handles = []
-    for step_batches in _batches():
+    for step_batches in _fully_sharded_batches():
         mine = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in zip(("row", "col", "w", "y"), step_batches[rank])}
         routed = route_by_row_owner(mine, WORLD, rank, dist)
         handles.append(stepper.add_batch(routed["row"], routed["col"], routed["w"], routed["y"], 32))
@@ -158,14 +174,14 @@ def test_fully_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
     mp.spawn(_fully_sharded_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
-    for step_batches in _batches():
+    for step_batches in _fully_sharded_batches():
         ref.train_step(t, *[np.concatenate([b[i] for b in step_batches]) for i in range(4)], hp)
     shards = [np.load(tmp_path / ("full%d.npz" % r)) for r in range(WORLD)]
     for r, s in enumerate(shards):
         for n in ("R", "br", "C", "bc", "A_C"):
             np.testing.assert_allclose(s[n], getattr(t, n)[r::WORLD], rtol=1e-10, atol=1e-13, err_msg=n)
         np.testing.assert_allclose(s["g"], t.g, rtol=1e-10)
-        assert int(s["step"]) == STEPS
+        assert int(s["step"]) == STEPS + 2
 
 
 # ---- the input side on several ranks: every nonzero of the file belongs to exactly one rank

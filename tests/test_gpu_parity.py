@@ -919,7 +919,8 @@ def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap
     np.testing.assert_array_equal(ids, np.r_[np.unique(row), np.unique(col)])
 
 
-@pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 5000, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8)])
+@pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 5000, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8),
+                                     (700, 300, 64, 11)])
 def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
     """W virtual ranks on one GPU, each with its own batch: their packed lists combined in rank order == the dense
     buffer they would have all-reduced (dense_grad of every plan into one G, in rank order), bit for bit, and both
@@ -942,7 +943,12 @@ def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
         lists = [hip.packed_list(recv[r]) for r in range(W)]
         for r, lst in enumerate(lists):
             hip.combine_packed(lst, r, a, Ga, mark, cap)
-        hip.apply_packed(lists, a, h, Ga, mark, None, la, cap)
+        tail = None
+        if W > 8:           # more lists than one apply launch takes: the loss partials are handed over summed (rank order)
+            tail = torch.zeros(4, device="cuda:0")
+            for r in range(W):
+                tail += recv[r, 0, 2:6]
+        hip.apply_packed(lists, a, h, Ga, mark, tail, la, cap)
         for p in plans:
             hip.passes(p, b, h)
             hip.dense_grad(p, b, h, Gb)

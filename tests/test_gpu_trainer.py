@@ -269,6 +269,7 @@ def _two_rank_sharded(rank, port, out_dir, V, d, B, steps):
     for p in (here.parent, here.parent / "oracle", here):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+    import numpy as np
     from helpers import make_batch, to_dev
     from trainer.hip_api import DeviceTables
     from trainer.stepper import HipBackend, ShardedStepper, owned_rows, route_by_row_owner
@@ -281,7 +282,11 @@ def _two_rank_sharded(rank, port, out_dir, V, d, B, steps):
     st = ShardedStepper(HipBackend("cuda:0"), shard, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, 2, rank, dist)
     handles = []
     for k in range(steps):
-        row, col, w, y = to_dev(*make_batch(4000 + 10 * k + rank, B, V))
+        row, col, w, y = make_batch(4000 + 10 * k + rank, B, V)
+        if k == steps - 1:                # a step whose col ids all belong to rank 0 (even ids): rank 1 serves nothing
+            col = (col // 2 * 2) % V
+            col[col == row] = (col[col == row] + 2) % V
+        row, col, w, y = to_dev(row, col.astype(np.int32), w, y)
         got = route_by_row_owner(dict(row=row, col=col, w=w, y=y), 2, rank, dist)
         handles.append(st.add_batch(got["row"], got["col"], got["w"], got["y"], 16))
     for h in handles:
@@ -303,7 +308,12 @@ def test_two_rank_fully_sharded_step_on_one_gpu(hip, tmp_path):
     h = make_hyper(learning_rate=0.05, batch_size=2 * B, step_form=1)
     loss_out = torch.zeros(4, device="cuda:0")
     for k in range(steps):
-        joint = [np.concatenate(x) for x in zip(*[make_batch(4000 + 10 * k + r, B, V) for r in range(2)])]
+        parts = [list(make_batch(4000 + 10 * k + r, B, V)) for r in range(2)]
+        if k == steps - 1:
+            for p_ in parts:
+                p_[1] = ((p_[1] // 2 * 2) % V).astype(np.int32)
+                p_[1][p_[1] == p_[0]] = (p_[1][p_[1] == p_[0]] + 2) % V
+        joint = [np.concatenate(x) for x in zip(*parts)]
         hip.step_adagrad(hip.build_plan(*to_dev(*joint), V, chunk_cap=16), ref_t, h, loss_out)
     shards = [torch.load(tmp_path / ("shard%d.pt" % r)) for r in range(2)]
     for r, s_ in enumerate(shards):
