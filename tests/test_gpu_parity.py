@@ -288,6 +288,31 @@ def test_trajectory(hip, optimizer, B, V, d):
         assert float(G.abs().max()) == 0.0     # the dense apply leaves the gradient buffer zeroed
 
 
+@pytest.mark.parametrize("form", [2, 3, 4])
+@pytest.mark.parametrize("B,V,d,cap", [(8192, 3000, 64, 16), (6000, 500, 300, 8), (4000, 20000, 128, 4)])
+def test_trajectory_in_the_fused_step_forms(hip, form, B, V, d, cap):
+    """30 consecutive steps on fresh batches through a fused step form (pass kernel applies the ids it holds; slots,
+    in place, or twinned row table with version flips carried from step to step): loss of every step and the final
+    state within tolerance of the float64 oracle."""
+    from trainer.hip_api import DeviceTables
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    dt = tables_from_oracle(t, DeviceTables)
+    if form == 4:
+        dt.enable_twin()
+    loss_out = torch.zeros(4, device="cuda:0")
+    for s in range(30):
+        row, col, w, y = make_batch(3000 + s, B, V)
+        plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap).compact(hip.lib, d=1 << 20)   # d: records whatever the fill
+        assert plan.r_crec is not None
+        hip.step_adagrad(plan, dt, _hyper(hp, B, step_form=form), loss_out)
+        loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss_out[0].item(), loss, rtol=5e-5, err_msg="step %d" % s)
+    if form == 4:
+        assert int(dt.R_ver.sum()) > 0          # rows live in both copies by now
+    assert_tables_close(dt, t, rtol=2e-4, atol=1e-5)   # 30 steps of fp32 rounding
+
+
 @pytest.mark.parametrize("B,V,d,cap", [(7, 50, 8, 32), (1024, 300, 64, 32), (1024, 120, 300, 32), (5000, 60, 64, 4),
                                        (1024, 200, 50, 32), (300, 31, 3, 8)])
 def test_adam_single_step_dense_decay(hip, B, V, d, cap):
