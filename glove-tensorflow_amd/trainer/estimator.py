@@ -81,6 +81,8 @@ class Estimator:
                                  V_row=owned_rows(whole.V, self.world, self.rank))
             shard.load_whole_state_dict(whole.state_dict(), self.world, self.rank)
             self.model.tables = shard
+            if hasattr(self.backend, "shard_rows"):
+                self.backend.shard_rows = shard.V_row        # the routed stream carries shard-local row ids
         self.ckpt = CheckpointManager(params["job_dir"], params.get("save_checkpoints_secs", 300.0),
                                       params.get("keep_checkpoint_max", 5))
         self.ckpt.restore(self.model.tables, shard=(self.world, self.rank) if self.row_sharded else None)

@@ -32,10 +32,11 @@ class HipBackend:
         self.hip = GloveHip(device)
         self.device = torch.device(device)
         self.row_floats = None      # floats per table row, once the tables exist: lets resident plans carry what the fused step needs
+        self.shard_rows = 0         # rows of this rank's row-table shard when the row ids handed in are shard-local (else 0)
 
     def build_plan(self, row, col, w, y, V, chunk_cap):
         return self.hip.build_plan(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), V,
-                                   chunk_cap=chunk_cap, compact=True, d=self.row_floats)
+                                   chunk_cap=chunk_cap, compact=True, d=self.row_floats, V_row=self.shard_rows)
 
     def make_hyper(self, **kw):
         from trainer.hip_api import make_hyper
@@ -389,6 +390,8 @@ class ShardedStepper:
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.batches, self.bufs, self.view, self.owner_state = [], None, None, {}
+        if hasattr(backend, "shard_rows"):
+            backend.shard_rows = tables.V_row       # local row ids: anything outside the shard counts as id 0, like a bad col id
 
     def add_batch(self, row, col, w, y, chunk_cap=0) -> int:
         """row: this rank's LOCAL row indices; col: global col ids.  Collective; returns the batch's handle."""
