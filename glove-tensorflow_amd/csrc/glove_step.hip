@@ -238,10 +238,13 @@ struct StepConsts {
     float l2, m, inv_batch, inv_d;
 };
 
+#ifndef GLOVE_FUSE_WAVES
+#define GLOVE_FUSE_WAVES 3       // experiment switch; 4 (128 VGPRs) spills 140-188 B per lane and runs twice as long
+#endif
 // FUSE kernels keep the accumulator row of a run in registers as well: held to 3 waves per SIMD (168 VGPRs), which the
 // d = 300 shape misses by one register otherwise
 template <int LPR, int NV, bool FULL, bool REC, bool FUSE>
-__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value) void sidepass_kernel(
+__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_WAVES : PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
