@@ -218,3 +218,17 @@ def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
         bench.main(["--gpus", "2"])
     # under a launcher (WORLD_SIZE set) the process is a rank: no second launch
     assert bench.steps_per_graph(20) == 20 and bench.steps_per_graph(200) == 50 and bench.steps_per_graph(97) == 1
+
+
+def test_reference_module_names_are_aliases():
+    """The reference's own command lines (Makefile:16-36,84,95,140: `python -m src.config NAME`, `python -m
+    src.models.estimator`, `python -m src.data.text8`, `python -m src.models.export_embeddings`) reach this build."""
+    import subprocess
+    import sys
+    root = str(Path(__file__).resolve().parent.parent)
+    run = lambda *a: subprocess.run([sys.executable, "-m", *a], cwd=root, capture_output=True, text=True, timeout=120)
+    assert run("src.config", "BATCH_SIZE").stdout.strip() == "1024" and run("src.config", "OPTIMIZER").stdout.strip() == "Adam"
+    for mod, flag in (("src.models.estimator", "--embedding-size"), ("src.models.logistic_matrix_factorisation", "--neg-factor"),
+                      ("src.data.text8", "--context-size"), ("src.models.export_embeddings", "--job-dir")):
+        out = run(mod, "--help")
+        assert out.returncode == 0 and flag in out.stdout, (mod, out.stderr[-300:])
