@@ -1778,6 +1778,8 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
     return (int)hipGetLastError();
 }
 
+size_t glove_fused_step_bytes(void) { return (size_t)256 << 20; }
+
 // Which form a sparse Adagrad step takes (glove_hyper.step_form; see include/glove_hip.h).
 static int pick_step_form(const glove_plan *p, const glove_tables *t, const glove_hyper *h)
 {
@@ -1790,7 +1792,7 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
     // (V = 50 k, d = 300, B = 131,072: 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches
     // 106 us, fused 103 - 111; V = 400 k at B = 131,072, 336 MB: 172 against 156; V = 50 k at B = 1 M, 432 MB: 378 against 314)
-    if (ids * t->d * 16 < ((int64_t)256 << 20)) return GLOVE_STEP_TWO_LAUNCH;
+    if (ids * t->d * 16 < (int64_t)glove_fused_step_bytes()) return GLOVE_STEP_TWO_LAUNCH;
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 

@@ -26,7 +26,7 @@ RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk record
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
-FUSED_STEP_BYTES = 256 << 20    # glove_step.hip pick_step_form: touched ids x row bytes x 4 beyond which the fused step pays
+FUSED_STEP_BYTES = 256 << 20    # glove_fused_step_bytes(): touched ids x row bytes x 4 beyond which the fused step pays (re-read from the library at load)
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
-    "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32",
+    "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -128,6 +128,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
         "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
+        "glove_fused_step_bytes": (sz, []),
         "glove_canonicalize_f32": (C.c_int, [P(GloveTables), vp]),
         "glove_rowside_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
@@ -142,6 +143,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
             continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    global FUSED_STEP_BYTES
+    if hasattr(lib, "glove_fused_step_bytes"):
+        FUSED_STEP_BYTES = int(lib.glove_fused_step_bytes())       # one number, owned by the library
     if lib.glove_abi_version() != GLOVE_ABI_VERSION and not (path and os.environ.get("GLOVE_AB_ANY_ABI")):   # A/B tools load old builds
         raise GloveHipError("ABI mismatch: library %d, binding %d" % (lib.glove_abi_version(), GLOVE_ABI_VERSION))
     if path is None:

@@ -273,6 +273,10 @@ int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const 
  * BEFORE this call.  Without chunk records it falls back to glove_rowpass_f32 + glove_apply_adagrad_f32. */
 int glove_rowside_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                                    void *ws, size_t ws_bytes, void *stream);
+/* GLOVE_STEP_AUTO takes a fused form when (distinct row ids + distinct col ids of the plan) x d x 16 B — the rows a
+ * step reads and writes — reaches this many bytes (and the plan carries chunk records); callers that keep a twinned
+ * table use the same number to know whether a step may have left versions flipped. */
+size_t glove_fused_step_bytes(void);
 /* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
  * cleared.  A no-op without a twin.  Call before anything but glove_step(s)_adagrad_f32 reads or writes R / br. */
 int glove_canonicalize_f32(const glove_tables *t, void *stream);
