@@ -976,6 +976,13 @@ __device__ inline int packed_count(const PackedList &pl)
     return __float_as_int(pl.header[0]) + __float_as_int(pl.header[1]);
 }
 
+// mark[id]: bits 0..7 = how many lists touch the id (count_packed_kernel; 0 = not counted), bits 8.. = 1 + tag of the
+// first list that stored the id's row in the dense buffer (0 = none yet)
+constexpr int kMarkCountBits = 8, kMarkCountMask = (1 << kMarkCountBits) - 1;
+
+// (count_packed_kernel below is the optional first pass over ALL lists: afterwards an id only one list touches needs no
+// trip through the dense buffer — the apply kernel takes its gradient straight from that list's entry, combine skips it.)
+
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void combine_packed_kernel(PackedList pl, int tag, DenseViews dv, int d4)
 {
@@ -989,7 +996,9 @@ __global__ __launch_bounds__(kBlock) void combine_packed_kernel(PackedList pl, i
         const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x.y);
         const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
         int32_t *mk = dv.mark + (is_row ? 0 : dv.V_row) + id;
-        const int32_t seen = *mk;           // every lane of the group reads it before lane 0 rewrites it below
+        const int32_t m = *mk;              // every lane of the group reads it before lane 0 rewrites it below
+        if ((m & kMarkCountMask) == 1) continue;        // counted, and this list alone touches the id: applied from the entry
+        const int32_t seen = m >> kMarkCountBits;
         f4 g[NV];
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) {
@@ -1007,12 +1016,25 @@ __global__ __launch_bounds__(kBlock) void combine_packed_kernel(PackedList pl, i
         store_row<LPR, NV>(Gt, (size_t)id, d4, lg, g);
         if (lg == 0) {
             Gb[id] = seen != 0 ? Gb[id] + x.x : x.x;
-            if (seen == 0) *mk = tag + 1;
+            if (seen == 0) *mk = m | ((tag + 1) << kMarkCountBits);
         }
     }
 }
 
 struct PackedLists { PackedList l[8]; int n; };
+
+__global__ __launch_bounds__(kBlock) void count_packed_kernel(PackedLists pls, DenseViews dv, int d4)
+{
+    const PackedList &pl = pls.l[blockIdx.y];
+    const int n = packed_count(pl);
+    const size_t stride = ((size_t)d4 + 1) * 4;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float *x = pl.entries + (size_t)i * stride + (size_t)d4 * 4;
+        const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x[1]);
+        const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x[2])) == 0;
+        atomicAdd(dv.mark + (is_row ? 0 : dv.V_row) + id, 1);
+    }
+}
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
@@ -1030,13 +1052,25 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
         const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x.y);
         const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
         int32_t *mk = dv.mark + (is_row ? 0 : dv.V_row) + id;
-        if (*mk != tag + 1) continue;       // another list touched the id first: that list's entry applies it
+        const int32_t m = *mk;
+        const bool direct = (m & kMarkCountMask) == 1;          // this entry is the id's only one: its row IS the sum
+        if (!direct && (m >> kMarkCountBits) != tag + 1) continue;   // another list stored the id first: its entry applies it
         const SideBufs &sb = is_row ? rs : cs;
         f4 G[NV], Wv[NV], A[NV];
-        load_row<LPR, NV>(G, is_row ? dv.G_R : dv.G_C, id, d4, lg);
+        if (direct) {
+            const f4 *e = reinterpret_cast<const f4 *>(pl.entries) + (size_t)i * stride4;
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) {
+                const int i4 = lg + kk * LPR;
+                const f4 v = e[i4 < d4 ? i4 : d4 - 1];
+                G[kk] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            load_row<LPR, NV>(G, is_row ? dv.G_R : dv.G_C, id, d4, lg);
+        }
         load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
         load_row<LPR, NV>(A, sb.S1, id, d4, lg);
-        float Gb = (is_row ? dv.G_br : dv.G_bc)[id], bval = sb.bias[id], Ab = sb.S1b[id];
+        float Gb = direct ? x.x : (is_row ? dv.G_br : dv.G_bc)[id], bval = sb.bias[id], Ab = sb.S1b[id];
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[kk], A[kk], G[kk], k.lr, k.eps);
         store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
@@ -1720,6 +1754,29 @@ int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const g
 #define CALL(LPR, NV) hipLaunchKernelGGL((combine_packed_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, pl, (int)tag, dv, d4)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_count_packed_f32(const glove_packed_list *lists, int32_t n_lists, const glove_tables *t, float *G_flat,
+                           int32_t *mark, int64_t capacity_entries, void *stream)
+{
+    DenseViews dv;
+    if (int rc = packed_common(t, G_flat, mark, dv)) return rc;
+    if (!lists || n_lists < 1 || n_lists > kMarkCountMask || capacity_entries < 0) return GLOVE_E_BADARG;
+    const int d4 = t->d / 4;
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t first = 0; first < n_lists; first += 8) {
+        PackedLists pls;
+        pls.n = n_lists - first < 8 ? n_lists - first : 8;
+        int64_t n_max = 0;
+        for (int i = 0; i < pls.n; ++i) {
+            if (!to_list(lists + first + i, pls.l[i])) return GLOVE_E_BADARG;
+            const int64_t n = pls.l[i].header ? capacity_entries : pls.l[i].n_host;
+            n_max = n > n_max ? n : n_max;
+        }
+        if (n_max > 0)
+            hipLaunchKernelGGL(count_packed_kernel, dim3(blocks_for(n_max, kBlock), pls.n), dim3(kBlock), 0, st, pls, dv, d4);
+    }
     return (int)hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
+    "glove_count_packed_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -126,6 +127,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_packed_entry_floats": (sz, [i32]),
         "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
+        "glove_count_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
         "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
         "glove_fused_step_bytes": (sz, []),
@@ -680,6 +682,12 @@ class GloveHip:
             raise GloveHipError("mark needs V_row + V entries")
         _check(self.lib.glove_combine_packed_f32(C.byref(lst), tag, C.byref(tables.struct()), _ptr(G_flat), _ptr(mark),
                                                  capacity, _stream()), "glove_combine_packed_f32")
+
+    def count_packed(self, lists, tables, G_flat, mark, capacity: int = 0):
+        """Optional before the combines: ids only one list touches are then applied straight from their entry."""
+        arr = (GlovePackedList * len(lists))(*lists)
+        _check(self.lib.glove_count_packed_f32(arr, len(lists), C.byref(tables.struct()), _ptr(G_flat), _ptr(mark), capacity,
+                                               _stream()), "glove_count_packed_f32")
 
     def apply_packed(self, lists, tables, hyper, G_flat, mark, tail=None, loss_out=None, capacity: int = 0):
         arr = (GlovePackedList * len(lists))(*lists)

@@ -104,6 +104,7 @@ class HipBackend:
         lists = bufs.get("_lists")
         if lists is None:
             lists = bufs["_lists"] = [self.hip.packed_list(bufs["recv"][r]) for r in range(world)]
+        self.hip.count_packed(lists, tables, G, bufs["mark"], cap)       # ids one rank alone touched skip the dense buffer
         for r, lst in enumerate(lists):
             self.hip.combine_packed(lst, r, tables, G, bufs["mark"], cap)
         self.hip.apply_packed(lists, tables, hyper, G, bufs["mark"], None, loss_out, cap)
@@ -148,8 +149,9 @@ class HipBackend:
             off += n
         if not lists:                         # nothing to apply: the scalar work (global bias, loss) still has to happen
             lists = [self.hip.packed_list(recv[0:1], with_header=False, ids=None, n=0, side=0)]
+        self.hip.count_packed(lists, view, G, mark, 0)                    # ids one rank alone touched skip the dense buffer
         for k, lst in enumerate(lists):       # tag = position among the non-empty lists, in rank order
-            if lst.n:
+            if lst.n and len(lists) > 1:      # a single list: every id is its alone, nothing to combine
                 self.hip.combine_packed(lst, k, view, G, mark, 0)
         self.hip.apply_packed(lists, view, hyper, G, mark, tail, loss_out, 0)
 

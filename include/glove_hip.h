@@ -244,8 +244,14 @@ typedef struct glove_packed_list {
     int32_t n;
     int32_t side;
 } glove_packed_list;
+/* Optional, before the combines: counts in mark how many of the lists touch every id (at most 255 lists).  An id only
+ * one list touches then skips the dense buffer altogether — glove_combine_packed_f32 leaves it alone and
+ * glove_apply_packed_adagrad_f32 takes its gradient straight from the entry: two row moves less for most ids of a
+ * Zipf batch.  Same results. */
+int glove_count_packed_f32(const glove_packed_list *lists, int32_t n_lists, const glove_tables *t, float *G_flat,
+                           int32_t *mark, int64_t capacity_entries, void *stream);
 /* Adds one list into G_flat (layout of glove_dense_grad_layout): the first list to touch an id stores its row and
- * leaves tag + 1 in mark[id] (mark: int32[V_row + V], rows first, all zero between steps), later lists add behind
+ * leaves its tag in mark[id] (mark: int32[V_row + V], rows first, all zero between steps), later lists add behind
  * it.  Call once per list, in rank order, on one stream: the sum over ranks then has a fixed order.  G_flat needs no
  * zeroing.  capacity_entries bounds the entry count of a list whose count lives in its header. */
 int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const glove_tables *t, float *G_flat,
