@@ -305,7 +305,8 @@ __global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, i
                 if (slot[mid] <= j) lo = mid; else hi = mid;
             }
             const uint32_t rem = (uint32_t)(slot[lo + 1] - 1 - j);
-            v = make_int4(id, n, s, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
+            // word 2: the id's position among the side's distinct ids (ascending id order)
+            v = make_int4(id, n, lo, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
         } else {
             const int field = (f - 1) / (capP / 4), t0 = ((f - 1) % (capP / 4)) * 4;
             int o[4];

@@ -228,9 +228,14 @@ struct PassSide {
     float *S1, *S1b;               // this side's Adagrad accumulators
     const uint8_t *own_ver, *other_ver;   // not null: that table is twinned, ver[id] != 0 = the current row is id + twin rows
     int own_twin, other_twin;             // rows between the two copies (V_row)
+    //   fuse == kFusePack     nothing is applied: the id's summed gradient (incl. the activity-L2 term) goes straight into
+    //                         its entry of a packed list (glove_pack_grad_f32's layout) — the multi-GPU forms, whose
+    //                         gradients travel before anything is applied; the pack launch then only adds the other ids
+    float *packed;                        // the list
+    int pack_base;                        // entries in front of this side's (1 header + the row side's ids for the col side)
 };
 
-constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2, kFuseTwin = 3;
+constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2, kFuseTwin = 3, kFusePack = 4;
 
 struct StepConsts {
     float kappa, kappa_b;       // 2 m l2 inv_batch / d , 2 m l2 inv_batch
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     const int j_end = FUSE ? (j + per < n_chunks ? j + per : n_chunks) : n_chunks;
     const int j_step = FUSE ? 1 : nblk * GPB;
     int32_t cur_u = -1, own_at = 0;
-    int run_first = 0, run_pairs = 0;
+    int run_first = 0, run_pairs = 0, run_q = 0;
     bool run_whole = false;
     f4 r[NV], acc[NV], A[NV];
     float own_b = 0.f, bg = 0.f, Ab = 0.f, se = 0.f;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     for (;; j += j_step) {
         const bool have = j < j_end;
         int32_t u = -1;
-        int s = 0, n = 0;
+        int s = 0, n = 0, uq = 0;           // uq (records only): position of the id among the side's distinct ids
         uint32_t hw = 0;                    // record header word 3: (first chunk of its id) << 31 | chunks of the id after this one
         const int capP = sd.capP;
         if (!have) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             const uint4 hdr = lrec[0];          // same wave wrote it: LDS ops of one wave complete in order
             u = (int32_t)hdr.x;
             n = (int)hdr.y;
-            s = (int)hdr.z;
+            uq = (int)hdr.z;
             hw = hdr.w;
             GLOVE_DRAIN(); GLOVE_STAMP(1);
         } else {
@@ -346,7 +351,22 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
         const bool new_run = !FUSE || !pending || u != cur_u;
         if (FUSE && pending && (!have || new_run)) {        // the run in registers is complete
             pending = false;
-            if (FUSE && run_whole) {
+            if (FUSE && run_whole && sd.fuse == kFusePack) {
+                // the id's whole gradient is here and it is wanted as a packed-list entry (PackGrad's arithmetic)
+                const float cnt = (float)run_pairs;
+                const float kcn = kc.kappa * cnt;
+                float Gb = se;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) acc[k] += kcn * r[k];
+                Gb += kc.kappa_b * cnt * own_b;
+                f4 *e = reinterpret_cast<f4 *>(sd.packed) + (size_t)(sd.pack_base + run_q) * ((size_t)d4 + 1);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int i4 = lg + k * LPR;
+                    if (i4 < d4) e[i4] = acc[k];
+                }
+                if (lg == 0) e[d4] = f4{Gb, __int_as_float(cur_u), __int_as_float(is_row ? 0 : 1), 0.f};
+            } else if (FUSE && run_whole) {
                 // the id's whole gradient is here: G = sum + activity-L2 term, then Adagrad (the arithmetic of
                 // for_each_id + AdagradApply; on an id with a single chunk expression for expression, bit-identical)
                 const float cnt = (float)run_pairs;
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
         if (new_run) {
             cur_u = u;
             run_first = j;
+            run_q = uq;
             run_pairs = 0;
             own_at = u;
             if (FUSE && sd.own_ver) own_at = u + (sd.own_ver[u] ? sd.own_twin : 0);     // the current copy of a twinned table
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             bg = own_b + g;
             // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
             run_whole = FUSE && sd.fuse != kFuseNone && (hw >> 31) != 0 && j + (int)(hw & 0x7fffffffu) < j_end;
-            if (FUSE && run_whole) {            // requested with the own row: arrives under the partner-row trips
+            if (FUSE && run_whole && sd.fuse != kFusePack) {   // requested with the own row: arrives under the partner-row trips
                 load_row_stream<LPR, NV>(A, sd.S1, u, d4, lg);
                 Ab = sd.S1b[u];
             }
@@ -1506,19 +1527,23 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.own_ver = twin && row ? t->R_ver : nullptr;
     sd.other_ver = twin && !row ? t->R_ver : nullptr;
     sd.own_twin = sd.other_twin = v_row(t);
+    sd.packed = nullptr;
+    sd.pack_base = 0;
     return sd;
 }
 
 // which: 1 = row side, 2 = col side, 3 = both in one launch
 static int launch_passes(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                          void *stream, int which, float *mark_rows = nullptr, float *mark_cols = nullptr,
-                         bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone, bool twin = false)
+                         bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone, bool twin = false,
+                         float *packed = nullptr)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     const bool fuse = fuse_r != kFuseNone || fuse_c != kFuseNone || twin;
     if ((twin || fuse_r == kFuseTwin) && !t->R_ver) return GLOVE_E_BADARG;
     if (fuse_c == kFuseTwin) return GLOVE_E_BADARG;          // only the row table has a twin
-    if (fuse && (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc)) return GLOVE_E_BADARG;
+    const bool applies = twin || (fuse_r != kFuseNone && fuse_r != kFusePack) || (fuse_c != kFuseNone && fuse_c != kFusePack);
+    if (applies && (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc)) return GLOVE_E_BADARG;
     // in place is only legal for a side whose table no concurrent chunk gathers from: one side per launch
     if ((fuse_r == kFuseInPlace && (which & 2)) || (fuse_c == kFuseInPlace && (which & 1))) return GLOVE_E_BADARG;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
@@ -1531,10 +1556,17 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     PassSide rs = pass_side(p, t, w, true, want_e, fuse_r, twin), cs = pass_side(p, t, w, false, false, fuse_c, twin);
     rs.mark = mark_rows;
     cs.mark = mark_cols;
+    if (fuse_r == kFusePack || fuse_c == kFusePack) {
+        if (!packed || p->host_counts[1] < 0) return GLOVE_E_BADARG;
+        rs.packed = cs.packed = packed;
+        rs.pack_base = 1;                                                 // behind the header
+        cs.pack_base = 1 + (fuse_r == kFusePack ? p->host_counts[1] : 0);  // and behind the row side's ids when both sides pack
+    }
     const StepConsts kc = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work
-    const bool rec = p->r_crec != nullptr && p->c_crec != nullptr;
+    // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
+    const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
 #define LAUNCH(LPR, NV, FULL, REC, FUSE) \
     hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
 #define CALL(LPR, NV)                                                                   \
@@ -1711,6 +1743,59 @@ int glove_pack_grad_f32(const glove_plan *p, const glove_tables *t, const glove_
     const RowShape shape = pick_row_shape(d4);
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
+    const StepConsts k = make_consts(t, h);
+    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(LPR, NV)                                                                                       \
+    hipLaunchKernelGGL((pack_grad_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, d4, k, packed, \
+                       w.blockpart, nb_row)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+// The passes can write packed-list entries themselves when the plan has chunk records (run-merged schedule) and its
+// counts are known on the host (the col side's entries start behind the row side's).
+static bool packing_ok(const glove_plan *p)
+{
+    return p->r_crec && p->c_crec && p->host_counts[1] >= 0 && p->host_counts[3] >= 0;
+}
+
+int glove_passes_packing_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                             float *packed, int64_t capacity_entries, void *stream)
+{
+    if (!p || !h) return GLOVE_E_BADARG;
+    const int sides = sides_of(h);
+    if (!packing_ok(p)) return launch_passes(p, t, h, ws, ws_bytes, stream, sides);
+    if (!packed) return GLOVE_E_BADARG;
+    const int64_t nr = (sides & 1) ? p->host_counts[1] : 0, nc = (sides & 2) ? p->host_counts[3] : 0;
+    if (1 + nr + nc > capacity_entries) return GLOVE_E_WORKSPACE;
+    return launch_passes(p, t, h, ws, ws_bytes, stream, sides, nullptr, nullptr, false, (sides & 1) ? kFusePack : kFuseNone,
+                         (sides & 2) ? kFusePack : kFuseNone, false, packed);
+}
+
+int glove_pack_rest_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                        float *packed, int64_t capacity_entries, void *stream)
+{
+    if (!p) return GLOVE_E_BADARG;
+    if (!packing_ok(p)) return glove_pack_grad_f32(p, t, h, ws, ws_bytes, packed, capacity_entries, stream);
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    if (!packed) return GLOVE_E_BADARG;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    IdWork wk = id_work(p);
+    wk.sides = sides_of(h);
+    const int64_t nr = (wk.sides & 1) ? p->host_counts[1] : 0, nc = (wk.sides & 2) ? p->host_counts[3] : 0;
+    if (1 + nr + nc > capacity_entries) return GLOVE_E_WORKSPACE;
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    const int lpr = pass_shape(d4).lpr;
+    wk.pre_r = (wk.sides & 1) ? kFusePack : kFuseNone;
+    wk.pre_c = (wk.sides & 2) ? kFusePack : kFuseNone;
+    wk.per = fuse_per(p, lpr);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
+    // the loss partials: of the packing row pass (its grid), or folded by glove_rowside_step_adagrad_f32 (any count reads them)
+    const int nb_row = fusepass_blocks(p, lpr, wk.per, true);
     const StepConsts k = make_consts(t, h);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     hipStream_t st = (hipStream_t)stream;

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
-    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
+    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
     "glove_count_packed_f32",
 )
@@ -126,6 +126,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_packed_entry_floats": (sz, [i32]),
         "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
+        "glove_passes_packing_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
+        "glove_pack_rest_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_count_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
@@ -674,6 +676,22 @@ class GloveHip:
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
         _check(self.lib.glove_pack_grad_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
                                             ws.numel(), _ptr(packed), packed.shape[0], _stream()), "glove_pack_grad_f32")
+
+    def _packing_call(self, name, plan, tables, hyper, packed, ws):
+        _require(packed, torch.float32)
+        if packed.dim() != 2 or packed.shape[1] != tables.d + 4:
+            raise GloveHipError("packed buffer must be [entries, d + 4]")
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(getattr(self.lib, name)(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
+                                       ws.numel(), _ptr(packed), packed.shape[0], _stream()), name)
+
+    def passes_packing(self, plan, tables, hyper, packed: torch.Tensor, ws=None):
+        """The passes of hyper.sides; ids one lane group holds completely land in the packed list right away."""
+        self._packing_call("glove_passes_packing_f32", plan, tables, hyper, packed, ws)
+
+    def pack_rest(self, plan, tables, hyper, packed: torch.Tensor, ws=None):
+        """Completes the list passes_packing started (the other ids, the header)."""
+        self._packing_call("glove_pack_rest_f32", plan, tables, hyper, packed, ws)
 
     def combine_packed(self, lst: GlovePackedList, tag: int, tables, G_flat, mark, capacity: int):
         _require(G_flat, torch.float32)

@@ -98,6 +98,14 @@ class HipBackend:
     def pack_grad(self, plan, tables, hyper, send):
         self.hip.pack_grad(plan, tables, hyper, send)
 
+    def passes_packing(self, plan, tables, hyper, send):
+        """The passes of hyper.sides, writing the list entries of the ids a lane group holds completely on the way."""
+        self.hip.passes_packing(plan, tables, hyper, send)
+
+    def pack_rest(self, plan, tables, hyper, send):
+        """The rest of the list passes_packing started (the other ids and the header)."""
+        self.hip.pack_rest(plan, tables, hyper, send)
+
     def apply_gathered(self, bufs, world, tables, hyper, G, loss_out):
         """Adds the ranks' lists into G in rank order, then Adagrad on every touched id (G needs no zeroing)."""
         cap = bufs["capacity"]
@@ -222,7 +230,8 @@ class Stepper:
         if not self.dense:
             return [("step", lambda p: b.step_sparse_adagrad(p, t, h, self.loss_out))]
         if self.rows:
-            ph = [("passes", lambda p: b.passes(p, t, h)), ("pack_grad", lambda p: b.pack_grad(p, t, h, self.bufs["send"]))]
+            ph = [("passes", lambda p: b.passes_packing(p, t, h, self.bufs["send"])),
+                  ("pack_grad", lambda p: b.pack_rest(p, t, h, self.bufs["send"]))]
             if self.world > 1:
                 ph.append(("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])))
             else:
@@ -337,10 +346,13 @@ class RowShardedStepper:
             return [("step", lambda p: b.step_sparse_adagrad(p, t, self.hyper, self.loss_out))]
         # the col pass first (it gathers the old rows of R), then the whole row side, applied in place by its pass where a
         # lane group holds an id completely: R, br are local, nothing else reads them in this step
-        ph = [("colpass", lambda p: b.colpass(p, t, self.hyper_cols)),
-              ("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows))]
+        if self.rows:       # the col pass already writes the list entries of the col ids it sums completely
+            ph = [("colpass", lambda p: b.passes_packing(p, t, self.hyper_cols, self.bufs["send"]))]
+        else:
+            ph = [("colpass", lambda p: b.colpass(p, t, self.hyper_cols))]
+        ph.append(("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows)))
         if self.rows:
-            ph += [("pack_grad_cols", lambda p: b.pack_grad(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before its update
+            ph += [("pack_grad_cols", lambda p: b.pack_rest(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before its update
                    ("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])),
                    ("combine_apply_cols", lambda p: b.apply_gathered(self.bufs, self.world, t, self.hyper_cols, self.G,
                                                                        self.loss_out))]
@@ -457,9 +469,10 @@ class ShardedStepper:
         return [("serve_rows", lambda i: b.gather_rows(t, bt[i]["serve_idx"], f["send_rows"], f["send_bias"])),
                 ("fetch_all_to_all", fetch),
                 # the col pass first: it gathers the OLD rows of R, which the row side then updates in place
-                ("colpass", lambda i: b.colpass(bt[i]["plan"], self.view, self.hyper_cols)),
+                # (it also writes the list entries of the col ids it sums completely)
+                ("colpass", lambda i: b.passes_packing(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
                 ("rowside_step", lambda i: b.rowside_step(bt[i]["plan"], self.view, self.hyper_rows)),
-                ("pack_grad_cols", lambda i: b.pack_grad(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
+                ("pack_grad_cols", lambda i: b.pack_rest(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
                 ("push_all_to_all", push),
                 ("owner_apply_cols", lambda i: b.owner_apply(t, self.owner_state, f["recv"], bt[i]["serve_idx"], bt[i]["serve"],
                                                              self.hyper, self.tail, self.loss_out))]

@@ -157,7 +157,7 @@ typedef struct glove_plan {
      * them a whole workgroup that starts ahead of the per-lane-group work on the light ids. */
     int32_t *heavy;
     /* Optional per-chunk records (NULL = absent): chunk j of a side owns rec_dwords = 4 + 3*capP dwords
-     * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, first pair, (1 << 31 if it is the first chunk of its id) | chunks of the same id behind it | partner[capP] | w[capP] |
+     * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, position of the id among the side's distinct ids, (1 << 31 if it is the first chunk of its id) | chunks of the same id behind it | partner[capP] | w[capP] |
      * y[capP]}, padding slots carrying weight 0.  With them the pass kernel gets a chunk's descriptor AND
      * its pair fields in ONE memory round trip (contiguous 16-B loads) instead of two dependent ones.
      * Filled by glove_plan_build when non-NULL, or later by glove_plan_fill_records for an exact-size
@@ -233,6 +233,17 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
  * 2 V (d+1) floats), and it is how a rank returns its col gradients to the owners of a sharded col table. */
 size_t glove_packed_entry_floats(int32_t d);
 int glove_pack_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                        void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
+/* The same list in two calls, for plans with chunk records and host counts (otherwise the pair falls back to
+ * glove_passes_f32-of-the-selected-sides + glove_pack_grad_f32): glove_passes_packing_f32 is the pass launch of
+ * hyper.sides (3 both, 1 rows, 2 cols) in the run-merged schedule of the fused step forms, in which a lane group that
+ * holds every chunk of an id writes that id's entry itself, straight from registers; glove_pack_rest_f32 then packs
+ * the other ids and the header.  In between the caller may run glove_rowside_step_adagrad_f32 (sides 2: the row pass's
+ * loss partials reach the header that way).  Ids with several chunks are summed pair by pair in the first call and
+ * chunk by chunk in glove_pack_grad_f32: equal within fp32 rounding, not bitwise. */
+int glove_passes_packing_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                             void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
+int glove_pack_rest_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
 /* One received list.  entries: the first entry behind the header (or a bare run of entries); ids: if not NULL,
  * ids[i] replaces the id stored in entry i (an owner's local indices); header: if not NULL the entry count is read

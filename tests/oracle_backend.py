@@ -55,6 +55,12 @@ class OracleBackend:
     def rowside_step(self, plan, tables, hyper):
         self.apply_sparse(plan, tables, hyper)
 
+    def passes_packing(self, plan, tables, hyper, send):
+        self.passes(plan, tables, hyper)             # the list is written in one go by pack_rest
+
+    def pack_rest(self, plan, tables, hyper, send):
+        self.pack_grad(plan, tables, hyper, send)
+
     def dense_grad(self, plan, tables, hyper, G):
         gr = self._gr
         G_R, G_br, G_C, G_bc, tail = self._views(tables, G)

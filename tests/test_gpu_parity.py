@@ -104,7 +104,7 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(plan.c_uniq_slot.cpu().numpy()[:nu_c + 1], want["c_uniq_slot"])
     np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
-    # per-chunk records {id, n, start, 0 | partner | w | y} (small plans carry them from the build, big ones
+    # per-chunk records {id, n, id's position, flag | chunks behind | partner | w | y} (small plans carry them from the build, big ones
     # get them when compacted): same content as the SoA arrays, padding slots weigh 0
     cpr = plan.compact(hip.lib)
     capP = (cap + 7) // 8 * 8
@@ -119,10 +119,11 @@ def test_plan_build_bit_exact(hip, B, V, cap):
             ids = np.asarray(ids)
             np.testing.assert_array_equal(rec[:, 0], ids)
             np.testing.assert_array_equal(rec[:, 1], n)
-            np.testing.assert_array_equal(rec[:, 2], starts[:-1])
-            # word 3: first-chunk-of-its-id flag in bit 31, chunks of the same id behind this one below it
+            # word 2: the id's position among the side's distinct ids; word 3: first-chunk-of-its-id flag in bit 31,
+            # chunks of the same id behind this one below it
             first = np.r_[True, ids[1:] != ids[:-1]]
             run_id = np.cumsum(first) - 1
+            np.testing.assert_array_equal(rec[:, 2], run_id)
             run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
             want_w3 = (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31)
             np.testing.assert_array_equal(rec[:, 3].view(np.uint32), want_w3)
@@ -932,9 +933,17 @@ def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap
     for _ in range(3):
         for st in steppers:
             st.step(plan)
-    for other in tabs[1:]:
-        _assert_same_bits(tabs[0], other)
-    assert torch.equal(steppers[0].loss_out[:3], steppers[1].loss_out[:3])
+    _assert_same_bits(tabs[1], tabs[2])
+    if plan.r_crec is None or plan.host_counts[6] == 1:
+        _assert_same_bits(tabs[0], tabs[1])
+        assert torch.equal(steppers[0].loss_out[:3], steppers[1].loss_out[:3])
+    else:
+        # with chunk records the stepper's passes write the entries of the ids they sum completely themselves
+        # (glove_passes_packing_f32): ids of several chunks are then summed pair by pair instead of chunk by chunk
+        for n in ("R", "C", "br", "bc"):
+            torch.testing.assert_close(getattr(tabs[0], n), getattr(tabs[1], n), rtol=2e-5, atol=2e-6)
+            torch.testing.assert_close(tabs[0].s1[n], tabs[1].s1[n], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(steppers[0].loss_out[:3], steppers[1].loss_out[:3], rtol=1e-6, atol=0)
     np.testing.assert_allclose(steppers[0].loss_out.cpu().numpy(), steppers[2].loss_out.cpu().numpy(), rtol=1e-6)
     assert int(steppers[0].bufs["mark"].abs().max()) == 0
     n_r, n_c = plan.host_counts[1], plan.host_counts[3]
@@ -942,6 +951,63 @@ def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap
     assert head == [n_r, n_c]
     ids = steppers[0].bufs["send"][1:1 + n_r + n_c, d + (-d) % 4 + 1].view(torch.int32).cpu().numpy()
     np.testing.assert_array_equal(ids, np.r_[np.unique(row), np.unique(col)])
+
+
+@pytest.mark.parametrize("B,V,d,cap,sides", [(3000, 101, 64, 16, 3), (3000, 101, 64, 16, 2), (20000, 5000, 128, 4, 3),
+                                             (9000, 700, 300, 8, 2), (9000, 700, 300, 8, 1), (6000, 50, 52, 32, 3),
+                                             (40000, 30000, 128, 16, 3), (200000, 3000, 64, 16, 3),
+                                             (600000, 20000, 64, 8, 3), (600000, 20000, 128, 8, 2)])   # several chunks per lane group
+def test_packing_passes_write_the_same_list(hip, B, V, d, cap, sides):
+    """glove_passes_packing_f32 + glove_pack_rest_f32 == glove_passes_f32 + glove_pack_grad_f32: same header, same ids
+    in the same places; gradient rows of single-chunk ids bit for bit, the others (summed pair by pair instead of chunk by
+    chunk) within fp32 rounding; heavy ids and ids split between lane groups come from pack_rest.  Without chunk
+    records the pair IS the second pair of calls."""
+    import os
+    from trainer.hip_api import DeviceTables, make_hyper
+    row, col, w, y = make_batch(B + d, B, V)
+    t = tables_from_oracle(oracle_tables(V, d, "Adagrad"), DeviceTables)
+    h = make_hyper(learning_rate=0.05, batch_size=B, l2_reg=0.01, reg_mult=2.0)
+    h.sides = sides
+    raw = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
+    for records in ("1", "0"):
+        os.environ["GLOVE_RECORDS"] = records
+        try:
+            plan = raw.compact(hip.lib, t.d)
+        finally:
+            del os.environ["GLOVE_RECORDS"]
+        assert (plan.r_crec is not None) == (records == "1")
+        n = 1 + plan.host_counts[1] + plan.host_counts[3]
+        a = torch.full((n, t.d + 4), float("nan"), device="cuda:0")
+        b = torch.full((n, t.d + 4), float("nan"), device="cuda:0")
+        if sides == 2:      # the sharded forms: col pass, row side's step (folds the loss partials), then the pack
+            hr = make_hyper(learning_rate=0.0, batch_size=B, l2_reg=0.01, reg_mult=2.0)     # lr 0: the tables stay as they are
+            hr.sides = 1
+            hip.passes_packing(plan, t, h, a)
+            hip.rowside_step(plan, t, hr)
+            hip.pack_rest(plan, t, h, a)
+            hip.colpass(plan, t, h)
+            hip.rowside_step(plan, t, hr)
+            hip.pack_grad(plan, t, h, b)
+        else:
+            hip.passes_packing(plan, t, h, a)
+            hip.pack_rest(plan, t, h, a)
+            hip.passes(plan, t, h)
+            hip.pack_grad(plan, t, h, b)
+        nr = plan.host_counts[1] if sides & 1 else 0
+        nc = plan.host_counts[3] if sides & 2 else 0
+        a, b = a[:1 + nr + nc].cpu(), b[:1 + nr + nc].cpu()
+        assert not torch.isnan(a[1:]).any() and not torch.isnan(b[1:]).any()        # every entry was written (the header: 8 floats)
+        assert torch.equal(a[0, :2].view(torch.int32), b[0, :2].view(torch.int32))
+        torch.testing.assert_close(a[0, 2:6], b[0, 2:6], rtol=2e-6, atol=0)
+        assert torch.equal(a[1:, t.d + 1:], b[1:, t.d + 1:])                       # id, side, 0
+        if records == "0":
+            assert torch.equal(a[1:], b[1:])
+            continue
+        chunks = np.r_[plan.r_uniq_rec.cpu().numpy().reshape(-1, 4)[:nr, 2], plan.c_uniq_rec.cpu().numpy().reshape(-1, 4)[:nc, 2]]
+        single = torch.from_numpy(chunks == 1)
+        assert single.any() and (chunks > 1).any()
+        assert torch.equal(a[1:, :t.d][single], b[1:, :t.d][single])         # (their bias gradients: a last-bit difference on a few)
+        torch.testing.assert_close(a[1:], b[1:], rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 5000, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8),
