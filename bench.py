@@ -141,7 +141,7 @@ def measured_traffic(workload, B, cap, fused):
         try:
             j = json.load(open(f))
             m = j.get("meta", {})
-            prof_fused = any(k.startswith("sidepass_kernel") and k.rstrip().endswith("true>") for k in j.get("kernels", {}))
+            prof_fused = any(k.startswith("sidepass_kernel") and k.rstrip().endswith(("true>", ", 1>", ", 2>")) for k in j.get("kernels", {}))
             if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap \
                     and prof_fused == bool(fused):
                 return float(j["traffic_bytes_per_step"]), os.path.basename(f)

@@ -231,8 +231,8 @@ struct PassSide {
     //   fuse == kFusePack     nothing is applied: the id's summed gradient (incl. the activity-L2 term) goes straight into
     //                         its entry of a packed list (glove_pack_grad_f32's layout) — the multi-GPU forms, whose
     //                         gradients travel before anything is applied; the pack launch then only adds the other ids
-    float *packed;                        // the list
-    int pack_base;                        // entries in front of this side's (1 header + the row side's ids for the col side)
+    //                         (no fields of their own — the struct is held in scalar registers, which are short: the list
+    //                         is passed in own_out, the number of entries in front of this side's in own_twin)
 };
 
 constexpr int kFuseNone = 0, kFuseSlot = 1, kFuseInPlace = 2, kFuseTwin = 3, kFusePack = 4;
@@ -243,12 +243,21 @@ struct StepConsts {
     float l2, m, inv_batch, inv_d;
 };
 
+// FUSE == 1: the accumulator row a whole run is going to need is requested when the run starts (it arrives under the
+// partner-row trips).  1 = it waits in LDS, written there by the load itself (global_load_lds_dwordx4: no VGPRs held
+// across the trips; the image is [k][lane of the wave], which is the order that instruction writes); 0 = in registers
+// (NV float4 more per lane: the d = 300 shape then spills at 3 waves per SIMD).
+#ifndef GLOVE_ACC_IN_LDS
+#define GLOVE_ACC_IN_LDS 1
+#endif
 #ifndef GLOVE_FUSE_WAVES
 #define GLOVE_FUSE_WAVES 3       // experiment switch; 4 (128 VGPRs) spills 140-188 B per lane and runs twice as long
 #endif
 // FUSE kernels keep the accumulator row of a run in registers as well: held to 3 waves per SIMD (168 VGPRs), which the
 // d = 300 shape misses by one register otherwise
-template <int LPR, int NV, bool FULL, bool REC, bool FUSE>
+// FUSE: 0 classic schedule, 1 run-merged and applying (kFuseSlot / kFuseInPlace / kFuseTwin), 2 run-merged and packing
+// (kFusePack) — a build of its own: the apply code and its accumulator rows would cost the other their registers
+template <int LPR, int NV, bool FULL, bool REC, int FUSE>
 __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_WAVES : PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
@@ -265,6 +274,9 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
     uint32_t(*fld)[3][kFieldStride] = reinterpret_cast<uint32_t(*)[3][kFieldStride]>(fld_raw);
     uint32_t *rec = fld_raw + grp_of(threadIdx.x, LPR) * kRecStride;
+    constexpr bool kPark = FUSE == 1 && GLOVE_ACC_IN_LDS != 0;
+    __shared__ __attribute__((aligned(16))) f4 park_raw[kPark ? (kBlock / 64) * NV * 64 : 1];
+    f4 *park = park_raw + (kPark ? (threadIdx.x / 64) * NV * 64 : 0);       // this wave's image
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const bool is_row = (int)blockIdx.x < row_blocks;
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
         const bool new_run = !FUSE || !pending || u != cur_u;
         if (FUSE && pending && (!have || new_run)) {        // the run in registers is complete
             pending = false;
-            if (FUSE && run_whole && sd.fuse == kFusePack) {
+            if (FUSE == 2 && run_whole) {
                 // the id's whole gradient is here and it is wanted as a packed-list entry (PackGrad's arithmetic)
                 const float cnt = (float)run_pairs;
                 const float kcn = kc.kappa * cnt;
@@ -359,14 +371,14 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += kcn * r[k];
                 Gb += kc.kappa_b * cnt * own_b;
-                f4 *e = reinterpret_cast<f4 *>(sd.packed) + (size_t)(sd.pack_base + run_q) * ((size_t)d4 + 1);
+                f4 *e = reinterpret_cast<f4 *>(sd.own_out) + (size_t)(sd.own_twin + run_q) * ((size_t)d4 + 1);
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     const int i4 = lg + k * LPR;
                     if (i4 < d4) e[i4] = acc[k];
                 }
                 if (lg == 0) e[d4] = f4{Gb, __int_as_float(cur_u), __int_as_float(is_row ? 0 : 1), 0.f};
-            } else if (FUSE && run_whole) {
+            } else if (FUSE == 1 && run_whole) {
                 // the id's whole gradient is here: G = sum + activity-L2 term, then Adagrad (the arithmetic of
                 // for_each_id + AdagradApply; on an id with a single chunk expression for expression, bit-identical)
                 const float cnt = (float)run_pairs;
@@ -375,6 +387,12 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += kcn * r[k];
                 Gb += kc.kappa_b * cnt * bval;
+                if (kPark) {
+                    // every load of the run has been consumed by now, the parked row (requested before them) has landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) A[k] = park[k * 64 + (threadIdx.x & 63)];
+                }
 #pragma unroll
                 for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], acc[k], kc.lr, kc.eps);
                 store_row_stream<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
@@ -408,8 +426,19 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             bg = own_b + g;
             // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
             run_whole = FUSE && sd.fuse != kFuseNone && (hw >> 31) != 0 && j + (int)(hw & 0x7fffffffu) < j_end;
-            if (FUSE && run_whole && sd.fuse != kFusePack) {   // requested with the own row: arrives under the partner-row trips
-                load_row_stream<LPR, NV>(A, sd.S1, u, d4, lg);
+            if (FUSE == 1 && run_whole) {   // requested with the own row: arrives under the partner-row trips
+                if (kPark) {
+                    const f4 *src = reinterpret_cast<const f4 *>(sd.S1) + (size_t)u * d4;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const int i4 = lg + k * LPR;
+                        // destination: the wave-uniform base + lane * 16 B (the hardware adds the lane part)
+                        if (FULL || i4 < d4)
+                            __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 0);
+                    }
+                } else {
+                    load_row_stream<LPR, NV>(A, sd.S1, u, d4, lg);
+                }
                 Ab = sd.S1b[u];
             }
 #pragma unroll
@@ -500,7 +529,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
                 bsq += valid * bcv[a] * bcv[a];
                 ev[a] = e;
             }
-            if (sd.e_out) {                                  // glove_rowpass_f32 only: e_i for diagnostics
+            if (!REC && sd.e_out) {                               // glove_rowpass_f32 only: e_i for diagnostics
                 constexpr int ES = (U + LPR - 1) / LPR;      // pairs of this trip whose e a lane stores
 #pragma unroll
                 for (int x = 0; x < ES; ++x) {
@@ -1527,8 +1556,6 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.own_ver = twin && row ? t->R_ver : nullptr;
     sd.other_ver = twin && !row ? t->R_ver : nullptr;
     sd.own_twin = sd.other_twin = v_row(t);
-    sd.packed = nullptr;
-    sd.pack_base = 0;
     return sd;
 }
 
@@ -1556,11 +1583,13 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     PassSide rs = pass_side(p, t, w, true, want_e, fuse_r, twin), cs = pass_side(p, t, w, false, false, fuse_c, twin);
     rs.mark = mark_rows;
     cs.mark = mark_cols;
-    if (fuse_r == kFusePack || fuse_c == kFusePack) {
-        if (!packed || p->host_counts[1] < 0) return GLOVE_E_BADARG;
-        rs.packed = cs.packed = packed;
-        rs.pack_base = 1;                                                 // behind the header
-        cs.pack_base = 1 + (fuse_r == kFusePack ? p->host_counts[1] : 0);  // and behind the row side's ids when both sides pack
+    const bool pack = fuse_r == kFusePack || fuse_c == kFusePack;
+    if (pack) {
+        // the packing build neither applies nor reads plain arrays: records, and no other fuse mode beside it
+        if (!packed || p->host_counts[1] < 0 || !p->r_crec || !p->c_crec || want_e || applies) return GLOVE_E_BADARG;
+        rs.own_out = cs.own_out = packed;
+        rs.own_twin = 1;                                                  // behind the header
+        cs.own_twin = 1 + (fuse_r == kFusePack ? p->host_counts[1] : 0);  // and behind the row side's ids when both sides pack
     }
     const StepConsts kc = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
@@ -1571,11 +1600,11 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
 #define CALL(LPR, NV)                                                                   \
     if (LPR * NV == d4) {                                                               \
-        if (rec) { if (fuse) LAUNCH(LPR, NV, true, true, true); else LAUNCH(LPR, NV, true, true, false); }      \
-        else { if (fuse) LAUNCH(LPR, NV, true, false, true); else LAUNCH(LPR, NV, true, false, false); }        \
+        if (rec) { if (pack) LAUNCH(LPR, NV, true, true, 2); else if (fuse) LAUNCH(LPR, NV, true, true, 1); else LAUNCH(LPR, NV, true, true, 0); } \
+        else { if (fuse) LAUNCH(LPR, NV, true, false, 1); else LAUNCH(LPR, NV, true, false, 0); }        \
     } else {                                                                            \
-        if (rec) { if (fuse) LAUNCH(LPR, NV, false, true, true); else LAUNCH(LPR, NV, false, true, false); }    \
-        else { if (fuse) LAUNCH(LPR, NV, false, false, true); else LAUNCH(LPR, NV, false, false, false); }      \
+        if (rec) { if (pack) LAUNCH(LPR, NV, false, true, 2); else if (fuse) LAUNCH(LPR, NV, false, true, 1); else LAUNCH(LPR, NV, false, true, 0); } \
+        else { if (fuse) LAUNCH(LPR, NV, false, false, 1); else LAUNCH(LPR, NV, false, false, 0); }      \
     }
     GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL

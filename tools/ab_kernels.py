@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--libs", default="", help="comma-separated builds of libglove_hip.so to compare (default: the shipped one)")
     ap.add_argument("--step-form", type=int, default=0)
     ap.add_argument("--only", default="", help="comma-separated subset of rowpass,colpass,passes,apply,step")
+    ap.add_argument("--twin", action="store_true", help="twinned row table (step form 4 under auto)")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=40)
     args = ap.parse_args()
@@ -33,6 +34,8 @@ def main():
     V, d, B = wl["V"], wl["d"], args.batch_size
     nb = min(8, wl["row"].numel() // B)
     tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
+    if args.twin:
+        tables.enable_twin()
     hyper = make_hyper(learning_rate=0.05, batch_size=B, step_form=args.step_form)
     loss = torch.zeros(4, device=dev)
     configs = []

@@ -15,7 +15,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def kind(r):
     n = r["Kernel_Name"].split("(")[0]
     if "sidepass" in n:
-        return "pass_fused" if n.rstrip().endswith("true>") else "pass"
+        # last template argument: the run-merged schedule (bool in the first round-2 builds, 0 / 1 / 2 since)
+        return "pass_fused" if n.rstrip().endswith(("true>", ", 1>", ", 2>")) else "pass"
     return "apply" if "apply_adagrad" in n else "triage" if "triage" in n else "other"
 
 
