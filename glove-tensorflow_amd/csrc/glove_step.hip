@@ -250,6 +250,12 @@ struct StepConsts {
 #ifndef GLOVE_ACC_IN_LDS
 #define GLOVE_ACC_IN_LDS 1
 #endif
+// Experiment switch (never on in the shipped build): the first GLOVE_HOT_TILE rows of the partner table — the most frequent
+// tokens when ids are frequency ranks, as in a GloVe vocabulary — are staged in LDS by every workgroup of the classic
+// passes and partner gathers of those ids read LDS instead of L2.  DESIGN.md §3 has what it measured.
+#ifndef GLOVE_HOT_TILE
+#define GLOVE_HOT_TILE 0
+#endif
 #ifndef GLOVE_FUSE_WAVES
 #define GLOVE_FUSE_WAVES 3       // experiment switch; 4 (128 VGPRs) spills 140-188 B per lane and runs twice as long
 #endif
@@ -274,6 +280,9 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
     uint32_t(*fld)[3][kFieldStride] = reinterpret_cast<uint32_t(*)[3][kFieldStride]>(fld_raw);
     uint32_t *rec = fld_raw + grp_of(threadIdx.x, LPR) * kRecStride;
+    constexpr int kHot = (FUSE == 0 && LPR * NV <= 16) ? GLOVE_HOT_TILE : 0;     // rows of up to 256 B
+    constexpr int kHotStride = LPR * NV + 1;                    // float4 per staged row (+1: rows start on different banks)
+    __shared__ __attribute__((aligned(16))) f4 hot[kHot ? kHot * kHotStride : 1];
     constexpr bool kPark = FUSE == 1 && GLOVE_ACC_IN_LDS != 0;
     __shared__ __attribute__((aligned(16))) f4 park_raw[kPark ? (kBlock / 64) * NV * 64 : 1];
     f4 *park = park_raw + (kPark ? (threadIdx.x / 64) * NV * 64 : 0);       // this wave's image
@@ -281,6 +290,11 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     const int grp = threadIdx.x / LPR;
     const bool is_row = (int)blockIdx.x < row_blocks;
     const PassSide &sd = is_row ? rowside : colside;
+    if (kHot) {
+        const f4 *src = reinterpret_cast<const f4 *>(sd.other);
+        for (int i = threadIdx.x; i < kHot * d4; i += kBlock) hot[(i / d4) * kHotStride + i % d4] = src[i];
+        __syncthreads();
+    }
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
     const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
     GLOVE_STAMP(0);
@@ -469,7 +483,12 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             float bcv[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
-                load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                if (kHot && col[a] < kHot) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) c[a][k] = (FULL || lg + k * LPR < d4) ? hot[col[a] * kHotStride + lg + k * LPR] : f4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                }
                 // the partner bias enters the dot once, through lane 0 of the group (a masked 1-lane-per-group
                 // load instead of a 64-lane gather of the same 4 bytes), and the butterfly spreads it
                 bcv[a] = 0.f;
