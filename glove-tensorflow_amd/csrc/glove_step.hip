@@ -1105,6 +1105,11 @@ __global__ __launch_bounds__(kBlock) void count_packed_kernel(PackedLists pls, D
     }
 }
 
+// A lane group walks entries gg, gg + TG, gg + 2 TG, ... (TG lane groups in the launch).  Looked up one entry at a time
+// that is three dependent round trips per entry (id -> mark -> rows) and ~16 entries per group at C5, a latency chain.
+// Instead the group's LPR lanes look LPR entries up at once — lane t the id, side, bias gradient and mark of the t-th
+// of them — and the rows are then moved two entries at a time, what each needs handed round by lane shuffles: one
+// round trip per pair of entries.
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
     PackedLists pls, DenseViews dv, SideBufs rs, SideBufs cs, int d4, StepConsts k, int first_tag,
@@ -1115,40 +1120,72 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
     const size_t stride4 = (size_t)d4 + 1;
     const PackedList &pl = pls.l[blockIdx.y];
     const int tag = first_tag + blockIdx.y;
-    const int n = packed_count(pl);
-    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
-        const f4 x = (reinterpret_cast<const f4 *>(pl.entries) + (size_t)i * stride4)[d4];
-        const int32_t id = pl.ids ? pl.ids[i] : __float_as_int(x.y);
-        const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
-        int32_t *mk = dv.mark + (is_row ? 0 : dv.V_row) + id;
-        const int32_t m = *mk;
-        const bool direct = (m & kMarkCountMask) == 1;          // this entry is the id's only one: its row IS the sum
-        if (!direct && (m >> kMarkCountBits) != tag + 1) continue;   // another list stored the id first: its entry applies it
-        const SideBufs &sb = is_row ? rs : cs;
-        f4 G[NV], Wv[NV], A[NV];
-        if (direct) {
-            const f4 *e = reinterpret_cast<const f4 *>(pl.entries) + (size_t)i * stride4;
-#pragma unroll
-            for (int kk = 0; kk < NV; ++kk) {
-                const int i4 = lg + kk * LPR;
-                const f4 v = e[i4 < d4 ? i4 : d4 - 1];
-                G[kk] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-            load_row<LPR, NV>(G, is_row ? dv.G_R : dv.G_C, id, d4, lg);
+    const long n = packed_count(pl);
+    const long TG = (long)gridDim.x * GPB, gg = (long)blockIdx.x * GPB + grp;
+    const f4 *entries = reinterpret_cast<const f4 *>(pl.entries);
+    for (long t0 = 0; gg + t0 * TG < n; t0 += LPR) {
+        const long il = gg + (t0 + lg) * TG;
+        int32_t id_l = 0;
+        int row_l = 1, todo_l = 0;      // todo: 0 nothing (past the end, or another list stored the id first: its entry
+        float gb_l = 0.f;               // applies it), 1 this entry is the id's only one: its row IS the sum, 2 the dense buffer has the sum
+        if (il < n) {
+            const f4 x = entries[il * stride4 + d4];
+            id_l = pl.ids ? pl.ids[il] : __float_as_int(x.y);
+            row_l = (pl.side >= 0 ? pl.side : __float_as_int(x.z)) == 0;
+            gb_l = x.x;
+            const int32_t m = dv.mark[(row_l ? 0 : dv.V_row) + id_l];
+            todo_l = (m & kMarkCountMask) == 1 ? 1 : ((m >> kMarkCountBits) == tag + 1 ? 2 : 0);
         }
-        load_row<LPR, NV>(Wv, sb.W, id, d4, lg);
-        load_row<LPR, NV>(A, sb.S1, id, d4, lg);
-        float Gb = direct ? x.x : (is_row ? dv.G_br : dv.G_bc)[id], bval = sb.bias[id], Ab = sb.S1b[id];
+        for (int tt = 0; tt < LPR; tt += 2) {
+            if (gg + (t0 + tt) * TG >= n) break;
+            int todo[2];
+            int32_t id[2];
+            bool is_row[2];
+            float Gb[2], bval[2], Ab[2];
+            f4 G[2][NV], Wv[2][NV], A[2][NV];
 #pragma unroll
-        for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[kk], A[kk], G[kk], k.lr, k.eps);
-        store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, A);
-        store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
-        if (lg == 0) {
-            adagrad_elem(bval, Ab, Gb, k.lr, k.eps);
-            sb.S1b[id] = Ab;
-            sb.bias[id] = bval;
-            *mk = 0;
+            for (int e = 0; e < 2; ++e) {
+                todo[e] = __shfl(todo_l, tt + e, LPR);
+                id[e] = __shfl(id_l, tt + e, LPR);
+                is_row[e] = __shfl(row_l, tt + e, LPR) != 0;
+                Gb[e] = __shfl(gb_l, tt + e, LPR);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!todo[e]) continue;
+                const float *W = is_row[e] ? rs.W : cs.W, *S1 = is_row[e] ? rs.S1 : cs.S1;
+                if (todo[e] == 1) {
+                    const f4 *row = entries + (size_t)(gg + (t0 + tt + e) * TG) * stride4;
+#pragma unroll
+                    for (int kk = 0; kk < NV; ++kk) {
+                        const int i4 = lg + kk * LPR;
+                        const f4 v = row[i4 < d4 ? i4 : d4 - 1];
+                        G[e][kk] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                } else {
+                    load_row<LPR, NV>(G[e], is_row[e] ? dv.G_R : dv.G_C, id[e], d4, lg);
+                    Gb[e] = (is_row[e] ? dv.G_br : dv.G_bc)[id[e]];
+                }
+                load_row<LPR, NV>(Wv[e], W, id[e], d4, lg);
+                load_row<LPR, NV>(A[e], S1, id[e], d4, lg);
+                bval[e] = (is_row[e] ? rs.bias : cs.bias)[id[e]];
+                Ab[e] = (is_row[e] ? rs.S1b : cs.S1b)[id[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!todo[e]) continue;
+                float *W = is_row[e] ? rs.W : cs.W, *S1 = is_row[e] ? rs.S1 : cs.S1;
+#pragma unroll
+                for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[e][kk], A[e][kk], G[e][kk], k.lr, k.eps);
+                store_row<LPR, NV>(S1, (size_t)id[e], d4, lg, A[e]);
+                store_row<LPR, NV>(W, (size_t)id[e], d4, lg, Wv[e]);
+                if (lg == 0) {
+                    adagrad_elem(bval[e], Ab[e], Gb[e], k.lr, k.eps);
+                    (is_row[e] ? rs.S1b : cs.S1b)[id[e]] = Ab[e];
+                    (is_row[e] ? rs.bias : cs.bias)[id[e]] = bval[e];
+                    dv.mark[(is_row[e] ? 0 : dv.V_row) + id[e]] = 0;
+                }
+            }
         }
     }
     if (do_scalars && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
