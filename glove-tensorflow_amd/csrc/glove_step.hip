@@ -875,6 +875,14 @@ __global__ __launch_bounds__(kBlock) void fold_blockpart_kernel(float *__restric
     for (int i = threadIdx.x; i < kMaxBlocks * kPartials; i += kBlock) blockpart[i] = i < kPartials ? keep[i] : 0.f;
 }
 
+// The loss partials of the last row pass as they travel in a packed list's header: {sum e, sum w diff^2, sum |r|^2+|c|^2, sum b^2}
+__global__ __launch_bounds__(kBlock) void loss_partials_kernel(const float *__restrict__ blockpart, int nblocks, float *__restrict__ out)
+{
+    float tot[kPartials];
+    sum_blockpart(blockpart, nblocks, tot);
+    if (threadIdx.x == 0) { out[0] = tot[3]; out[1] = tot[0]; out[2] = tot[1]; out[3] = tot[2]; }
+}
+
 template <int LPR, int NV>
 struct AdagradApply {
     SideBufs rs, cs;
@@ -1889,6 +1897,19 @@ int glove_pack_rest_f32(const glove_plan *p, const glove_tables *t, const glove_
                        w.blockpart, nb_row)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
+    return (int)hipGetLastError();
+}
+
+int glove_loss_partials_f32(const glove_plan *p, const glove_tables *t, void *ws, size_t ws_bytes, float *out4, void *stream)
+{
+    if (!p || !t || !ws || !out4 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
+    const int lpr = pass_shape(t->d / 4).lpr;
+    if (lpr == 0) return GLOVE_E_BADARG;
+    // the grid of the row pass that left them (folded by glove_rowside_step_adagrad_f32: any count reads the same)
+    const int nb_row = packing_ok(p) ? fusepass_blocks(p, lpr, fuse_per(p, lpr), true) : rowpass_blocks(p, lpr);
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, w.blockpart, nb_row, out4);
     return (int)hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
-    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
+    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_loss_partials_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
     "glove_count_packed_f32",
 )
@@ -128,6 +128,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_passes_packing_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_pack_rest_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
+        "glove_loss_partials_f32": (C.c_int, [P(GlovePlan), P(GloveTables), vp, sz, vp, vp]),
         "glove_combine_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_count_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
@@ -692,6 +693,13 @@ class GloveHip:
     def pack_rest(self, plan, tables, hyper, packed: torch.Tensor, ws=None):
         """Completes the list passes_packing started (the other ids, the header)."""
         self._packing_call("glove_pack_rest_f32", plan, tables, hyper, packed, ws)
+
+    def loss_partials(self, plan, tables, out4: torch.Tensor, ws=None):
+        """out4 = {sum e, sum w diff^2, sum |r|^2+|c|^2, sum b^2} of the plan's last row pass (a list header's floats 2..5)."""
+        _require(out4, torch.float32, 4)
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        _check(self.lib.glove_loss_partials_f32(C.byref(plan.struct()), C.byref(tables.struct()), _ptr(ws), ws.numel(),
+                                                _ptr(out4), _stream()), "glove_loss_partials_f32")
 
     def combine_packed(self, lst: GlovePackedList, tag: int, tables, G_flat, mark, capacity: int):
         _require(G_flat, torch.float32)

@@ -102,12 +102,17 @@ class HipBackend:
         """The passes of hyper.sides, writing the list entries of the ids a lane group holds completely on the way."""
         self.hip.passes_packing(plan, tables, hyper, send)
 
+    def loss_partials(self, plan, tables, out4):
+        """out4 = {sum e, sum w diff^2, sum |r|^2+|c|^2, sum b^2} of the plan's last row pass (floats 2..5 of a list header)."""
+        self.hip.loss_partials(plan, tables, out4)
+
     def pack_rest(self, plan, tables, hyper, send):
         """The rest of the list passes_packing started (the other ids and the header)."""
         self.hip.pack_rest(plan, tables, hyper, send)
 
-    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out):
-        """Adds the ranks' lists into G in rank order, then Adagrad on every touched id (G needs no zeroing)."""
+    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out, tail=None):
+        """Adds the ranks' lists into G in rank order, then Adagrad on every touched id (G needs no zeroing).
+        tail: the loss partials summed over the ranks when the lists' headers do not carry them."""
         cap = bufs["capacity"]
         lists = bufs.get("_lists")
         if lists is None:
@@ -115,7 +120,7 @@ class HipBackend:
         self.hip.count_packed(lists, tables, G, bufs["mark"], cap)       # ids one rank alone touched skip the dense buffer
         for r, lst in enumerate(lists):
             self.hip.combine_packed(lst, r, tables, G, bufs["mark"], cap)
-        self.hip.apply_packed(lists, tables, hyper, G, bufs["mark"], None, loss_out, cap)
+        self.hip.apply_packed(lists, tables, hyper, G, bufs["mark"], tail, loss_out, cap)
 
     # ---- both tables sharded (ShardedStepper)
     def gather_rows(self, tables, idx, rows, biases):
@@ -174,12 +179,12 @@ class HipBackend:
         return self.hip.topk_cosine(R, query_ids, k)
 
 
-def all_gather_rows(dist, recv, send):
-    """recv[r] = rank r's `send` (equal shapes)."""
+def all_gather_rows(dist, recv, send, async_op=False):
+    """recv[r] = rank r's `send` (equal shapes).  async_op: returns the work handle (wait() before reading recv)."""
     try:
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        return dist.all_gather_into_tensor(recv.view(-1), send.view(-1), async_op=async_op)
     except (RuntimeError, NotImplementedError):          # a transport without the flat form
-        dist.all_gather([recv[r] for r in range(recv.shape[0])], send)
+        return dist.all_gather([recv[r] for r in range(recv.shape[0])], send, async_op=async_op)
 
 
 class Stepper:
@@ -322,6 +327,8 @@ class RowShardedStepper:
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
+        self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials over the ranks
+        self._gather = None                     # the lists' all-gather while it is in flight
         self.G = backend.dense_grad_buffer(tables) if self.world > 1 else None
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(backend.col_half(tables, self.G).numel()) if self.G is not None else 0
@@ -350,13 +357,28 @@ class RowShardedStepper:
             ph = [("colpass", lambda p: b.passes_packing(p, t, self.hyper_cols, self.bufs["send"]))]
         else:
             ph = [("colpass", lambda p: b.colpass(p, t, self.hyper_cols))]
-        ph.append(("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows)))
         if self.rows:
+            # the lists travel while the row side runs: the all-gather is started (it waits for what this stream has
+            # enqueued — the list is complete) and awaited after the row side; the loss partials, which the row pass
+            # leaves, follow in a 4-float all-reduce
+            def gather(p):
+                self._gather = all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"], async_op=True)
+
+            def loss_tail(p):
+                if self._gather is not None:
+                    self._gather.wait()
+                    self._gather = None
+                b.loss_partials(p, t, self.tail)
+                self.dist.all_reduce(self.tail)
+
             ph += [("pack_grad_cols", lambda p: b.pack_rest(p, t, self.hyper_cols, self.bufs["send"])),      # reads C: before its update
-                   ("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])),
+                   ("all_gather", gather),
+                   ("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows)),
+                   ("loss_tail", loss_tail),
                    ("combine_apply_cols", lambda p: b.apply_gathered(self.bufs, self.world, t, self.hyper_cols, self.G,
-                                                                       self.loss_out))]
+                                                                       self.loss_out, self.tail))]
         else:
+            ph.append(("rowside_step", lambda p: b.rowside_step(p, t, self.hyper_rows)))
             ph += [("dense_grad_cols", lambda p: b.dense_grad(p, t, self.hyper_cols, self.G)),   # reads C (activity-L2 term): before its update
                    ("all_reduce", lambda p: self.dist.all_reduce(b.col_half(t, self.G))),
                    ("dense_adagrad_cols", lambda p: b.apply_dense(t, self.hyper_cols, self.G, self.loss_out))]
@@ -404,6 +426,8 @@ class ShardedStepper:
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.batches, self.bufs, self.view, self.owner_state = [], None, None, {}
+        self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials, summed over ranks
+        self._push = None                       # the col gradients' all-to-all while it is in flight
         if hasattr(backend, "shard_rows"):
             backend.shard_rows = tables.V_row       # local row ids: anything outside the shard counts as id 0, like a bad col id
 
@@ -460,9 +484,21 @@ class ShardedStepper:
             a2a(f["bc"][:n], f["send_bias"][:ns], bt[i]["want"], bt[i]["serve"])
 
         def push(i):
+            # started, not awaited: the row side below runs while the gradients travel (the collective waits for what
+            # this stream has enqueued so far — the packed list is complete — and runs on the transport's own stream)
             n, ns = bt[i]["n"], bt[i]["ns"]
-            a2a(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"], bt[i]["want"])
-            self.tail = f["packed"][0, 2:6].clone()
+            if W > 1:
+                self._push = dist.all_to_all_single(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"], bt[i]["want"],
+                                                    async_op=True)
+            else:
+                f["recv"][:ns].copy_(f["packed"][1:1 + n])
+
+        def loss_tail(i):
+            if self._push is not None:
+                self._push.wait()
+                self._push = None
+            # the loss partials come from the row pass, which ran after the list left: handed to the owners' apply apart
+            b.loss_partials(bt[i]["plan"], self.view, self.tail)
             if W > 1:
                 dist.all_reduce(self.tail)
 
@@ -471,9 +507,10 @@ class ShardedStepper:
                 # the col pass first: it gathers the OLD rows of R, which the row side then updates in place
                 # (it also writes the list entries of the col ids it sums completely)
                 ("colpass", lambda i: b.passes_packing(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
-                ("rowside_step", lambda i: b.rowside_step(bt[i]["plan"], self.view, self.hyper_rows)),
                 ("pack_grad_cols", lambda i: b.pack_rest(bt[i]["plan"], self.view, self.hyper_cols, f["packed"])),
                 ("push_all_to_all", push),
+                ("rowside_step", lambda i: b.rowside_step(bt[i]["plan"], self.view, self.hyper_rows)),
+                ("loss_tail", loss_tail),
                 ("owner_apply_cols", lambda i: b.owner_apply(t, self.owner_state, f["recv"], bt[i]["serve_idx"], bt[i]["serve"],
                                                              self.hyper, self.tail, self.loss_out))]
 

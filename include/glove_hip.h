@@ -245,6 +245,13 @@ int glove_passes_packing_f32(const glove_plan *plan, const glove_tables *t, cons
                              void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
 int glove_pack_rest_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
+/* out4 (device float[4]) = {sum e, sum w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2} of the plan's last row pass — what
+ * a list's header carries in floats 2..5 — for callers that send the list BEFORE the row side has run (the push of
+ * the col gradients then overlaps glove_rowside_step_adagrad_f32) and hand the sums over afterwards
+ * (glove_apply_packed_adagrad_f32's `tail`).  Valid after glove_rowside_step_adagrad_f32 or a
+ * glove_passes_packing_f32 that included the row side. */
+int glove_loss_partials_f32(const glove_plan *plan, const glove_tables *t, void *ws, size_t ws_bytes,
+                            float *out4, void *stream);
 /* One received list.  entries: the first entry behind the header (or a bare run of entries); ids: if not NULL,
  * ids[i] replaces the id stored in entry i (an owner's local indices); header: if not NULL the entry count is read
  * from it on the device, otherwise n is the count; side: -1 = every entry names its side, 0 / 1 = all of that side. */

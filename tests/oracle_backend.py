@@ -48,6 +48,7 @@ class OracleBackend:
         if getattr(tables, "_base", None) is not None:      # a col_view: the global bias lives in the real tables
             tables.t.g = tables._base.t.g
         self._gr = ref.gradients(tables.t, row, col, w, y, hyper["hp"], inv_batch=hyper["inv_batch"])
+        self._inv_batch = hyper["inv_batch"]
 
     def colpass(self, plan, tables, hyper):
         self.passes(plan, tables, hyper)             # the oracle forms every gradient at once, from the pre-step tables
@@ -60,6 +61,13 @@ class OracleBackend:
 
     def pack_rest(self, plan, tables, hyper, send):
         self.pack_grad(plan, tables, hyper, send)
+
+    tail_dtype = torch.float64
+
+    def loss_partials(self, plan, tables, out4):
+        out4.zero_()
+        out4[0] = float(self._gr["sum_e"])
+        out4[1] = float(self._gr["L"]) / self._inv_batch
 
     def dense_grad(self, plan, tables, hyper, G):
         gr = self._gr
@@ -158,13 +166,15 @@ class OracleBackend:
             loss_out[1] = tail[1] * inv_batch
             t.step += 1
 
-    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out):
+    def apply_gathered(self, bufs, world, tables, hyper, G, loss_out, tail_in=None):
         recv = bufs["recv"].numpy()
         lists, tail = [], np.zeros(2)
         for r in range(world):
             n = int(recv[r, 0, 0] + recv[r, 0, 1])
             lists.append((recv[r, 1:1 + n], None, None))
             tail += recv[r, 0, 2:4]
+        if tail_in is not None:                 # the loss partials were handed over apart from the lists
+            tail = tail_in.numpy()[:2].copy()
         self._apply_lists(tables.t, hyper["hp"], lists, hyper["sides"], tail, loss_out, hyper["inv_batch"])
 
     # ---- both tables sharded
