@@ -516,9 +516,22 @@ def test_randomized_forms_agree_bitwise(hip, seed):
         if c["optimizer"] == "Adagrad" else []
     if fused:
         fused[2][0].enable_twin()              # form 4 steps on a twinned row table
+    exch = None
+    if fused and seed % 2:
+        # the touched-rows exchange of the data-parallel form on one rank: packing passes + pack_rest -> count, combine,
+        # apply from the list.  With chunk records it sums like the fused forms, without them like the two-launch step
+        from trainer.stepper import HipBackend, Stepper
+        et = tables_from_oracle(t, DeviceTables)
+        exch = Stepper(HipBackend("cuda:0"), et, dict(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=hp.learning_rate,
+                                                      epsilon=hp.epsilon, head=hp.head, neg_factor=hp.neg_factor),
+                       c["B"], exchange="rows")
+        exch.prepare([plan])
+        assert exch.rows
     for _ in range(c["steps"]):
         for ft, fh in fused:                   # the forms whose single-chunk ids are applied by the pass kernel itself
             hip.step_adagrad(plan, ft, fh)
+        if exch:
+            exch.step(plan)
         if c["optimizer"] == "Adagrad":
             hip.step_adagrad(plan, a, h)
             hip.passes(plan, b, h)
@@ -541,6 +554,9 @@ def test_randomized_forms_agree_bitwise(hip, seed):
         _assert_same_bits(fused[0][0], fused[1][0], "step_form 2 vs 3 " + info)
         _assert_same_bits(fused[0][0], fused[2][0], "step_form 2 vs 4 " + info)
         _assert_tables_agree(a, fused[0][0], 2e-5 * c["steps"], 2e-6 * c["steps"], "step_form 2 vs 1 " + info)
+    if exch:
+        _assert_same_bits(fused[0][0] if plan.r_crec is not None else a, exch.tables, "rows exchange " + info)
+        assert int(exch.bufs["mark"].abs().max()) == 0, info
 
 
 @pytest.mark.parametrize("B,V,d,cap", STEP_CASES + [(4096, 4096, 64, 32), (9000, 20000, 300, 16), (30000, 300000, 128, 16),
