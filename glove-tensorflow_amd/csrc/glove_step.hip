@@ -848,6 +848,7 @@ __global__ __launch_bounds__(kBlock) void triage_kernel(IdWork wk, SideBufs rs, 
     const int q = blockIdx.x * kBlock + threadIdx.x;
     if (q >= nu_r + nu_c) return;
     const bool is_row = q < nu_r;
+    if (!(wk.sides & (is_row ? 1 : 2))) return;          // not a side of this step
     const int4 rec = is_row ? reinterpret_cast<const int4 *>(rs.uniq_rec)[q] : reinterpret_cast<const int4 *>(cs.uniq_rec)[q - nu_r];
     if (rec.z > wk.heavy_chunks) return;
     const int pre = is_row ? wk.pre_r : wk.pre_c;
@@ -1722,10 +1723,13 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
         rs.twin = v_row(t);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (pre_r == kFuseTwin && pre_c == kFuseInPlace && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0 && wk.sides == 3) {
+    const bool short_list = (pre_r == kFuseTwin && pre_c == kFuseInPlace && wk.sides == 3) ||
+                            (pre_r == kFuseInPlace && wk.sides == 1);        // glove_rowside_step_adagrad_f32
+    if (short_list && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0) {
         // sort the ids out first (triage_kernel, a thread per id): the launch below then walks the list of those that
         // still need it.  Only where that list is short — the twin form, whose finished ids need a version flip at most
-        // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage).  Behind the slot form every row id still needs its
+        // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage), and the in-place row side of the sharded forms,
+        // whose finished ids need nothing.  Behind the slot form every row id still needs its
         // copy, nearly all ids go onto the list and its one counter becomes the bottleneck (V = 2 M: 51 us of triage)
         wk.work = w.work;
         const int nbt = (int)(((int64_t)wk.nu_r_host + wk.nu_c_host + kBlock - 1) / kBlock);
