@@ -30,15 +30,19 @@ __device__ inline void stamp(int slot)
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- per-chunk records (glove_plan.r_crec / c_crec) --------------------------------------------------
-// A record is 4 + 3 * capP dwords: header, then partner[capP], w[capP], y[capP], with capP = rec_cap(chunk_cap).
+// A record is 4 + 3 * capP dwords, capP = rec_cap(chunk_cap): the header, then capP / kRecPad blocks of kRecPad pairs,
+// each block {partner[8] | w[8] | y[8]} — so that what a chunk of n pairs needs is the PREFIX of 4 + 24 ceil(n / 8)
+// dwords (a reader that knows n, or finds it in the header after a first 112-byte read, fetches no padding).
 // INVARIANT: a trip of the pass kernel reads U <= kRecPad consecutive pair slots of each field starting at a multiple
-// of U below the chunk's pair count, so every field must hold a multiple of kRecPad slots, the slots behind the
-// chunk's pairs being VALID partner ids with weight 0 (fill_records replays pair 0 there).  A record sized for the
+// of U below the chunk's pair count, i.e. inside one block; the slots behind the chunk's pairs in the chunk's last
+// block are VALID partner ids with weight 0 (fill_records replays pair 0 there).  A record sized for the
 // bare chunk_cap (or rounded to 4 only) lets the 8-slot trips of the d <= 32 shapes read the head of the w field as
 // partner ids — float bit patterns used as row numbers, a load far outside the table: the GPU fault behind the
 // aborted run of (B = 3000, V = 40, d = 16, chunk_cap = 2) while the records were being written.
 constexpr int kRecPad = 8;
 __host__ __device__ inline int rec_cap(int chunk_cap) { return (chunk_cap + kRecPad - 1) / kRecPad * kRecPad; }
+// dword of pair q's partner id inside a record (its weight: + kRecPad, its value: + 2 kRecPad)
+__host__ __device__ inline int rec_pair(int q) { return 4 + 3 * kRecPad * (q / kRecPad) + q % kRecPad; }
 
 // ---- cross-lane sums ------------------------------------------------------------------
 // Butterfly all-reduce inside an aligned group of LPR lanes.  Strides 1,2 use quad_perm DPP;

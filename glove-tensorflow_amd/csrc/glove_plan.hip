@@ -308,7 +308,9 @@ __global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, i
             // word 2: the id's position among the side's distinct ids (ascending id order)
             v = make_int4(id, n, lo, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
         } else {
-            const int field = (f - 1) / (capP / 4), t0 = ((f - 1) % (capP / 4)) * 4;
+            // blocks of kRecPad = 8 pairs, each {partner[8] | w[8] | y[8]}: float4 r of block b holds field r / 2, pairs 8 b + 4 (r % 2) ..
+            const int b = (f - 1) / 6, r = (f - 1) % 6;
+            const int field = r / 2, t0 = b * kRecPad + (r % 2) * 4;
             int o[4];
             for (int x = 0; x < 4; ++x) {
                 const int t = t0 + x;

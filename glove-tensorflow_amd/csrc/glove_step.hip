@@ -256,6 +256,10 @@ struct StepConsts {
 #ifndef GLOVE_HOT_TILE
 #define GLOVE_HOT_TILE 0
 #endif
+// 1 = the run-merged passes over wide rows read a chunk record in two steps (first block, then the rest if the chunk is longer)
+#ifndef GLOVE_REC_TWO_PHASE
+#define GLOVE_REC_TWO_PHASE 1
+#endif
 #ifndef GLOVE_FUSE_WAVES
 #define GLOVE_FUSE_WAVES 3       // experiment switch; 4 (128 VGPRs) spills 140-188 B per lane and runs twice as long
 #endif
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
     static_assert(U % 4 == 0 && U <= kRecPad && kRecPad % U == 0, "fields are read back four pairs at a time; record fields are padded to kRecPad slots");
     // [group][field][pair]: 0 partner, 1 w (REC) or w2 = 2 w inv_batch, 2 y.  With records the group's LDS image
-    // is the record itself: header float4, then the three fields, each capP dwords
+    // is the record itself: header float4, then the blocks of 8 pairs (glove_common.h)
     constexpr int kRecStride = 4 + 3 * kChunkMax + 4;        // dwords; +16 B staggers the groups over the banks
     static_assert(kChunkMax % kRecPad == 0 && 4 + 3 * kChunkMax <= kRecStride, "the largest record fits a group's LDS image");
     __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
@@ -335,11 +339,27 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
         const int capP = sd.capP;
         if (!have) {
         } else if (REC) {
-            // ONE round trip: the whole record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
+            // the record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
             const int rq = 1 + 3 * capP / 4;
             const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rq;
             uint4 *lrec = reinterpret_cast<uint4 *>(rec);
-            for (int f = lg; f < rq; f += LPR) lrec[f] = rp[f];
+            if (FUSE != 0 && GLOVE_REC_TWO_PHASE != 0 && NV >= 3) {
+                // run-merged passes over wide rows (bound by bytes): header + first block of 8 pairs (112 B, one round
+                // trip); a chunk of more pairs fetches its other blocks once the header has told how many (a second
+                // round trip for the long chunks only) — the padding up to the cap, 3/4 of a record on average, is
+                // never read.  Measured in one process against whole-record reads: V = 400 k, d = 300, B = 1 M
+                // 574 vs 579 us per step; V = 2 M, d = 128 495.6 vs 492.6 (512-B rows: bound by requests in flight,
+                // not by bytes — hence NV >= 3); V = 400 k at B = 131,072 139.0 vs 139.6
+                constexpr int kHead = 1 + 6;
+                static_assert(LPR >= kHead, "one load per lane covers the header and the first block");
+                if (lg < kHead) lrec[lg] = rp[lg];
+                const int n1 = (int)lrec[0].y;
+                const int nq = 1 + 6 * ((n1 + kRecPad - 1) / kRecPad);
+                for (int f = kHead + lg; f < nq; f += LPR) lrec[f] = rp[f];
+            } else {
+                // latency-bound forms: ONE round trip for the whole record
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[f];
+            }
             const uint4 hdr = lrec[0];          // same wave wrote it: LDS ops of one wave complete in order
             u = (int32_t)hdr.x;
             n = (int)hdr.y;
@@ -368,10 +388,10 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
         if (FUSE && have && sd.other_ver) {
             // twinned partner table: the staged partner ids become the rows that are current.  One byte gather per pair,
             // issued with the own-row load below (whose latency covers it), instead of a dependent hop in every trip
-            uint32_t *ids = REC ? rec + 4 : &fld[grp][0][0];
             for (int t = lg; t < n; t += LPR) {
-                const uint32_t id = ids[t];
-                ids[t] = id + (sd.other_ver[id] ? (uint32_t)sd.other_twin : 0u);
+                uint32_t *slot = REC ? rec + rec_pair(t) : &fld[grp][0][t];
+                const uint32_t id = *slot;
+                *slot = id + (sd.other_ver[id] ? (uint32_t)sd.other_twin : 0u);
             }
         }
         const bool new_run = !FUSE || !pending || u != cur_u;
@@ -469,9 +489,10 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             float w2[U], yq[U];
 #pragma unroll
             for (int a4 = 0; a4 < U; a4 += 4) {
-                const uint4 pc = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + q0 + a4] : &fld[grp][0][q0 + a4]);
-                const uint4 pw = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + capP + q0 + a4] : &fld[grp][1][q0 + a4]);
-                const uint4 py = *reinterpret_cast<const uint4 *>(REC ? &rec[4 + 2 * capP + q0 + a4] : &fld[grp][2][q0 + a4]);
+                const int rp0 = rec_pair(q0 + a4);          // records: blocks of 8 pairs {partner | w | y}
+                const uint4 pc = *reinterpret_cast<const uint4 *>(REC ? &rec[rp0] : &fld[grp][0][q0 + a4]);
+                const uint4 pw = *reinterpret_cast<const uint4 *>(REC ? &rec[rp0 + kRecPad] : &fld[grp][1][q0 + a4]);
+                const uint4 py = *reinterpret_cast<const uint4 *>(REC ? &rec[rp0 + 2 * kRecPad] : &fld[grp][2][q0 + a4]);
                 col[a4] = (int32_t)pc.x; col[a4 + 1] = (int32_t)pc.y; col[a4 + 2] = (int32_t)pc.z; col[a4 + 3] = (int32_t)pc.w;
                 const float sc2 = 2.0f * inv_batch;
                 w2[a4] = sc2 * __uint_as_float(pw.x); w2[a4 + 1] = sc2 * __uint_as_float(pw.y);

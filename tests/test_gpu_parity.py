@@ -104,7 +104,7 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(plan.c_uniq_slot.cpu().numpy()[:nu_c + 1], want["c_uniq_slot"])
     np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
-    # per-chunk records {id, n, id's position, flag | chunks behind | partner | w | y} (small plans carry them from the build, big ones
+    # per-chunk records {id, n, id's position, flag | chunks behind | blocks of 8 pairs: partner, w, y} (small plans carry them from the build, big ones
     # get them when compacted): same content as the SoA arrays, padding slots weigh 0
     cpr = plan.compact(hip.lib)
     capP = (cap + 7) // 8 * 8
@@ -127,12 +127,15 @@ def test_plan_build_bit_exact(hip, B, V, cap):
             run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
             want_w3 = (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31)
             np.testing.assert_array_equal(rec[:, 3].view(np.uint32), want_w3)
+            # the pairs in blocks of 8: {partner[8] | w[8] | y[8]} per block
+            blocks = rec[:, 4:].reshape(nc, capP // 8, 3, 8)
             for j in (0, nc // 2, nc - 1):
                 sl = slice(starts[j], starts[j + 1])
-                np.testing.assert_array_equal(rec[j, 4:4 + n[j]], partner[sl])
-                np.testing.assert_array_equal(rec[j, 4 + capP:4 + capP + n[j]].view(np.float32), ww[sl])
-                np.testing.assert_array_equal(rec[j, 4 + 2 * capP:4 + 2 * capP + n[j]].view(np.float32), yy[sl])
-                assert (rec[j, 4 + capP + n[j]:4 + 2 * capP].view(np.float32) == 0).all()
+                np.testing.assert_array_equal(blocks[j, :, 0].reshape(-1)[:n[j]], partner[sl])
+                np.testing.assert_array_equal(blocks[j, :, 1].reshape(-1)[:n[j]].view(np.float32), ww[sl])
+                np.testing.assert_array_equal(blocks[j, :, 2].reshape(-1)[:n[j]].view(np.float32), yy[sl])
+                assert (blocks[j, :, 1].reshape(-1)[n[j]:].view(np.float32) == 0).all()
+                assert ((blocks[j, :, 0] >= 0) & (blocks[j, :, 0] < V)).all()          # padding slots hold valid ids
     assert (plan.r_crec is not None) == (B <= 4096)
     assert (cpr.r_crec is not None) == (4 * B >= cap * max(nc_r, nc_c))     # only reasonably filled chunks
     # compacted copy describes the same index

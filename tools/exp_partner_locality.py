@@ -41,5 +41,5 @@ for M in (65536, 8192, 1024):
         capP = (p.chunk_cap + 7) // 8 * 8
         rd = 4 + 3 * capP
         for rec, n in ((p.r_crec, p.host_counts[0]), (p.c_crec, p.host_counts[2])):
-            rec[:n * rd].view(n, rd)[:, 4:4 + capP] %= M
+            rec[:n * rd].view(n, rd)[:, 4:].reshape(n, capP // 8, 3, 8)[:, :, 0] %= M       # the partner ids of every block
     timeit("partners folded into [0, %d)" % M)
