@@ -388,6 +388,12 @@ class RowShardedStepper:
         for _, fn in self.phases():
             fn(plan)
 
+    def finish_async(self):
+        """Waits for the collective a phase started (for callers that time the phases one by one)."""
+        if self._gather is not None:
+            self._gather.wait()
+            self._gather = None
+
     def step_many(self, plans):
         ph = self.phases()
         for plan in plans:
@@ -517,6 +523,12 @@ class ShardedStepper:
     def step(self, i: int):
         for _, fn in self.phases():
             fn(i)
+
+    def finish_async(self):
+        """Waits for the collective a phase started (for callers that time the phases one by one)."""
+        if self._push is not None:
+            self._push.wait()
+            self._push = None
 
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
