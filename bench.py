@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--optimizer", default="Adagrad", choices=["Adagrad", "Adam"],
                     help="Adam = Keras-legacy dense-decay Adam (config 1 of BASELINE.json), single GPU only")
     ap.add_argument("--learning-rate", type=float, default=0.05)
+    ap.add_argument("--collectives", action="store_true",
+                    help="with --row-sharded / --force-dense on one GPU: issue every collective through RCCL although there is one rank")
     ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table")
     ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
     ap.add_argument("--build-ahead", type=int, default=1,
@@ -309,7 +311,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     t0 = time.perf_counter()
     stepper = None
     if mode == "sharded":
-        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist)
+        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives)
         handles = [stepper.add_batch(*bt, cap) for bt in batches]
         plans = [stepper.batches[h]["plan"] for h in handles]
     else:
@@ -324,10 +326,10 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     u_col = sum(c[3] for c in counts) / nb
     chunks = sum(c[0] + c[2] for c in counts) / nb
     if mode == "rowsharded":
-        stepper = RowShardedStepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange)
+        stepper = RowShardedStepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange, collectives=ctx.args.collectives)
         stepper.prepare(plans)
     elif mode == "dp":
-        stepper = Stepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange)
+        stepper = Stepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange, collectives=ctx.args.collectives)
         if world == 1:
             stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
         stepper.prepare(plans)

@@ -192,9 +192,12 @@ class Stepper:
     lists (Adagrad); "auto" = rows when `prepare(plans)` finds the ranks' lists together shorter than the dense
     buffer, else dense."""
 
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None, exchange="auto"):
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None, exchange="auto",
+                 collectives=False):
+        """collectives: go through the transport even with one rank (tests: RCCL is really called on a one-GPU box)."""
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
-        if self.world > 1 and dist is None:
+        self._multi = self.world > 1 or bool(collectives)
+        if self._multi and dist is None:
             raise ValueError("world > 1 needs an initialised torch.distributed module")
         if exchange not in ("auto", "dense", "rows"):
             raise ValueError("exchange must be auto, dense or rows")
@@ -203,7 +206,7 @@ class Stepper:
         self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
-        self.dense = self.world > 1 or tables.optimizer != "Adagrad"
+        self.dense = self._multi or tables.optimizer != "Adagrad"
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
@@ -213,12 +216,12 @@ class Stepper:
     def prepare(self, plans, force_world=None):
         """Static stream: agree (collectively) on the exchange from the id counts of every rank's resident plans."""
         world = self.world if force_world is None else force_world
-        if self.tables.optimizer != "Adagrad" or self.exchange == "dense" or (world == 1 and self.exchange != "rows"):
+        if self.tables.optimizer != "Adagrad" or self.exchange == "dense" or (world == 1 and not self._multi and self.exchange != "rows"):
             return
         if self.G is None:
             self.G, self.dense = self.backend.dense_grad_buffer(self.tables), True
         most = max(sum(self.backend.id_counts(p)) for p in plans)
-        if self.world > 1:
+        if self._multi:
             t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             most = int(t.item())
@@ -237,14 +240,14 @@ class Stepper:
         if self.rows:
             ph = [("passes", lambda p: b.passes_packing(p, t, h, self.bufs["send"])),
                   ("pack_grad", lambda p: b.pack_rest(p, t, h, self.bufs["send"]))]
-            if self.world > 1:
+            if self._multi:
                 ph.append(("all_gather", lambda p: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"])))
             else:
                 ph.append(("all_gather", lambda p: self.bufs["recv"][0].copy_(self.bufs["send"])))
             ph.append(("combine_apply", lambda p: b.apply_gathered(self.bufs, self.world, t, h, self.G, self.loss_out)))
             return ph
         ph = [("passes", lambda p: b.passes(p, t, h)), ("dense_grad", lambda p: b.dense_grad(p, t, h, self.G))]
-        if self.world > 1:
+        if self._multi:
             ph.append(("all_reduce", lambda p: self.dist.all_reduce(self.G)))     # sum over ranks; the tail carries the loss partials
         ph.append(("dense_apply", lambda p: b.apply_dense(t, h, self.G, self.loss_out)))
         return ph
@@ -257,7 +260,7 @@ class Stepper:
         """Several consecutive steps; on one GPU they are issued by one C call."""
         if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
             self.backend.steps_sparse_adagrad(plans, self.tables, self.hyper, self.loss_out)
-        elif (self.world == 1 and self.tables.optimizer == "Adam" and not self.rows and hasattr(self.backend, "steps_dense_adam")):
+        elif (not self._multi and self.tables.optimizer == "Adam" and not self.rows and hasattr(self.backend, "steps_dense_adam")):
             self.backend.steps_dense_adam(plans, self.tables, self.hyper, self.G, self.loss_out)
         else:
             ph = self.phases()
@@ -316,12 +319,14 @@ class RowShardedStepper:
     With inv_batch = 1 / (world * B) the result equals a single-GPU step on the union of the ranks'
     batches (tests/test_dp_gloo.py).  On one rank nothing is exchanged and the step is the plain sparse one."""
 
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, dist, exchange="auto"):
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, dist, exchange="auto",
+                 collectives=False):
         if tables.optimizer != "Adagrad":
             raise ValueError("the row-sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
         if exchange not in ("auto", "dense", "rows"):
             raise ValueError("exchange must be auto, dense or rows")
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
+        self._multi = self.world > 1 or bool(collectives)      # collectives: the transport even with one rank (tests)
         gb = batch_size * self.world
         self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
@@ -329,13 +334,13 @@ class RowShardedStepper:
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials over the ranks
         self._gather = None                     # the lists' all-gather while it is in flight
-        self.G = backend.dense_grad_buffer(tables) if self.world > 1 else None
+        self.G = backend.dense_grad_buffer(tables) if self._multi else None
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(backend.col_half(tables, self.G).numel()) if self.G is not None else 0
 
     def prepare(self, plans):
         """Static stream: agree (collectively) on the col-side exchange from the col id counts of all resident plans."""
-        if self.world == 1 or self.exchange == "dense":
+        if not self._multi or self.exchange == "dense":
             return
         most = max(self.backend.id_counts(p)[1] for p in plans)
         t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
@@ -349,7 +354,7 @@ class RowShardedStepper:
 
     def phases(self):
         b, t = self.backend, self.tables
-        if self.world == 1:
+        if not self._multi:
             return [("step", lambda p: b.step_sparse_adagrad(p, t, self.hyper, self.loss_out))]
         # the col pass first (it gathers the old rows of R), then the whole row side, applied in place by its pass where a
         # lane group holds an id completely: R, br are local, nothing else reads them in this step
@@ -422,10 +427,11 @@ class ShardedStepper:
     union of the ranks' batches.  The stream is static: `add_batch` (collective) prepares a batch once — the fetch
     lists, what this rank serves, the dedup index on the renumbered ids — and `step` replays it."""
 
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, rank: int, dist):
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, rank: int, dist, collectives=False):
         if tables.optimizer != "Adagrad":
             raise ValueError("the sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
         self.backend, self.tables, self.world, self.rank, self.dist = backend, tables, int(world), int(rank), dist
+        self._multi = self.world > 1 or bool(collectives)      # collectives: the transport even with one rank (tests)
         gb = batch_size * self.world
         self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
@@ -449,13 +455,13 @@ class ShardedStepper:
         want = torch.bincount(owner, minlength=W)
         req = (uc[order] // W).to(torch.int32).contiguous()
         serve = torch.empty_like(want)
-        if W > 1:
+        if self._multi:
             dist.all_to_all_single(serve, want)
         else:
             serve.copy_(want)
         want_l, serve_l = [int(x) for x in want.tolist()], [int(x) for x in serve.tolist()]
         serve_idx = torch.empty(sum(serve_l), dtype=torch.int32, device=req.device)
-        if W > 1:
+        if self._multi:
             dist.all_to_all_single(serve_idx, req, serve_l, want_l)
         else:
             serve_idx.copy_(req)
@@ -479,7 +485,7 @@ class ShardedStepper:
         f, bt = self.bufs, self.batches
 
         def a2a(out, inp, out_split, in_split):
-            if W > 1:
+            if self._multi:
                 dist.all_to_all_single(out, inp, out_split, in_split)
             else:
                 out.copy_(inp)
@@ -493,7 +499,7 @@ class ShardedStepper:
             # started, not awaited: the row side below runs while the gradients travel (the collective waits for what
             # this stream has enqueued so far — the packed list is complete — and runs on the transport's own stream)
             n, ns = bt[i]["n"], bt[i]["ns"]
-            if W > 1:
+            if self._multi:
                 self._push = dist.all_to_all_single(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"], bt[i]["want"],
                                                     async_op=True)
             else:
@@ -505,7 +511,7 @@ class ShardedStepper:
                 self._push = None
             # the loss partials come from the row pass, which ran after the list left: handed to the owners' apply apart
             b.loss_partials(bt[i]["plan"], self.view, self.tail)
-            if W > 1:
+            if self._multi:
                 dist.all_reduce(self.tail)
 
         return [("serve_rows", lambda i: b.gather_rows(t, bt[i]["serve_idx"], f["send_rows"], f["send_bias"])),

@@ -126,6 +126,63 @@ def test_data_parallel_form_on_one_gpu_matches_sparse_step(hip):
         dist.destroy_process_group()
 
 
+def test_exchange_forms_through_rccl_with_one_rank(hip):
+    """Every collective of the multi-GPU forms issued through RCCL on this one GPU (a process group of one rank,
+    `collectives=True`): the all-gather of packed lists (data parallel, and row-sharded started asynchronously), the
+    all-to-alls with split sizes and the asynchronous push of the fully sharded form, the 4-float all-reduces.  Each
+    form must equal the plain single-GPU step on the same batches."""
+    import os
+    import torch.distributed as dist
+    from helpers import make_batch, tables_from_oracle, to_dev
+    from trainer.hip_api import DeviceTables
+    from trainer.stepper import HipBackend, RowShardedStepper, ShardedStepper, Stepper
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        B, V, d, steps = 6000, 700, 64, 4
+        backend = HipBackend("cuda:0")
+        t = ref.Tables(V, d, "Adagrad", dtype=np.float32, seed=4).astype(np.float64)
+        kw = dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05)
+        batches = [to_dev(*make_batch(40 + s, B, V)) for s in range(steps)]
+        plans = [backend.build_plan(*bt, V, 0).compact(hip.lib, d) for bt in batches]
+        plain_t = tables_from_oracle(t, DeviceTables)
+        plain = Stepper(backend, plain_t, kw, B)
+        runs = {}
+        tabs = tables_from_oracle(t, DeviceTables)
+        st = Stepper(backend, tabs, kw, B, world=1, dist=dist, exchange="rows", collectives=True)
+        st.prepare(plans)
+        assert st.rows and "all_gather" in dict(st.phases())
+        runs["data parallel, rows"] = (tabs, st, plans)
+        tabs = tables_from_oracle(t, DeviceTables)
+        st = RowShardedStepper(backend, tabs, kw, B, 1, dist, exchange="rows", collectives=True)
+        st.prepare(plans)
+        assert st.rows and "loss_tail" in dict(st.phases())
+        runs["row-sharded, rows"] = (tabs, st, plans)
+        tabs = tables_from_oracle(t, DeviceTables)
+        st = RowShardedStepper(backend, tabs, kw, B, 1, dist, exchange="dense", collectives=True)
+        st.prepare(plans)
+        assert not st.rows and "all_reduce" in dict(st.phases())
+        runs["row-sharded, dense"] = (tabs, st, plans)
+        tabs = tables_from_oracle(t, DeviceTables)
+        st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True)
+        handles = [st.add_batch(*bt) for bt in batches]
+        runs["both tables sharded"] = (tabs, st, handles)
+        for s in range(steps):
+            plain.step(plans[s])
+            for tabs, st, items in runs.values():
+                st.step(items[s])
+        want = plain.read_loss()
+        for name, (tabs, st, _) in runs.items():
+            for n in ("R", "C", "br", "bc"):
+                torch.testing.assert_close(getattr(tabs, n), getattr(plain_t, n), rtol=2e-5, atol=2e-6, msg=lambda m: name + " " + n + ": " + m)
+            torch.testing.assert_close(tabs.scalars, plain_t.scalars, rtol=2e-5, atol=2e-6)
+            assert tabs.global_step == plain_t.global_step == steps, name
+            got = st.read_loss()
+            assert abs(got["loss"] - want["loss"]) <= 2e-5 * abs(want["loss"]), (name, got, want)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_whole_pipeline_recovers_planted_topics(hip, tmp_path):
     """corpus -> trainer.text8 (GPU co-occurrence) -> trainer.estimator (CLI) -> PREDICT.  The corpus is built from
     8 topics of 30 words; sentences stay inside one topic, so a word's nearest neighbours by cosine over the

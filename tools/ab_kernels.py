@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--step-form", type=int, default=0)
     ap.add_argument("--only", default="", help="comma-separated subset of rowpass,colpass,passes,apply,step")
     ap.add_argument("--twin", action="store_true", help="twinned row table (step form 4 under auto)")
+    ap.add_argument("--batches", type=int, default=8, help="resident batches cycled through (1: the plan stays cache-warm)")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=40)
     args = ap.parse_args()
@@ -32,7 +33,7 @@ def main():
     hip = hips[0]
     wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], args.batch_size
-    nb = min(8, wl["row"].numel() // B)
+    nb = min(args.batches, wl["row"].numel() // B)
     tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
     if args.twin:
         tables.enable_twin()
