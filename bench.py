@@ -634,7 +634,12 @@ def main(argv=None):
                   ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
                   # the headline workload at the reference's batch size and at (nearly) the whole stream per step
                   ("text8_d64_bs1024", dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
-                  ("text8_d64_bs1048576", dict(workload="text8_d64", B=1048576, steps=100, warmup=10))]
+                  ("text8_d64_bs1048576", dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
+                  # the headline with the dedup index (the reference's per-step Unique + segment-sum) rebuilt INSIDE every
+                  # timed step instead of once at load: one build at a time, and six in flight on their own streams
+                  ("text8_d64_index_rebuilt_every_step", dict(workload="text8_d64", B=131072, steps=100, warmup=10, dynamic=True)),
+                  ("text8_d64_index_rebuilt_every_step_6_in_flight", dict(workload="text8_d64", B=131072, steps=100, warmup=10,
+                                                                          dynamic=True, build_ahead=6))]
                  if world == 1 else
                  # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), the same workload
                  # with both tables sharded (traffic follows the batch, not the vocabulary), and config 5
