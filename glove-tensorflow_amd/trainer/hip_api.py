@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 4
+GLOVE_ABI_VERSION = 5
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
