@@ -41,9 +41,9 @@ def main():
     loss = torch.zeros(4, device=dev)
     configs = []
     for cap in [int(c) for c in args.caps.split(",")]:
-        plans = [hip.build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
-                                chunk_cap=cap, compact=True, d=(d + 3) // 4 * 4) for b in range(nb)]
-        for v in range(len(hips)):
+        for v in range(len(hips)):       # every build indexes the batches itself (the plan's record layout is the library's own)
+            plans = [hips[v].build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
+                                        chunk_cap=cap, compact=True, d=(d + 3) // 4 * 4) for b in range(nb)]
             configs.append((cap, v, plans))
     ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
     res = {(c, v): {"rowpass": [], "colpass": [], "passes": [], "apply": [], "step": []} for c, v, _ in configs}
