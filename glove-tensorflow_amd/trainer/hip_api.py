@@ -16,7 +16,7 @@ import torch
 logger = logging.getLogger(__name__)
 
 PKG_DIR = Path(__file__).resolve().parent.parent
-LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
+LIB_PATH = Path(os.environ.get("GLOVE_LIB") or PKG_DIR / "lib" / "libglove_hip.so")     # GLOVE_LIB: experiment builds (make variant)
 
 GLOVE_ABI_VERSION = 5
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
