@@ -8,15 +8,18 @@ together with their dedup index (DESIGN.md "Data layout"; the index of a static 
 `--dynamic` puts the index build of every batch inside the timed region instead).
 
 N = 1: the sparse Adagrad step (fused forward+gradient pass kernel(s) + apply kernel; glove_step_adagrad_f32 picks the
-form).  The headline is BASELINE.json's configs[1] (text8, d = 64, Adagrad); unless `--single` is given the same JSON
-line also carries `configs`: the HBM-bound workloads (V = 50 k and V = 400 k at d = 300, V = 2 M at d = 128) and the
-reference's default shape (Keras-legacy Adam, batch 1,024), each with its own roofline.
+form).  The headline is the workload BASELINE.json's metric is quoted on at 1, 2, 4 and 8 GPUs — config 4, synthetic
+Zipf V = 400 k, d = 300 — as the one-GPU shard of its 200 M nonzeros (25 M, batches of 1 M): the configuration where
+"achieved HBM GB/s vs peak" is about HBM (text8's tables live in the caches).  Unless `--single` is given the same JSON
+line also carries `configs`: text8 d = 64 (BASELINE configs[1]: static index, index rebuilt every step, the
+reference's batch size, Keras-legacy Adam), V = 50 k at d = 300 and V = 2 M at d = 128, each with its own roofline —
+as far as the wall-clock budget (`--budget-seconds`) goes; what did not fit is named in `configs_skipped`.
 
 N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child process; under a launcher it
-is a rank).  Every rank owns its own shard of nonzeros; per step the ranks exchange either the dense gradient buffer
-(all-reduce) or their packed lists of touched rows (all-gather), whichever is the shorter payload for the resident
-batches, and apply the identical update (global batch = N * B, weak scaling).  `configs` then carries the V = 400 k
-data-parallel run and the V = 2 M run with both tables sharded (all-to-all of the touched col rows).
+is a rank).  Every rank owns its own shard of nonzeros (global batch = N * B, weak scaling).  The headline is config 4
+with both tables sharded (touched col rows fetched from / returned to their owners by all-to-all: the exchange follows
+the batch, not the vocabulary); `configs` carries config 4 data parallel as BASELINE.json words it (dense-gradient
+all-reduce or touched-rows all-gather, whichever is the shorter payload) and config 5 sharded.
 
 Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is measured live with HIP events on the
 launch stream in a second, instrumented pass over the same batches; `cpu_baseline` times the C port of the oracle
@@ -34,6 +37,7 @@ import time
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent
+T_START = time.perf_counter()
 sys.path.insert(0, str(REPO))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -42,6 +46,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
 HBM_STREAM_GBS = 6290.0        # measured float4-copy ceiling of the same guide (BASELINE.md §3 asks for both)
 WORKLOADS = ["text8_d64", "text8_v50k_d300", "zipf_v400k_d300", "zipf_v2m_d128"]
+DEFAULT_BATCH = {"text8_d64": 131072, "text8_v50k_d300": 131072, "zipf_v400k_d300": 1048576, "zipf_v2m_d128": 1048576}
 DATA_NOTE = {"text8_d64": "synthetic (text8-shaped Poisson model of the reference's data prep: 17 M-token Zipf corpus, "
                           "window 5, count >= 10; no text8 on disk)",
              "text8_v50k_d300": "synthetic (Zipf(1.0) ids over V = 50,000, SURVEY.md §8d generator)",
@@ -54,13 +59,13 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="text8_d64", choices=WORKLOADS)
+    ap.add_argument("--workload", default="zipf_v400k_d300", choices=WORKLOADS)
     ap.add_argument("--row-sharded", action="store_true",
                     help="BASELINE config 5: both tables sharded by id %% N, nonzeros routed to row owners (all-to-all at "
                          "load), touched col rows fetched from / returned to their owners every step")
     ap.add_argument("--cols-replicated", action="store_true",
                     help="with --row-sharded: keep the col table replicated (RowShardedStepper: col side data parallel)")
-    ap.add_argument("--batch-size", type=int, default=131072)
+    ap.add_argument("--batch-size", type=int, default=0, help="0 = the workload's own (DEFAULT_BATCH)")
     ap.add_argument("--chunk-cap", type=int, default=0, help="0 = auto (hip_api.auto_chunk_cap)")
     ap.add_argument("--force-dense", action="store_true", help="run the data-parallel form also on one GPU")
     ap.add_argument("--exchange", default="auto", choices=["auto", "dense", "rows"],
@@ -77,8 +82,11 @@ def parse(argv=None):
                          "input pipeline prefetches batches; 1 = build and step strictly alternate on one stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-time budget of all CPU legs together")
-    ap.add_argument("--max-batches", type=int, default=64, help="resident batches to cycle through")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of all CPU legs together")
+    ap.add_argument("--budget-seconds", type=float, default=300.0,
+                    help="wall-clock budget of the whole run: a configs[] entry is only started while the time spent so "
+                         "far leaves room for it; the ones left out are listed in configs_skipped")
+    ap.add_argument("--max-batches", type=int, default=16, help="resident batches to cycle through")
     ap.add_argument("--single", action="store_true", help="only the named workload (no configs[] array)")
     ap.add_argument("--with-configs", action="store_true", help="the configs[] array also under --rehearse-on-one-gpu")
     ap.add_argument("--min-timed-ms", type=float, default=20.0,
@@ -621,42 +629,55 @@ def main(argv=None):
     ctx = Ctx(args, world, rank, dev, dist, hip)
     common = dict(lr=args.learning_rate, chunk_cap=args.chunk_cap, step_form=args.step_form, exchange=args.exchange,
                   no_graph=args.no_graph, max_batches=args.max_batches, min_timed_ms=args.min_timed_ms)
-    out = run_config(ctx, args.workload, args.batch_size, args.optimizer, mode, args.steps, args.warmup,
+    B_head = args.batch_size or DEFAULT_BATCH[args.workload]
+    big = args.workload in ("zipf_v400k_d300", "zipf_v2m_d128")
+    if mode == "auto" and world > 1 and big and args.exchange == "auto":
+        mode = "sharded"        # the form whose exchange follows the batch, not the vocabulary (DESIGN.md "Multi-GPU")
+    out = run_config(ctx, args.workload, B_head, args.optimizer, mode, args.steps, args.warmup,
                      dynamic=args.dynamic, build_ahead=args.build_ahead, **common)
-    plain = not (args.single or args.dynamic or args.optimizer != "Adagrad" or mode != "auto" or args.step_form or
-                 args.chunk_cap or (args.rehearse_on_one_gpu and not args.with_configs))
+    plain = not (args.single or args.dynamic or args.optimizer != "Adagrad" or args.row_sharded or args.force_dense or
+                 args.step_form or args.chunk_cap or args.batch_size or args.workload != "zipf_v400k_d300" or
+                 (args.rehearse_on_one_gpu and not args.with_configs))
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and mode == "auto":
+        out["cpu_baseline"] = cpu_baseline(ctx, ctx.workload(args.workload), B_head, args.learning_rate, args.cpu_seconds)
     if plain:
-        # the other configurations of BASELINE.json / BASELINE.md §3 in the same line: where HBM is the bound
+        # the other configurations of BASELINE.json / BASELINE.md §3 in the same line, the HBM-bound ones last (the tail of
+        # a long line is what a log keeps).  (name, estimated seconds incl. load, run_config arguments)
         extra = dict(lr=args.learning_rate, max_batches=8, min_timed_ms=args.min_timed_ms, exchange=args.exchange)
-        specs = ([("c3_text8_v50k_d300", dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
-                  ("c4_zipf_v400k_d300_one_gpu_shard", dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4)),
-                  ("c5_zipf_v2m_d128_one_gpu_shard", dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4)),
-                  ("c1_shape_adam_bs1024", dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
-                  # the headline workload at the reference's batch size and at (nearly) the whole stream per step
-                  ("text8_d64_bs1024", dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
-                  ("text8_d64_bs1048576", dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
-                  # the headline with the dedup index (the reference's per-step Unique + segment-sum) rebuilt INSIDE every
-                  # timed step instead of once at load: one build at a time, and six in flight on their own streams
-                  ("text8_d64_index_rebuilt_every_step", dict(workload="text8_d64", B=131072, steps=100, warmup=10, dynamic=True)),
-                  ("text8_d64_index_rebuilt_every_step_6_in_flight", dict(workload="text8_d64", B=131072, steps=100, warmup=10,
-                                                                          dynamic=True, build_ahead=6))]
+        specs = ([("c1_shape_adam_bs1024", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
+                  # BASELINE configs[1] at the reference's batch size and at (nearly) the whole stream per step
+                  ("text8_d64_bs1024", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
+                  ("text8_d64_bs1048576", 4, dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
+                  # the dedup index (the reference's per-step Unique + segment-sum) rebuilt INSIDE every timed step instead
+                  # of once at load — what a reshuffled epoch costs: one build at a time, and six in flight on their own streams
+                  ("text8_d64_index_rebuilt_every_step", 5, dict(workload="text8_d64", B=131072, steps=100, warmup=10, dynamic=True)),
+                  ("text8_d64_index_rebuilt_every_step_6_in_flight", 5, dict(workload="text8_d64", B=131072, steps=100, warmup=10,
+                                                                             dynamic=True, build_ahead=6)),
+                  ("c2_text8_d64", 4, dict(workload="text8_d64", B=131072, steps=200, warmup=20, max_batches=64)),
+                  ("c3_text8_v50k_d300", 6, dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
+                  ("c5_zipf_v2m_d128_one_gpu_shard", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4))]
                  if world == 1 else
-                 # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), the same workload
-                 # with both tables sharded (traffic follows the batch, not the vocabulary), and config 5
-                 [("c4_zipf_v400k_d300_data_parallel", dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3)),
-                  ("c4_zipf_v400k_d300_both_tables_sharded", dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="sharded")),
-                  ("c5_zipf_v2m_d128_both_tables_sharded", dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
-        configs = []
-        for name, spec in specs:
+                 # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), and config 5
+                 [("c4_zipf_v400k_d300_data_parallel", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="dp")),
+                  ("c5_zipf_v2m_d128_both_tables_sharded", 60, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
+        configs, skipped = [], []
+        for name, est, spec in specs:
+            # the decision is rank 0's (the ranks' clocks differ) and collective
+            go = torch.tensor([1 if time.perf_counter() - T_START + est <= args.budget_seconds else 0], device=dev)
+            if world > 1:
+                dist.broadcast(go, src=0)
+            if not int(go.item()):
+                skipped.append(name)
+                continue
             kw = dict(extra)
             kw.update({k: v for k, v in spec.items() if k not in ("workload", "B")})
             r = brief(run_config(ctx, spec["workload"], spec["B"], **kw))
             r["name"] = name
             configs.append(r)
+        out["configs_skipped"] = skipped
         out["configs"] = configs
+    out["wall_seconds"] = time.perf_counter() - T_START
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and mode == "auto":
-            out["cpu_baseline"] = cpu_baseline(ctx, ctx.workload(args.workload), args.batch_size, args.learning_rate, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

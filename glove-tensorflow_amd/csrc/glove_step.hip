@@ -68,49 +68,6 @@ __device__ inline void store_row(float *table, size_t row_index, int d4, int lg,
     }
 }
 
-// Streaming variants (experiment switch GLOVE_STREAM, default 0 = plain): rows that are touched once per step — own
-// rows, accumulators, partial rows — marked so that they do not displace the partner rows the gathers want to find in L2.
-//   1: nontemporal builtins (global_load/store ... nt)      2: stores with sc1 (the line is dropped from L2), loads nt
-#ifndef GLOVE_STREAM
-#define GLOVE_STREAM 0
-#endif
-template <int LPR, int NV>
-__device__ inline void load_row_stream(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
-{
-#if GLOVE_STREAM == 0
-    load_row<LPR, NV>(dst, table, id, d4, lg);
-#else
-    const f4 *p = reinterpret_cast<const f4 *>(table) + (size_t)id * d4;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int i4 = lg + k * LPR;
-        const f4 v = __builtin_nontemporal_load(&p[i4 < d4 ? i4 : d4 - 1]);
-        dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
-    }
-#endif
-}
-
-template <int LPR, int NV>
-__device__ inline void store_row_stream(float *table, size_t row_index, int d4, int lg, const f4 (&src)[NV])
-{
-#if GLOVE_STREAM == 0
-    store_row<LPR, NV>(table, row_index, d4, lg, src);
-#else
-    f4 *p = reinterpret_cast<f4 *>(table) + row_index * d4;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int i4 = lg + k * LPR;
-        if (i4 < d4) {
-#if GLOVE_STREAM == 1
-            __builtin_nontemporal_store(src[k], &p[i4]);
-#else
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&p[i4]), "v"(src[k]) : "memory");
-#endif
-        }
-    }
-#endif
-}
-
 // ---- optimizer arithmetic (Keras-legacy forms) -------------------------
 // x / (sqrt(a) + eps) uses the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE
 // expansions: ~3 ulp on the update term, far inside the 1e-5 parity tolerance, and a third of the
@@ -244,31 +201,15 @@ struct StepConsts {
 };
 
 // FUSE == 1: the accumulator row a whole run is going to need is requested when the run starts (it arrives under the
-// partner-row trips).  1 = it waits in LDS, written there by the load itself (global_load_lds_dwordx4: no VGPRs held
-// across the trips; the image is [k][lane of the wave], which is the order that instruction writes); 0 = in registers
-// (NV float4 more per lane: the d = 300 shape then spills at 3 waves per SIMD).
-#ifndef GLOVE_ACC_IN_LDS
-#define GLOVE_ACC_IN_LDS 1
-#endif
-// Experiment switch (never on in the shipped build): the first GLOVE_HOT_TILE rows of the partner table — the most frequent
-// tokens when ids are frequency ranks, as in a GloVe vocabulary — are staged in LDS by every workgroup of the classic
-// passes and partner gathers of those ids read LDS instead of L2.  DESIGN.md §3 has what it measured.
-#ifndef GLOVE_HOT_TILE
-#define GLOVE_HOT_TILE 0
-#endif
-// 1 = the run-merged passes over wide rows read a chunk record in two steps (first block, then the rest if the chunk is longer)
-#ifndef GLOVE_REC_TWO_PHASE
-#define GLOVE_REC_TWO_PHASE 1
-#endif
-#ifndef GLOVE_FUSE_WAVES
-#define GLOVE_FUSE_WAVES 3       // experiment switch; 4 (128 VGPRs) spills 140-188 B per lane and runs twice as long
-#endif
+// partner-row trips) and waits in LDS, written there by the load itself (global_load_lds_dwordx4: no VGPRs held across
+// the trips; the image is [k][lane of the wave], which is the order that instruction writes).  Kept in registers instead
+// (NV float4 more per lane) the d = 300 shape spills at 3 waves per SIMD (measured variants).
 // FUSE kernels keep the accumulator row of a run in registers as well: held to 3 waves per SIMD (168 VGPRs), which the
 // d = 300 shape misses by one register otherwise
 // FUSE: 0 classic schedule, 1 run-merged and applying (kFuseSlot / kFuseInPlace / kFuseTwin), 2 run-merged and packing
 // (kFusePack) — a build of its own: the apply code and its accumulator rows would cost the other their registers
 template <int LPR, int NV, bool FULL, bool REC, int FUSE>
-__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_WAVES : PassWaves<LPR>::value) void sidepass_kernel(
+__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
@@ -284,21 +225,13 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
     __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * (REC ? kRecStride : 3 * kFieldStride)];
     uint32_t(*fld)[3][kFieldStride] = reinterpret_cast<uint32_t(*)[3][kFieldStride]>(fld_raw);
     uint32_t *rec = fld_raw + grp_of(threadIdx.x, LPR) * kRecStride;
-    constexpr int kHot = (FUSE == 0 && LPR * NV <= 16) ? GLOVE_HOT_TILE : 0;     // rows of up to 256 B
-    constexpr int kHotStride = LPR * NV + 1;                    // float4 per staged row (+1: rows start on different banks)
-    __shared__ __attribute__((aligned(16))) f4 hot[kHot ? kHot * kHotStride : 1];
-    constexpr bool kPark = FUSE == 1 && GLOVE_ACC_IN_LDS != 0;
+    constexpr bool kPark = FUSE == 1;
     __shared__ __attribute__((aligned(16))) f4 park_raw[kPark ? (kBlock / 64) * NV * 64 : 1];
     f4 *park = park_raw + (kPark ? (threadIdx.x / 64) * NV * 64 : 0);       // this wave's image
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const bool is_row = (int)blockIdx.x < row_blocks;
     const PassSide &sd = is_row ? rowside : colside;
-    if (kHot) {
-        const f4 *src = reinterpret_cast<const f4 *>(sd.other);
-        for (int i = threadIdx.x; i < kHot * d4; i += kBlock) hot[(i / d4) * kHotStride + i % d4] = src[i];
-        __syncthreads();
-    }
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
     const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
     GLOVE_STAMP(0);
@@ -343,7 +276,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             const int rq = 1 + 3 * capP / 4;
             const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rq;
             uint4 *lrec = reinterpret_cast<uint4 *>(rec);
-            if (FUSE != 0 && GLOVE_REC_TWO_PHASE != 0 && NV >= 3) {
+            if (FUSE != 0 && NV >= 3) {
                 // run-merged passes over wide rows (bound by bytes): header + first block of 8 pairs (112 B, one round
                 // trip); a chunk of more pairs fetches its other blocks once the header has told how many (a second
                 // round trip for the long chunks only) — the padding up to the cap, 3/4 of a record on average, is
@@ -421,26 +354,24 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
 #pragma unroll
                 for (int k = 0; k < NV; ++k) acc[k] += kcn * r[k];
                 Gb += kc.kappa_b * cnt * bval;
-                if (kPark) {
-                    // every load of the run has been consumed by now, the parked row (requested before them) has landed
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // every load of the run has been consumed by now, the parked row (requested before them) has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) A[k] = park[k * 64 + (threadIdx.x & 63)];
-                }
+                for (int k = 0; k < NV; ++k) A[k] = park[k * 64 + (threadIdx.x & 63)];
 #pragma unroll
                 for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], acc[k], kc.lr, kc.eps);
-                store_row_stream<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
+                store_row<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
                 const bool to_slot = sd.fuse == kFuseSlot;
                 // in place: the row itself; twin: the copy that is NOT current (own_at is the current one)
                 const size_t out_at = sd.fuse == kFuseTwin ? (size_t)(own_at == cur_u ? cur_u + sd.own_twin : cur_u) : (size_t)cur_u;
-                store_row_stream<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
+                store_row<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
                 if (lg == 0) {
                     adagrad_elem(bval, Ab, Gb, kc.lr, kc.eps);
                     sd.S1b[cur_u] = Ab;
                     if (to_slot) sd.gb[run_first] = bval; else sd.own_bias_out[out_at] = bval;
                 }
             } else {
-                store_row_stream<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
+                store_row<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
                 if (lg == 0) {
                     sd.gb[run_first] = se;
                     if (sd.mark) sd.mark[cur_u] = 1.0f;
@@ -455,23 +386,19 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             run_pairs = 0;
             own_at = u;
             if (FUSE && sd.own_ver) own_at = u + (sd.own_ver[u] ? sd.own_twin : 0);     // the current copy of a twinned table
-            if (FUSE) load_row_stream<LPR, NV>(r, sd.own, own_at, d4, lg); else load_row<LPR, NV>(r, sd.own, u, d4, lg);
+            if (FUSE) load_row<LPR, NV>(r, sd.own, own_at, d4, lg); else load_row<LPR, NV>(r, sd.own, u, d4, lg);
             own_b = sd.own_bias[own_at];
             bg = own_b + g;
             // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
             run_whole = FUSE && sd.fuse != kFuseNone && (hw >> 31) != 0 && j + (int)(hw & 0x7fffffffu) < j_end;
             if (FUSE == 1 && run_whole) {   // requested with the own row: arrives under the partner-row trips
-                if (kPark) {
-                    const f4 *src = reinterpret_cast<const f4 *>(sd.S1) + (size_t)u * d4;
+                const f4 *src = reinterpret_cast<const f4 *>(sd.S1) + (size_t)u * d4;
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        const int i4 = lg + k * LPR;
-                        // destination: the wave-uniform base + lane * 16 B (the hardware adds the lane part)
-                        if (FULL || i4 < d4)
-                            __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 0);
-                    }
-                } else {
-                    load_row_stream<LPR, NV>(A, sd.S1, u, d4, lg);
+                for (int k = 0; k < NV; ++k) {
+                    const int i4 = lg + k * LPR;
+                    // destination: the wave-uniform base + lane * 16 B (the hardware adds the lane part)
+                    if (FULL || i4 < d4)
+                        __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 0);
                 }
                 Ab = sd.S1b[u];
             }
@@ -504,12 +431,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? GLOVE_FUSE_
             float bcv[U];
 #pragma unroll
             for (int a = 0; a < U; ++a) {
-                if (kHot && col[a] < kHot) {
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) c[a][k] = (FULL || lg + k * LPR < d4) ? hot[col[a] * kHotStride + lg + k * LPR] : f4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
-                }
+                load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
                 // the partner bias enters the dot once, through lane 0 of the group (a masked 1-lane-per-group
                 // load instead of a 64-lane gather of the same 4 bytes), and the butterfly spreads it
                 bcv[a] = 0.f;
@@ -787,9 +709,9 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
             // reads the old ones; twin -> the other copy holds the new row: flip the version
             if (pre == kFuseSlot) {
                 f4 Wn[NV];
-                load_row_stream<LPR, NV>(Wn, sb.gp, sl0, d4, lg);
+                load_row<LPR, NV>(Wn, sb.gp, sl0, d4, lg);
                 const float bn = sb.gb[sl0];
-                store_row_stream<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
+                store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wn);
                 if (lg == 0) sb.bias[id] = bn;
             }
             if (pre == kFuseTwin && lg == 0) sb.ver[id] ^= 1;
@@ -1133,6 +1055,20 @@ __global__ __launch_bounds__(kBlock) void count_packed_kernel(PackedLists pls, D
         const bool is_row = (pl.side >= 0 ? pl.side : __float_as_int(x[2])) == 0;
         atomicAdd(dv.mark + (is_row ? 0 : dv.V_row) + id, 1);
     }
+}
+
+// More than eight lists and no summed tail from the caller: the loss partials of ALL headers are added up first, eight
+// lists per launch in list order, into four scratch floats (the reserved half of G_flat's tail).
+__global__ void sum_headers_kernel(PackedLists pls, float *__restrict__ acc4, int first)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!first) { t[0] = acc4[0]; t[1] = acc4[1]; t[2] = acc4[2]; t[3] = acc4[3]; }
+    for (int r = 0; r < pls.n; ++r) {
+        const float *h = pls.l[r].header;
+        if (h) { t[0] += h[2]; t[1] += h[3]; t[2] += h[4]; t[3] += h[5]; }
+    }
+    acc4[0] = t[0]; acc4[1] = t[1]; acc4[2] = t[2]; acc4[3] = t[3];
 }
 
 // A lane group walks entries gg, gg + TG, gg + 2 TG, ... (TG lane groups in the launch).  Looked up one entry at a time
@@ -1593,6 +1529,12 @@ using namespace glove;
 extern "C" {
 
 int glove_abi_version(void) { return GLOVE_ABI_VERSION; }
+
+// Every entry point but the twin form of the Adagrad step reads and writes rows 0 .. V_row-1 of a twinned row table: it first
+// brings the table back to that form (one small launch over V_row version bytes plus the rows whose second copy was
+// current; nothing without a twin).  A caller that mixes step forms, or steps and anything else, on one twinned table
+// therefore never reads a stale copy.
+static int plain_table(const glove_tables *t, void *stream) { return t && t->R_ver ? glove_canonicalize_f32(t, stream) : 0; }
 #ifdef GLOVE_STAMPS
 int glove_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
 #endif
@@ -1702,18 +1644,21 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
 int glove_passes_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                      void *stream)
 {
+    if (int rc = plain_table(t, stream)) return rc;
     return launch_passes(p, t, h, ws, ws_bytes, stream, 3);
 }
 
 int glove_rowpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                       void *stream)
 {
+    if (int rc = plain_table(t, stream)) return rc;
     return launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, true);
 }
 
 int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                       void *stream)
 {
+    if (int rc = plain_table(t, stream)) return rc;
     return launch_passes(p, t, h, ws, ws_bytes, stream, 2);
 }
 
@@ -1767,11 +1712,12 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
 int glove_apply_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
                             size_t ws_bytes, float *loss_out, void *stream)
 {
+    if (int rc = plain_table(t, stream)) return rc;
     return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseNone, kFuseNone);
 }
 
-int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
-                         float *G_flat, void *stream)
+static int launch_dense_grad(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                             float *G_flat, void *stream)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!G_flat) return GLOVE_E_BADARG;
@@ -1795,6 +1741,13 @@ int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();
+}
+
+int glove_dense_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                         float *G_flat, void *stream)
+{
+    if (int rc = plain_table(t, stream)) return rc;
+    return launch_dense_grad(p, t, h, ws, ws_bytes, G_flat, stream);
 }
 
 static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_flat, bool adam, DenseSegs &segs,
@@ -1822,6 +1775,7 @@ static int dense_common(const glove_tables *t, const glove_hyper *h, float *G_fl
 int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
 {
     DenseSegs segs; float *tail; int nbx, sides;
+    if (int rc = plain_table(t, stream)) return rc;
     if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx, sides)) return rc;
     const StepConsts k = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
@@ -1833,6 +1787,7 @@ int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *
 int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat, float *loss_out, void *stream)
 {
     DenseSegs segs; float *tail; int nbx, sides;
+    if (int rc = plain_table(t, stream)) return rc;
     if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx, sides)) return rc;
     if (!(h->beta1 > 0.0 && h->beta1 < 1.0 && h->beta2 > 0.0 && h->beta2 < 1.0)) return GLOVE_E_BADARG;
     const StepConsts k = make_consts(t, h);
@@ -1849,6 +1804,7 @@ int glove_pack_grad_f32(const glove_plan *p, const glove_tables *t, const glove_
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!packed) return GLOVE_E_BADARG;
+    if (int rc = plain_table(t, stream)) return rc;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     IdWork wk = id_work(p);
@@ -1883,6 +1839,7 @@ int glove_passes_packing_f32(const glove_plan *p, const glove_tables *t, const g
                              float *packed, int64_t capacity_entries, void *stream)
 {
     if (!p || !h) return GLOVE_E_BADARG;
+    if (int rc = plain_table(t, stream)) return rc;
     const int sides = sides_of(h);
     if (!packing_ok(p)) return launch_passes(p, t, h, ws, ws_bytes, stream, sides);
     if (!packed) return GLOVE_E_BADARG;
@@ -1899,6 +1856,7 @@ int glove_pack_rest_f32(const glove_plan *p, const glove_tables *t, const glove_
     if (!packing_ok(p)) return glove_pack_grad_f32(p, t, h, ws, ws_bytes, packed, capacity_entries, stream);
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!packed) return GLOVE_E_BADARG;
+    if (int rc = plain_table(t, stream)) return rc;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
     if (w.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
     IdWork wk = id_work(p);
@@ -2004,6 +1962,7 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
     if (int rc = packed_common(t, G_flat, mark, dv)) return rc;
     if (!h || !lists || n_lists < 1 || capacity_entries < 0) return GLOVE_E_BADARG;
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    if (int rc = plain_table(t, stream)) return rc;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
     const StepConsts k = make_consts(t, h);
@@ -2011,9 +1970,21 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
     SideBufs cs = {nullptr, nullptr, nullptr, t->C, t->s1_C, t->bc, t->s1_bc, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     // the scalar work (global bias, loss) goes with the col side, like everywhere else; without an explicit tail it
-    // reads the headers of the first (up to eight) lists
+    // sums the lists' headers in list order
     const int do_scalars = (sides_of(h) & 2) ? 1 : 0;
-    if (!tail && n_lists > 8 && do_scalars) return GLOVE_E_BADARG;
+    float *scratch = nullptr;
+    if (!tail && n_lists > 8 && do_scalars) {
+        // a launch sees eight lists: sum the loss partials of all headers first (list order, so the sum is repeatable)
+        scratch = G_flat + grad_layout(v_row(t), t->V, t->d).tail + 4;
+        for (int32_t first = 0; first < n_lists; first += 8) {
+            PackedLists pls;
+            pls.n = n_lists - first < 8 ? n_lists - first : 8;
+            for (int i = 0; i < pls.n; ++i)
+                if (!to_list(lists + first + i, pls.l[i])) return GLOVE_E_BADARG;
+            hipLaunchKernelGGL(sum_headers_kernel, dim3(1), dim3(64), 0, st, pls, scratch, first == 0 ? 1 : 0);
+        }
+        tail = scratch;
+    }
     for (int32_t first = 0; first < n_lists; first += 8) {
         PackedLists pls;
         pls.n = n_lists - first < 8 ? n_lists - first : 8;
@@ -2030,6 +2001,10 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
                            d4, k, (int)first, tail, t->scalars, loss_out, scal)
         GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
+    }
+    if (scratch) {
+        hipError_t e = hipMemsetAsync(scratch, 0, 4 * sizeof(float), st);      // the tail is all zero between steps
+        if (e != hipSuccess) return (int)e;
     }
     return (int)hipGetLastError();
 }
@@ -2072,7 +2047,12 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
 int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                            float *loss_out, void *stream)
 {
-    switch (pick_step_form(p, t, h)) {
+    const int form = pick_step_form(p, t, h);
+    // only the twin form follows the version bytes of a twinned row table: every other form first brings it home
+    // (a step of another form behind a twin step would otherwise read and write copy 0 of rows whose current copy is the second)
+    if (form != GLOVE_STEP_FUSED_TWIN)
+        if (int rc = plain_table(t, stream)) return rc;
+    switch (form) {
     case GLOVE_STEP_FUSED_ONE_PASS:
         // both sides in one launch: neither table may change under the other side's gathers, so both put their
         // finished rows into the slots and the apply launch moves them
@@ -2096,16 +2076,15 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
     default:
         return GLOVE_E_BADARG;
     }
-    // (a twinned table must be canonical here: glove_canonicalize_f32)
-    if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
-    return glove_apply_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
+    if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
+    return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseNone, kFuseNone);
 }
 
 int glove_rowside_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                                    void *stream)
 {
     if (!p || !t || !h || sides_of(h) != 1) return GLOVE_E_BADARG;          // hyper.sides = 1: this is the row side's step
-    if (t->R_ver) return GLOVE_E_BADARG;                                  // plain tables only
+    if (int rc = plain_table(t, stream)) return rc;
     if (!p->r_crec || !p->c_crec) {
         // no chunk records: the row pass stores its partial rows, the apply launch does every row id
         if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1)) return rc;
@@ -2185,10 +2164,11 @@ int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_
 {
     // a batch that touches a minority of the rows (the reference's 1,024 pairs): two launches, no gradient buffer
     // traffic; a batch that touches most rows: the dense form, whose sweep then wastes nothing
+    if (int rc = plain_table(t, stream)) return rc;
     if (p && t && h && sides_of(h) == 3 && 2 * p->B <= (int64_t)v_row(t) + t->V)
         return step_adam_fused(p, t, h, ws, ws_bytes, G_flat, loss_out, stream);
-    if (int rc = glove_passes_f32(p, t, h, ws, ws_bytes, stream)) return rc;
-    if (int rc = glove_dense_grad_f32(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
+    if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
+    if (int rc = launch_dense_grad(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
     return glove_dense_adam_f32(t, h, G_flat, loss_out, stream);
 }
 

@@ -16,7 +16,7 @@ import torch
 logger = logging.getLogger(__name__)
 
 PKG_DIR = Path(__file__).resolve().parent.parent
-LIB_PATH = Path(os.environ.get("GLOVE_LIB") or PKG_DIR / "lib" / "libglove_hip.so")     # GLOVE_LIB: experiment builds (make variant)
+LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
 GLOVE_ABI_VERSION = 5
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
@@ -92,8 +92,10 @@ class GloveHipError(RuntimeError):
 _lib = None
 
 
-def load_library(path: os.PathLike | None = None) -> C.CDLL:
-    """dlopen libglove_hip.so and declare the prototypes.  Raises if it is not built."""
+def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CDLL:
+    """dlopen libglove_hip.so and declare the prototypes.  Raises if it is not built.  `path` / `any_abi`: explicit
+    arguments of the A/B tools (tools/ab_kernels.py), which load other builds of the library — older ones included —
+    beside the shipped one; nothing in the product passes them and no environment variable is read."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -144,14 +146,14 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         "glove_cooccurrence_i32": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, sz, vp]),
     }
     for name, (res, args) in protos.items():
-        if path and os.environ.get("GLOVE_AB_ANY_ABI") and not hasattr(lib, name):
+        if path and any_abi and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
     global FUSED_STEP_BYTES
     if hasattr(lib, "glove_fused_step_bytes"):
         FUSED_STEP_BYTES = int(lib.glove_fused_step_bytes())       # one number, owned by the library
-    if lib.glove_abi_version() != GLOVE_ABI_VERSION and not (path and os.environ.get("GLOVE_AB_ANY_ABI")):   # A/B tools load old builds
+    if lib.glove_abi_version() != GLOVE_ABI_VERSION and not (path and any_abi):
         raise GloveHipError("ABI mismatch: library %d, binding %d" % (lib.glove_abi_version(), GLOVE_ABI_VERSION))
     if path is None:
         _lib = lib
@@ -477,10 +479,11 @@ class Plan:
             self._struct = s
         return self._struct
 
-    def compact(self, lib=None, d: int | None = None) -> "Plan":
+    def compact(self, lib=None, d: int | None = None, records: bool | None = None) -> "Plan":
         """Exact-size copy (one host sync): used when plans of a static stream stay resident.  With `lib`
         (the loaded C library) the copy also gets its per-chunk records; `d` (floats per table row) tells whether
-        the batch is one the library steps in its fused form, which reads the id layout from the records."""
+        the batch is one the library steps in its fused form, which reads the id layout from the records.
+        `records`: True / False overrides the rule below (tests and A/B tools)."""
         nc_r, nu_r, nc_c, nu_c, n_heavy, n_mapped = (int(x) for x in self.counts.tolist()[:6])
         if n_mapped:
             logger.warning("%d ids outside [0, %d) were treated as id 0 (the unknown token)", n_mapped, self.V)
@@ -509,10 +512,10 @@ class Plan:
         out.r_crec = out.c_crec = None
         # records pad every chunk to the cap: worth it for the latency they save unless the chunks are nearly
         # empty (V = 400 k, B = 1 M: 2.6 pairs per 16-slot chunk -> 7 % more traffic, measured slower)
-        want = os.environ.get("GLOVE_RECORDS")          # experiments: "0" never, "1" always
         fused = d is not None and (nu_r + nu_c) * d * 16 >= FUSED_STEP_BYTES
-        if lib is not None and out.B > 0 and want != "0" and (
-                want == "1" or fused or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)):
+        if records is None:
+            records = fused or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)
+        if lib is not None and out.B > 0 and records:
             n = max(out.cap_chunks, 1) * out.rec_dwords
             out.r_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
             out.c_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
@@ -556,8 +559,8 @@ def _step_struct(tables, plans, hyper):
 class GloveHip:
     """Thin object wrapper over the C ABI; one instance per process/GPU."""
 
-    def __init__(self, device="cuda:0", lib_path=None):
-        self.lib = load_library(lib_path)
+    def __init__(self, device="cuda:0", lib_path=None, any_abi=False):
+        self.lib = load_library(lib_path, any_abi)
         self.device = torch.device(device)
         self._plan_ws = None
         self._step_ws = None

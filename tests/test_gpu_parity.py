@@ -786,9 +786,10 @@ def test_row_sharded_pieces_on_one_gpu(hip, B, V, d, W):
     assert torch.equal(a.scalars, b.scalars)
 
 
-@pytest.mark.parametrize("exchange", ["dense", "rows"])
-def test_full_size_row_sharded_two_virtual_ranks(hip, exchange):
-    """BASELINE config 5 at its workload (V = 2 M, d = 128, 1 M nonzeros per step) as two virtual ranks on one GPU:
+@pytest.mark.parametrize("exchange,workload", [("dense", "zipf_v2m_d128"), ("rows", "zipf_v2m_d128"), ("rows", "zipf_v400k_d300")])
+def test_full_size_row_sharded_two_virtual_ranks(hip, exchange, workload):
+    """BASELINE config 5 at its workload (V = 2 M, d = 128, 1 M nonzeros per step) — and config 4's (V = 400 k, d = 300),
+    which `bench.py --gpus N` also runs in the sharded forms — as two virtual ranks on one GPU:
     each holds half of the row table (V_row = 1 M < V, local row ids: the union batch routed by row owner) and a
     replica of the col table; the col side is exchanged by hand where the collective would run — the summed dense
     halves, or the two packed lists combined in rank order.  Result == the single-GPU step on the union batch
@@ -797,7 +798,7 @@ def test_full_size_row_sharded_two_virtual_ranks(hip, exchange):
     from trainer import synthetic
     from trainer.hip_api import DeviceTables, make_hyper
     W, B = 2, 1048576
-    wl = synthetic.make_workload("zipf_v2m_d128", seed=4, device="cuda:0", work_device="cuda:0")
+    wl = synthetic.make_workload(workload, seed=4, device="cuda:0", work_device="cuda:0")
     V, d = wl["V"], wl["d"]
     row, col, w, y = (wl[k][:B].contiguous() for k in ("row", "col", "w", "y"))
     full = DeviceTables(V, d, "Adagrad", seed=6)
@@ -988,13 +989,9 @@ def test_packing_passes_write_the_same_list(hip, B, V, d, cap, sides):
     h = make_hyper(learning_rate=0.05, batch_size=B, l2_reg=0.01, reg_mult=2.0)
     h.sides = sides
     raw = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap)
-    for records in ("1", "0"):
-        os.environ["GLOVE_RECORDS"] = records
-        try:
-            plan = raw.compact(hip.lib, t.d)
-        finally:
-            del os.environ["GLOVE_RECORDS"]
-        assert (plan.r_crec is not None) == (records == "1")
+    for records in (True, False):
+        plan = raw.compact(hip.lib, t.d, records=records)
+        assert (plan.r_crec is not None) == records
         n = 1 + plan.host_counts[1] + plan.host_counts[3]
         a = torch.full((n, t.d + 4), float("nan"), device="cuda:0")
         b = torch.full((n, t.d + 4), float("nan"), device="cuda:0")
@@ -1100,6 +1097,140 @@ def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
     np.testing.assert_allclose(st.loss_out.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-5)
 
 
+@pytest.mark.parametrize("workload", ["zipf_v400k_d300", "zipf_v2m_d128"])
+def test_full_size_sharded_stepper_on_one_rank(hip, workload):
+    """trainer.stepper.ShardedStepper (both tables sharded: what `bench.py --gpus N` times at configs 4 and 5) at the
+    full size of those configs with world = 1: == the plain sparse step within the fp32 rounding of the pair-by-pair sums
+    of its fused row side, loss included; and bitwise repeatable."""
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ShardedStepper
+    B = 1048576
+    wl = synthetic.make_workload(workload, seed=4, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    bt = tuple(wl[k][:B].contiguous() for k in ("row", "col", "w", "y"))
+    runs = []
+    for _ in range(2):
+        a = DeviceTables(V, d, "Adagrad", seed=6)
+        backend = HipBackend("cuda:0")
+        backend.row_floats = a.d
+        st = ShardedStepper(backend, a, dict(learning_rate=0.05), B, 1, 0, None)
+        h = st.add_batch(*bt, 0)
+        assert st.batches[h]["plan"].r_crec is not None           # the fused row side and the packing col pass
+        st.step(h)
+        st.step(h)
+        runs.append((a, st.loss_out.clone()))
+        del st, backend
+    _assert_same_bits(runs[0][0], runs[1][0], "repeat")
+    assert torch.equal(runs[0][1], runs[1][1])
+    b = DeviceTables(V, d, "Adagrad", seed=6)
+    plan = hip.build_plan(*bt, V, chunk_cap=0, compact=True)
+    lb = torch.zeros(4, device="cuda:0")
+    for _ in range(2):
+        hip.step_adagrad(plan, b, make_hyper(learning_rate=0.05, batch_size=B, step_form=1), lb)
+    _assert_tables_agree(runs[0][0], b, 5e-5, 5e-6)
+    np.testing.assert_allclose(runs[0][1].cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,V,d,cap", [(9000, 20000, 64, 8), (30000, 300000, 128, 16), (6000, 700, 300, 8)])
+def test_step_forms_mixed_on_a_twinned_table_without_reads_in_between(hip, B, V, d, cap):
+    """A twin-form step leaves rows current in the second copy.  Any step of another form behind it (one C call after
+    the other, or one list through glove_steps_adagrad_f32; nothing reads R in between, so the Python side never
+    canonicalises) must see those rows: the library brings a twinned table home before every form but the twin one.
+    Compared bit for bit with the same sequence on plain tables (form 4 there is form 3: same arithmetic)."""
+    import ctypes as C
+    from trainer.hip_api import DeviceTables, GlovePlan
+    t = oracle_tables(V, d, "Adagrad")
+    hp = ref.Hyper(learning_rate=0.05)
+    plans = [hip.build_plan(*to_dev(*make_batch(70 + k, B, V)), V, chunk_cap=cap).compact(hip.lib, records=True) for k in range(3)]
+    seq = [(0, 4), (1, 1), (2, 4), (0, 3), (1, 4), (2, 2), (0, 4), (1, 4), (2, 1)]       # (plan, form)
+    plain, twin = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    twin.enable_twin()
+    ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, twin.d) for p in plans), dtype=torch.uint8, device="cuda:0")
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    ts = twin.struct(twin_ok=True)            # the raw struct: no accessor of the Python side runs between the steps
+    for k, form in seq:
+        hip.step_adagrad(plans[k], plain, _hyper(hp, B, step_form=3 if form == 4 else form), la, ws)
+        rc = hip.lib.glove_step_adagrad_f32(C.byref(plans[k].struct()), C.byref(ts), C.byref(_hyper(hp, B, step_form=form)),
+                                            ws.data_ptr(), ws.numel(), lb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        assert torch.equal(la, lb), (k, form)
+    twin._twin_dirty = True
+    _assert_same_bits(plain, twin, "forms mixed call by call")
+
+
+def test_auto_step_form_straddling_the_fused_threshold_on_a_twinned_table(hip):
+    """GLOVE_STEP_AUTO picks the form per plan: a stream whose batches straddle glove_fused_step_bytes() mixes the twin
+    form and the two-launch form inside ONE glove_steps_adagrad_f32 call.  Same bits as the same call on plain tables
+    (where auto takes the three-launch form for the big batches: the twin form's arithmetic)."""
+    import ctypes as C
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, GlovePlan, make_hyper
+    wl = synthetic.make_workload("zipf_v400k_d300", seed=2, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    plain, twin = DeviceTables(V, d, "Adagrad", seed=5), DeviceTables(V, d, "Adagrad", seed=5)
+    twin.enable_twin()
+
+    def build(first, n):
+        return hip.build_plan(*(wl[k][first:first + n].contiguous() for k in ("row", "col", "w", "y")), V,
+                              chunk_cap=32).compact(hip.lib, plain.d, records=True)
+    big = [build(0, 262144), build(262144, 262144)]
+    small = [build(600000 + 4096 * k, 4096) for k in range(3)]
+    thr = hip.lib.glove_fused_step_bytes()
+    assert all((p.host_counts[1] + p.host_counts[3]) * plain.d * 16 >= thr for p in big)
+    assert all((p.host_counts[1] + p.host_counts[3]) * plain.d * 16 < thr for p in small)
+    lists = [small[0], big[0], small[1], big[1], small[2], big[0], big[1], small[0]]
+    arr = (C.POINTER(GlovePlan) * len(lists))(*[C.pointer(p.struct()) for p in lists])
+    ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, plain.d) for p in lists), dtype=torch.uint8, device="cuda:0")
+    h = make_hyper(learning_rate=0.05, batch_size=262144)
+    losses = []
+    for tables in (plain, twin):
+        st = tables.struct(twin_ok=True) if tables is twin else tables.struct()
+        loss = torch.zeros(4, device="cuda:0")
+        for _ in range(2):
+            rc = hip.lib.glove_steps_adagrad_f32(arr, len(lists), C.byref(st), C.byref(h), ws.data_ptr(), ws.numel(),
+                                                 loss.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        losses.append(loss)
+    assert torch.equal(losses[0], losses[1])
+    twin._twin_dirty = True
+    _assert_same_bits(plain, twin)
+
+
+def test_more_than_eight_lists_without_a_summed_tail(hip):
+    """glove_apply_packed_adagrad_f32 with more than eight lists and tail = NULL (a data-parallel rows exchange over
+    more than eight ranks): the loss partials of ALL headers are summed in list order — same result as handing the
+    summed tail over, bit for bit, and the scratch floats in G_flat's tail are zero again afterwards."""
+    from trainer.hip_api import DeviceTables, make_hyper
+    B, V, d, W = 700, 300, 64, 11
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    plans = [hip.build_plan(*to_dev(*make_batch(500 + r, B, V)), V, chunk_cap=16, compact=True) for r in range(W)]
+    h = make_hyper(learning_rate=0.05, batch_size=W * B)
+    cap = 1 + max(p.host_counts[1] + p.host_counts[3] for p in plans)
+    out = []
+    for tables, with_tail in ((a, True), (b, False)):
+        recv = torch.zeros(W, cap, tables.d + 4, device="cuda:0")
+        mark = torch.zeros(2 * V, dtype=torch.int32, device="cuda:0")
+        G, loss = hip.dense_grad_buffer(tables), torch.zeros(4, device="cuda:0")
+        for r, p in enumerate(plans):
+            hip.passes(p, tables, h)
+            hip.pack_grad(p, tables, h, recv[r])
+        lists = [hip.packed_list(recv[r]) for r in range(W)]
+        for r, lst in enumerate(lists):
+            hip.combine_packed(lst, r, tables, G, mark, cap)
+        tail = None
+        if with_tail:
+            tail = torch.zeros(4, device="cuda:0")
+            for r in range(W):
+                tail += recv[r, 0, 2:6]
+        hip.apply_packed(lists, tables, h, G, mark, tail, loss, cap)
+        assert float(G[hip.grad_layout(tables)["tail"]:].abs().max()) == 0.0
+        out.append(loss)
+    _assert_same_bits(a, b)
+    assert torch.equal(out[0], out[1])
+
+
 EDGE_CASES = [
     # (B, V, d, cap)  — degenerate shapes the reference's data can produce
     (1, 2, 4, 1), (5, 2, 4, 32), (64, 3, 4, 1), (1000, 7, 12, 1), (4096, 4096, 64, 32), (2000, 2, 64, 16),
@@ -1163,28 +1294,49 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
             for n in ("R", "C", "br", "bc"):
                 assert torch.equal(getattr(b, n), prev[n]), n
         prev = {n: getattr(b, n).clone() for n in ("R", "C", "br", "bc")} if form == 2 else prev
+    if plan.r_crec is not None:
+        # (1c) the form bench.py times at the HBM-bound sizes: the fused step on a TWINNED row table (form 4, and the
+        # library's own choice on such a table) == the three-launch form, bit for bit, at this size
+        fused_auto = (plan.host_counts[1] + plan.host_counts[3]) * a.d * 16 >= hip.lib.glove_fused_step_bytes()
+        for form in (4, 0):
+            c = DeviceTables(V, d, "Adagrad", seed=5)
+            c.enable_twin()
+            hip.step_adagrad(plan, c, make_hyper(learning_rate=lr, batch_size=B, step_form=form))
+            flipped = int(c.R_ver.sum())                       # raw state, before any accessor canonicalises
+            if form == 4 or fused_auto:
+                assert flipped > 0, "step_form %d did not take the twin form" % form
+                for n in ("R", "C", "br", "bc"):
+                    assert torch.equal(getattr(c, n), prev[n]), (form, n)          # prev: form 2 == form 3
+            else:
+                assert flipped == 0                            # below the fused regime auto stays with two launches
+                for n in ("R", "C", "br", "bc"):
+                    assert torch.equal(getattr(c, n), getattr(a, n)), (form, n)
+            assert int(c.R_ver.sum()) == 0                     # reading R brought the table home
+            del c
     touched = torch.zeros(V, dtype=torch.bool, device="cuda:0")
     touched[row.long()] = True
     assert torch.equal(a.R[~touched], R0[~touched])                               # (2)
     assert bool((a.R[touched] != R0[touched]).any(dim=1).all())
-    # (3) float64 restatement for sampled row ids (heaviest, lightest and random ones)
-    rid = row.long()
-    cnt = torch.bincount(rid, minlength=V)
-    ids = torch.cat([cnt.argsort(descending=True)[:4], torch.nonzero(cnt == 1)[:4, 0],
-                     torch.nonzero(cnt > 0)[:: max(1, int((cnt > 0).sum()) // 24), 0]]).unique()
+    # (3) float64 restatement for sampled ids of BOTH sides (heaviest, singleton and strided ones)
     g = 0.0
     kappa, kappa_b = 2 * m * l2 / d / B, 2 * m * l2 / B
-    for u in ids.tolist():
-        sel = rid == u
-        c = C0[col[sel].long()].double()
-        r = R0[u].double()
-        p = c @ r + br0[u].double() + bc0[col[sel].long()].double() + g
-        e = 2.0 * w[sel].double() * (p - y[sel].double()) / B
-        n = int(sel.sum())
-        G_u = (e[:, None] * c).sum(0) + kappa * n * r
-        A = 0.1 + G_u ** 2
-        want = r - lr * G_u / (A.sqrt() + 1e-7)
-        np.testing.assert_allclose(a.R[u].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg="row %d" % u)
-        gb = e.sum() + kappa_b * n * br0[u].double()
-        want_b = br0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
-        np.testing.assert_allclose(a.br[u].item(), want_b.item(), rtol=2e-5, atol=1e-6)
+    for side, own_id, other_id, own0, other0, ownb0, otherb0, got, gotb in (
+            ("row", row, col, R0, C0, br0, bc0, a.R, a.br), ("col", col, row, C0, R0, bc0, br0, a.C, a.bc)):
+        oid = own_id.long()
+        cnt = torch.bincount(oid, minlength=V)
+        ids = torch.cat([cnt.argsort(descending=True)[:4], torch.nonzero(cnt == 1)[:4, 0],
+                         torch.nonzero(cnt > 0)[:: max(1, int((cnt > 0).sum()) // 24), 0]]).unique()
+        for u in ids.tolist():
+            sel = oid == u
+            partner = other0[other_id[sel].long()].double()
+            own = own0[u].double()
+            p = partner @ own + ownb0[u].double() + otherb0[other_id[sel].long()].double() + g
+            e = 2.0 * w[sel].double() * (p - y[sel].double()) / B
+            n = int(sel.sum())
+            G_u = (e[:, None] * partner).sum(0) + kappa * n * own
+            A = 0.1 + G_u ** 2
+            want = own - lr * G_u / (A.sqrt() + 1e-7)
+            np.testing.assert_allclose(got[u].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg="%s %d" % (side, u))
+            gb = e.sum() + kappa_b * n * ownb0[u].double()
+            want_b = ownb0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
+            np.testing.assert_allclose(gotb[u].item(), want_b.item(), rtol=2e-5, atol=1e-6, err_msg="%s bias %d" % (side, u))

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=131072)
     ap.add_argument("--caps", default="32,16")
     ap.add_argument("--libs", default="", help="comma-separated builds of libglove_hip.so to compare (default: the shipped one)")
+    ap.add_argument("--any-abi", action="store_true", help="accept builds of another ABI version (older commits)")
     ap.add_argument("--step-form", type=int, default=0)
     ap.add_argument("--only", default="", help="comma-separated subset of rowpass,colpass,passes,apply,step")
     ap.add_argument("--twin", action="store_true", help="twinned row table (step form 4 under auto)")
@@ -29,7 +30,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [x for x in args.libs.split(",") if x] or [None]
-    hips = [GloveHip(dev, lib_path=x) if x else GloveHip(dev) for x in libs]
+    hips = [GloveHip(dev, lib_path=x, any_abi=args.any_abi) if x else GloveHip(dev) for x in libs]
     hip = hips[0]
     wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], args.batch_size
