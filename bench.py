@@ -54,6 +54,12 @@ DATA_NOTE = {"text8_d64": "synthetic (text8-shaped Poisson model of the referenc
              "zipf_v2m_d128": "synthetic (Zipf(1.0) ids over V = 2,000,000, 25 M nonzeros = one GPU's shard of config 5)"}
 
 
+def log(msg: str):
+    """Progress on stderr (rank 0): a long run says where it is — and, should a run die, how far it got."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +291,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         mode = "dp" if world > 1 else "single"
     if adam and mode != "single":
         raise SystemExit("--optimizer Adam is benchmarked on one GPU")
+    log("%s B=%d %s mode=%s%s: generating the workload" % (workload, B, optimizer, mode, " dynamic" if dynamic else ""))
     wl = ctx.workload(workload)
     V, d = wl["V"], wl["d"]
     coo = {k: wl[k] for k in ("row", "col", "w", "y")}
@@ -316,6 +323,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 
     # ---- load time (untimed): resident batches + their dedup index
     batches = [tuple(coo[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")) for b in range(nb)]
+    log("  index of %d resident batches" % nb)
     t0 = time.perf_counter()
     stepper = None
     if mode == "sharded":
@@ -396,6 +404,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         else:
             hip.step_adagrad(plan, tables, hyper, loss_out, ws)
 
+    log("  %.1f ms per index; warm-up and capture" % plan_build_ms)
     # One hipGraph holds `spg` consecutive steps, a divisor of --steps: the timed region is a whole number of replays.
     use_graph = mode == "single" and not no_graph
     graph, spg = None, steps_per_graph(steps)
@@ -424,6 +433,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         for i in range(done, n_steps):
             step(first + i)
 
+    torch.cuda.synchronize()
+    log("  warm-up steps")
     run(warmup, 0)
     # the first tens of milliseconds after the load phase run slow whatever the kernels are (B = 1 M at text8 scale:
     # 158 us/step in a first region of 200 steps, 47 in every later one; the graph's first replay also carries its
@@ -438,6 +449,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             dist.all_reduce(warm, op=dist.ReduceOp.MAX)     # every rank takes the same number of rounds
         if float(warm.item()) >= 0.05:
             break
+    log("  timed region")
     # the timed region: exactly `steps` steps between barrier + synchronize on both sides, MAX over ranks; repeated
     # at least three times and until at least min_timed_ms have been measured (a single transient cannot swing the
     # figure), median reported
@@ -458,6 +470,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             break
     elapsed = statistics.median(elapsed_all)
     final_loss = float(loss_out[0].item())
+    log("  %.4f ms per step (%d repeats); per-kernel pass" % (elapsed / steps * 1e3, len(elapsed_all)))
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
 
@@ -569,7 +582,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
     }
     del tables, plans, handles, batches, stepper, graph
+    torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    log("  done: %.3g nonzeros/s, %.1f us per step of kernels, roofline %.3f" % (out["value"], step_us, out["roofline"]["frac"]))
     return out
 
 
@@ -639,6 +654,7 @@ def main(argv=None):
                  args.step_form or args.chunk_cap or args.batch_size or args.workload != "zipf_v400k_d300" or
                  (args.rehearse_on_one_gpu and not args.with_configs))
     if rank == 0 and not args.no_cpu_baseline and world == 1 and mode == "auto":
+        log("cpu baseline (%g s)" % args.cpu_seconds)
         out["cpu_baseline"] = cpu_baseline(ctx, ctx.workload(args.workload), B_head, args.learning_rate, args.cpu_seconds)
     if plain:
         # the other configurations of BASELINE.json / BASELINE.md §3 in the same line, the HBM-bound ones last (the tail of

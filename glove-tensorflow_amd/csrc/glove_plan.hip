@@ -5,13 +5,11 @@
 // of every step (reached from reference src/models/train_utils.py:13-16).  The
 // sums themselves happen in glove_step.hip; this file only orders the pairs.
 //
-// Integer work: two stable sorts (rocPRIM device primitives) + two tile kernels that number the chunks and
-// ids of both sides.  The result is bit-exact against oracle/glove_ref.py:build_plan.
+// Integer work: two stable sorts (a hand-written tiled LSD radix sort, below) + two tile kernels that number the
+// chunks and ids of both sides.  The result is bit-exact against oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/functional.hpp>
 
 namespace glove {
 
@@ -20,49 +18,220 @@ constexpr int kSmallPlanMax = 4096;
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st);
 
-// positions 0..n-1, and copies of the ids with anything outside [0, V) mapped to 0 — the id the reference's
-// vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) — so that no later kernel
-// can index outside the tables whatever the caller hands over; counts[5] reports how many were mapped
-__global__ void prepare_ids(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t n, int32_t Vr, int32_t V,
-                            int32_t *__restrict__ iota, int32_t *__restrict__ row_clean,
-                            int32_t *__restrict__ col_clean, int32_t *__restrict__ n_mapped)
+__device__ inline int wave_sum_int(int v)
 {
-    int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)row[i], c = (uint32_t)col[i];
-        iota[i] = (int32_t)i;
-        row_clean[i] = r < (uint32_t)Vr ? (int32_t)r : 0;
-        col_clean[i] = c < (uint32_t)V ? (int32_t)c : 0;
-        bad += (r >= (uint32_t)Vr) + (c >= (uint32_t)V);
-    }
-    if (bad) atomicAdd(n_mapped, bad);
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
+    return v;
 }
 
-// row side: pull col/w/y through the row-sort permutation
-__global__ void gather_row_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ col,
-                                const float *__restrict__ w, const float *__restrict__ y, int64_t n,
-                                int32_t *__restrict__ partner, float *__restrict__ ow, float *__restrict__ oy)
+// ---- stable LSD radix sort of (id, position), B > kSmallPlanMax ------------------------------------------------
+// Both sides need their pairs in (id, earlier order) order: the row side sorts the batch by row id, the col side sorts
+// the ROW-SORTED pairs by col id.  Keys are ids below V, i.e. ceil(log2 V) bits: P = ceil(bits / 8) passes over digits of
+// db = ceil(bits / P) bits (V = 10 k: two passes of 7 bits; V = 2 M: three of 7), least significant digit first, every pass
+// stable.  A pass is two launches over tiles of kSortThreads x E consecutive positions, one workgroup each:
+//   radix_hist     count[tile][digit] = keys of the tile with that digit (every entry written: nothing relies on zeroed memory)
+//   radix_scatter  position of a key = keys of smaller digits anywhere + keys of its digit in earlier tiles (both summed
+//                  from the count table by the workgroup itself: thread d walks column d) + keys of its digit earlier in
+//                  its own tile (its stable local rank)
+// Local ranks come from wave ballots: a wave takes 64 consecutive positions per round, the lanes holding the same digit
+// find each other with db ballots, the group's first lane fetches-and-adds the group's size to the wave's running count of
+// that digit (LDS atomic with return: rounds and peers are ordered by construction) and hands the old value round.
+// The LAST pass of a sort writes the plan's arrays itself (no gather launches): the row side's pass pulls col / w / y
+// through the permutation and maps col ids outside [0, V) to 0; the col side's writes c_perm, its inverse r_to_c, the
+// partner row ids and w / y in col order.  The first pass of the row side maps row ids outside the table to 0 on the
+// fly — id 0 is what the reference's vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) —
+// so that no later kernel can index outside the tables whatever the caller hands over; counts[5] reports how many.
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kMaxDigits = 256;
+
+struct SortIn {
+    const int32_t *keys;        // [n] keys of this pass, in the order the previous pass left them
+    const int32_t *vals;        // [n] original positions travelling with them; nullptr = the position itself (first pass)
+    int64_t n;
+    int32_t clean_below;        // > 0: first pass over raw ids: anything outside [0, clean_below) counts as id 0
+    int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
+    int ntiles;
+    int32_t *count;             // [ntiles][1 << db]
+    int32_t *n_mapped;          // plan counts[5]
+};
+
+struct SortOut {
+    int32_t *keys, *vals;       // not the last pass: the pair at its new position
+    // last pass: the sorted keys (the tile kernels below read them) and this side's plan arrays
+    int32_t *sorted_keys;
+    // row side: partner = col[p] (cleaned against V), w, y pulled through the permutation
+    const int32_t *col;
+    const float *w, *y;
+    int32_t V;
+    int32_t *r_partner;
+    float *r_w, *r_y;
+    // col side: p is a row-sorted position
+    const int32_t *row_sorted;
+    const float *in_w, *in_y;   // r_w, r_y
+    int32_t *c_perm, *c_partner, *r_to_c;
+    float *c_w, *c_y;
+};
+
+// lanes of the wave that hold the same digit as this one (valid lanes only); db ballots
+__device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t p = perm[i];
-        partner[i] = col[p];
-        ow[i] = w[p];
-        oy[i] = y[p];
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < db; ++b) {
+        const bool bit = (digit >> b) & 1;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+template <int E>
+__device__ inline void sort_load_keys(const SortIn &in, int64_t base, int32_t (&key)[E], int &mapped)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = base + j * 64 + lane;
+        int32_t k = 0;
+        if (i < in.n) {
+            k = in.keys[i];
+            if (in.clean_below > 0 && (uint32_t)k >= (uint32_t)in.clean_below) { k = 0; ++mapped; }
+        }
+        key[j] = k;
     }
 }
 
-// col side: partner = row id of the row-sorted pair the permutation points at; r_to_c = inverse
-__global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t *__restrict__ sorted_row,
-                                const float *__restrict__ r_w, const float *__restrict__ r_y, int64_t n,
-                                int32_t *__restrict__ partner, int32_t *__restrict__ r_to_c,
-                                float *__restrict__ c_w, float *__restrict__ c_y)
+template <int E>
+__global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t p = perm[i];
-        partner[i] = sorted_row[p];
-        r_to_c[p] = (int32_t)i;
-        c_w[i] = r_w[p];
-        c_y[i] = r_y[p];
+    __shared__ int hist[kMaxDigits];
+    const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
+    int32_t key[E];
+    int mapped = 0;
+    sort_load_keys<E>(in, base, key, mapped);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool valid = base + j * 64 + lane < in.n;
+        const int digit = (key[j] >> in.shift) & (nd - 1);
+        const unsigned long long peers = digit_peers(digit, in.db, valid);
+        if (valid && lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[digit], __popcll(peers));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nd) in.count[(size_t)blockIdx.x * nd + threadIdx.x] = hist[threadIdx.x];
+    // ids the cleaning mapped to 0 are reported once, by the pass that first sees the raw ids
+    if (in.clean_below > 0) {
+        mapped = wave_sum_int(mapped);
+        if (lane == 0 && mapped) atomicAdd(in.n_mapped, mapped);
+    }
+}
+
+template <int E, int LAST /* 0 no, 1 row side, 2 col side */>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut out)
+{
+    __shared__ int wcnt[kSortWaves][kMaxDigits];          // a wave's running digit counts; then every wave's bases
+    __shared__ int scan_red[kSortWaves];
+    const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < kSortWaves * kMaxDigits; i += kSortThreads) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
+    int32_t key[E], rank[E];
+    int mapped = 0;
+    sort_load_keys<E>(in, base, key, mapped);
+    mapped = 0;                                           // (row ids mapped to 0 are counted by radix_hist)
+    int32_t val[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = base + j * 64 + lane;
+        val[j] = in.vals ? (i < in.n ? in.vals[i] : 0) : (int32_t)i;
+    }
+    // ---- stable rank of every key among the keys of its digit in this wave's range
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool valid = base + j * 64 + lane < in.n;
+        const int digit = (key[j] >> in.shift) & (nd - 1);
+        const unsigned long long peers = digit_peers(digit, in.db, valid);
+        const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+        int before = 0;
+        if (valid && lane == leader) before = atomicAdd(&wcnt[wave][digit], __popcll(peers));
+        before = __shfl(before, leader, 64);
+        rank[j] = before + __popcll(peers & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    // ---- thread d: column d of the count table -> where the keys of digit d of this tile start
+    int all = 0, earlier = 0;
+    if ((int)threadIdx.x < nd) {
+        const int32_t *colp = in.count + threadIdx.x;
+        const int me = blockIdx.x;
+        int t = 0;
+        for (; t + 8 <= in.ntiles; t += 8) {              // eight independent loads in flight
+            int c[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) c[x] = colp[(size_t)(t + x) * nd];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { all += c[x]; earlier += (t + x < me) ? c[x] : 0; }
+        }
+        for (; t < in.ntiles; ++t) {
+            const int c = colp[(size_t)t * nd];
+            all += c;
+            earlier += (t < me) ? c : 0;
+        }
+    }
+    // exclusive scan of `all` over the digits (threads): wave scan, then the four wave totals
+    int incl = all;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl += o;
+    }
+    if (lane == 63) scan_red[wave] = incl;
+    __syncthreads();                                      // also: every wave's running counts are final
+    int start = incl - all + earlier;
+    for (int wv = 0; wv < wave; ++wv) start += scan_red[wv];
+    if ((int)threadIdx.x < nd) {
+        // wcnt[w][d] becomes the position of the first key of digit d that wave w of this tile holds
+        int run = start;
+#pragma unroll
+        for (int wv = 0; wv < kSortWaves; ++wv) {
+            const int c = wcnt[wv][threadIdx.x];
+            wcnt[wv][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // ---- every pair to its place
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t i = base + j * 64 + lane;
+        if (i >= in.n) continue;
+        const int digit = (key[j] >> in.shift) & (nd - 1);
+        const int dest = wcnt[wave][digit] + rank[j];
+        const int32_t p = val[j];
+        if (LAST == 0) {
+            out.keys[dest] = key[j];
+            out.vals[dest] = p;
+        } else if (LAST == 1) {
+            out.sorted_keys[dest] = key[j];
+            int32_t c = out.col[p];
+            if ((uint32_t)c >= (uint32_t)out.V) { c = 0; ++mapped; }
+            out.r_partner[dest] = c;
+            out.r_w[dest] = out.w[p];
+            out.r_y[dest] = out.y[p];
+        } else {
+            out.sorted_keys[dest] = key[j];
+            out.c_perm[dest] = p;
+            out.r_to_c[p] = dest;
+            out.c_partner[dest] = out.row_sorted[p];
+            out.c_w[dest] = out.in_w[p];
+            out.c_y[dest] = out.in_y[p];
+        }
+    }
+    if (LAST == 1) {                                      // col ids mapped to 0 (row ids: radix_hist of the first pass)
+        mapped = wave_sum_int(mapped);
+        if (lane == 0 && mapped) atomicAdd(in.n_mapped, mapped);
     }
 }
 
@@ -77,12 +246,6 @@ __global__ void gather_col_side(const int32_t *__restrict__ perm, const int32_t 
 //               recomputes its flags, numbers them with one block scan and writes chunk_id / chunk_start /
 //               uniq_slot; the last tile also writes the totals and the closing entries.
 // blockIdx.y selects the side.  Bit-exact against oracle/glove_ref.py:build_plan like the scans it replaces.
-__device__ inline int wave_sum_int(int v)
-{
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
-    return v;
-}
 
 constexpr int kTileThreads = 256;
 constexpr int kTilePer = 8;                               // consecutive positions per thread
@@ -336,16 +499,20 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 }
 
 struct PlanWs {
-    int32_t *iota, *perm, *keys_sorted, *row_sorted, *row_clean, *col_clean;
-    int64_t *tile_rs;    // [2][ntiles] start of the run that crosses a tile's left edge
-    int2 *tile_sums;     // [2][ntiles] (ids, chunks) opened inside a tile
-    int ntiles;
-    void *prim;          // rocPRIM temporary storage
-    size_t prim_bytes;
+    int32_t *keys[2], *vals[2];      // ping-pong buffers of the sort passes
+    int32_t *row_sorted;             // row ids in row-side order
+    int32_t *col_sorted;             // col ids in col-side order
+    int32_t *count;                  // [sort tiles][digits] of the pass in flight
+    int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
+    int2 *tile_sums;                 // [2][ntiles] (ids, chunks) opened inside a tile
+    int ntiles;                      // tiles of the numbering kernels (kTile positions)
+    int sort_e, sort_tiles;          // positions per thread and tiles of the sort passes
     size_t bytes;
 };
 
-static size_t prim_budget(int64_t B) { return (size_t)(4u << 20) + (size_t)B * 24; }
+// positions per thread of a sort tile: enough tiles to spread over the chip, few enough that walking a column of the
+// count table (one entry per tile) stays short
+static int sort_e_for(int64_t B) { return B <= 131072 ? 4 : B <= 524288 ? 8 : 16; }
 
 static PlanWs carve_plan_ws(void *ws, int64_t B)
 {
@@ -354,32 +521,61 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     char *base = (char *)ws;
     auto take = [&](size_t bytes) { void *q = base + off; off += align_up(bytes, 256); return q; };
     const size_t n = (size_t)(B > 0 ? B : 1);
-    p.iota = (int32_t *)take(n * 4);
-    p.perm = (int32_t *)take(n * 4);
-    p.keys_sorted = (int32_t *)take(n * 4);
+    for (int i = 0; i < 2; ++i) {
+        p.keys[i] = (int32_t *)take(n * 4);
+        p.vals[i] = (int32_t *)take(n * 4);
+    }
     p.row_sorted = (int32_t *)take(n * 4);
-    p.row_clean = (int32_t *)take(n * 4);
-    p.col_clean = (int32_t *)take(n * 4);
+    p.col_sorted = (int32_t *)take(n * 4);
+    p.sort_e = sort_e_for(B);
+    const size_t per_tile = (size_t)kSortThreads * p.sort_e;
+    p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
+    p.count = (int32_t *)take((size_t)p.sort_tiles * kMaxDigits * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
     p.tile_sums = (int2 *)take((size_t)2 * p.ntiles * 8);
-    p.prim_bytes = prim_budget(B);
-    p.prim = take(p.prim_bytes);
     p.bytes = off;
     return p;
 }
-
-// Below 2^20 items rocPRIM's radix_sort_pairs is a merge sort: a block sort of tiles, then one launch per doubling.
-// The default tile is 512 items (nine launches for a 131 k batch, each a few microseconds of mostly latency);
-// 8,192-item tiles (512 threads x 16) need four merges: 150 -> 133 us per dynamic step, 90 -> 67 with six builds in
-// flight.  (Tiles of 4,096 / 16,384: 139 / 156 us; forcing the onesweep radix path instead: 180 us.)
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<256, 512, 16>>;
 
 static int ceil_log2(int32_t v)
 {
     int b = 1;
     while (b < 31 && (1 << b) < v) ++b;
     return b;
+}
+
+// One stable sort by id: P passes of (radix_hist, radix_scatter).  first_keys: the ids as they arrive (row side: raw row
+// ids, cleaned against clean_below; col side: r_partner, already clean).  `last` carries the destination arrays of the last
+// pass; side = 1 row, 2 col.
+template <int E>
+static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t B, int bits, const PlanWs &pw, SortOut last,
+                        int side, int32_t *n_mapped, hipStream_t st)
+{
+    const int P = (bits + 7) / 8, db = (bits + P - 1) / P;
+    for (int p = 0; p < P; ++p) {
+        SortIn in;
+        in.keys = p == 0 ? first_keys : pw.keys[(p - 1) & 1];
+        in.vals = p == 0 ? nullptr : pw.vals[(p - 1) & 1];
+        in.n = B;
+        in.clean_below = p == 0 ? clean_below : 0;
+        in.shift = p * db;
+        in.db = db;
+        in.ntiles = pw.sort_tiles;
+        in.count = pw.count;
+        in.n_mapped = n_mapped;
+        hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
+        if (p < P - 1) {
+            SortOut out = last;
+            out.keys = pw.keys[p & 1];
+            out.vals = pw.vals[p & 1];
+            hipLaunchKernelGGL((radix_scatter<E, 0>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, out);
+        } else if (side == 1) {
+            hipLaunchKernelGGL((radix_scatter<E, 1>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, last);
+        } else {
+            hipLaunchKernelGGL((radix_scatter<E, 2>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, last);
+        }
+    }
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -424,32 +620,28 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     const PlanWs pw = carve_plan_ws(ws, B);
     if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
 
-    const int nb = blocks_for(B, kBlock);
     const int bits = ceil_log2(V);
-    size_t need = 0;
+    const int32_t Vr = plan->V_row > 0 ? plan->V_row : V;
 
-    // ---- row side: stable sort (row id, position)
-    hipLaunchKernelGGL(prepare_ids, dim3(nb), dim3(kBlock), 0, st, row, col, B, plan->V_row > 0 ? plan->V_row : V, V, pw.iota, pw.row_clean, pw.col_clean,
-                       plan->counts + 5);
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
-                                      (size_t)B, 0, bits, st));
-    if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(pw.prim, need, (const int32_t *)pw.row_clean, pw.row_sorted, pw.iota, pw.perm,
-                                      (size_t)B, 0, bits, st));
-    hipLaunchKernelGGL(gather_row_side, dim3(nb), dim3(kBlock), 0, st, pw.perm, pw.col_clean, w, y, B, plan->r_partner,
-                       plan->r_w, plan->r_y);
-
-    // ---- col side: stable sort of the row-sorted pairs by col id
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
-                                      plan->c_perm, (size_t)B, 0, bits, st));
-    if (need > pw.prim_bytes) return GLOVE_E_WORKSPACE;
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(pw.prim, need, (const int32_t *)plan->r_partner, pw.keys_sorted, pw.iota,
-                                      plan->c_perm, (size_t)B, 0, bits, st));
-    hipLaunchKernelGGL(gather_col_side, dim3(nb), dim3(kBlock), 0, st, plan->c_perm, pw.row_sorted, plan->r_w, plan->r_y, B,
-                       plan->c_partner, plan->r_to_c, plan->c_w, plan->c_y);
+    // ---- row side: stable sort by (row id, position); its last pass fills r_partner / r_w / r_y
+    SortOut ro = {};
+    ro.sorted_keys = pw.row_sorted;
+    ro.col = col; ro.w = w; ro.y = y; ro.V = V;
+    ro.r_partner = plan->r_partner; ro.r_w = plan->r_w; ro.r_y = plan->r_y;
+    // ---- col side: stable sort of the row-sorted pairs by col id; its last pass fills c_perm / r_to_c / c_partner / c_w / c_y
+    SortOut co = {};
+    co.sorted_keys = pw.col_sorted;
+    co.row_sorted = pw.row_sorted; co.in_w = plan->r_w; co.in_y = plan->r_y;
+    co.c_perm = plan->c_perm; co.c_partner = plan->c_partner; co.r_to_c = plan->r_to_c;
+    co.c_w = plan->c_w; co.c_y = plan->c_y;
+#define SORTS(E)                                                                                              \
+    launch_sort<E>(row, Vr, B, bits, pw, ro, 1, plan->counts + 5, st);                                        \
+    launch_sort<E>(plan->r_partner, 0, B, bits, pw, co, 2, plan->counts + 5, st)
+    if (pw.sort_e == 4) { SORTS(4); } else if (pw.sort_e == 8) { SORTS(8); } else { SORTS(16); }
+#undef SORTS
 
     // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
-    const SideKeys sk = {{pw.row_sorted, pw.keys_sorted}};
+    const SideKeys sk = {{pw.row_sorted, pw.col_sorted}};
     const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                         {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts};
     hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,

@@ -29,3 +29,25 @@ def hip():
         import __graft_entry__
         __graft_entry__.build()
     return hip_api.GloveHip("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def plan_checker(hip):
+    """tests/native/libglove_test_checks.so: device-side range checks of a plan, launched on the stream between the index
+    build and the step (also inside a captured hipGraph).  check(plan, V, errors8) adds to the int32[8] device array."""
+    import ctypes as C
+    import subprocess
+    import torch
+    from trainer.hip_api import GlovePlan
+    so = REPO / "tests" / "native" / "libglove_test_checks.so"
+    if not so.exists():
+        subprocess.run(["make", "-s", "-C", str(so.parent)], check=True)
+    lib = C.CDLL(str(so))
+    lib.glove_test_check_plan.restype = C.c_int
+    lib.glove_test_check_plan.argtypes = [C.POINTER(GlovePlan), C.c_int32, C.c_void_p, C.c_void_p]
+
+    def check(plan, V, errors):
+        assert errors.dtype == torch.int32 and errors.numel() == 8 and errors.is_cuda
+        rc = lib.glove_test_check_plan(C.byref(plan.struct()), V, errors.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+    return check

@@ -144,6 +144,121 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     np.testing.assert_array_equal(cp.r_chunk_start.cpu().numpy()[:nc_r + 1], want["r_chunk_start"])
 
 
+PLAN_ARRAYS = ("r_partner", "r_w", "r_y", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot", "r_uniq_rec", "c_partner",
+               "c_perm", "c_w", "c_y", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy", "counts")
+
+
+def _poison(plan, ws):
+    """0xFF into every array of a plan and into the build workspace: -1 as an id or position, NaN as a float — whatever a
+    build leaves unwritten, or expects zeroed from allocation time, shows."""
+    for n in PLAN_ARRAYS + ("r_crec", "c_crec"):
+        t = getattr(plan, n)
+        if t is not None:
+            t.view(torch.uint8).fill_(0xFF)
+    ws.fill_(0xFF)
+
+
+def _assert_plan_equals_oracle(plan, want, B, w, y):
+    counts = plan.counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, want["counts"])
+    nc_r, nu_r, nc_c, nu_c, n_heavy = counts[:5]
+    np.testing.assert_array_equal(np.sort(plan.heavy.cpu().numpy()[:n_heavy]), want["heavy"])
+    for name, exp, n in (("r_partner", want["r_partner"], B), ("c_partner", want["c_partner"], B), ("c_perm", want["c_perm"], B),
+                         ("r_to_c", want["r_to_c"], B), ("r_chunk_id", want["r_chunk_id"], nc_r),
+                         ("r_chunk_start", want["r_chunk_start"], nc_r + 1), ("r_uniq_slot", want["r_uniq_slot"], nu_r + 1),
+                         ("c_chunk_id", want["c_chunk_id"], nc_c), ("c_chunk_start", want["c_chunk_start"], nc_c + 1),
+                         ("c_uniq_slot", want["c_uniq_slot"], nu_c + 1)):
+        np.testing.assert_array_equal(getattr(plan, name).cpu().numpy()[:n], exp, err_msg=name)
+    np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
+    np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
+    np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
+    np.testing.assert_array_equal(plan.c_y.cpu().numpy()[:B], y[want["perm_r"]][want["c_perm"]])
+
+
+@pytest.mark.parametrize("B,V,cap", [(1000, 300, 8), (4096, 12000, 16), (9000, 97, 3), (131072, 10000, 16), (70000, 300000, 32),
+                                     (300000, 2000000, 32)])
+def test_consecutive_builds_into_a_poisoned_staging_plan(hip, plan_checker, B, V, cap):
+    """Two consecutive glove_plan_build calls into the SAME staging plan, every plan array and the whole build workspace
+    filled with 0xFF before each: the index must not depend on anything a build did not write itself (state zeroed at
+    allocation only, leftovers of the previous batch).  Bit-exact against the oracle both times, and the device-side
+    range check (every partner / perm / record slot a step kernel may read) finds nothing."""
+    from trainer.hip_api import Plan
+    staging = Plan(B, V, cap, "cuda:0")
+    if staging.r_crec is None and B <= 131072:          # records filled by the build as well (the per-step form of big batches)
+        staging.r_crec, staging.c_crec = (torch.zeros(staging.cap_chunks * staging.rec_dwords, dtype=torch.int32, device="cuda:0")
+                                          for _ in range(2))
+    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
+    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    for k in range(2):
+        row, col, w, y = make_batch(B + V + 31 * k, B, V, zipf=(k == 0))
+        if k == 1:
+            row[::9] = V + 5                             # ids outside the vocabulary count as id 0
+            col[3::13] = -7
+        _poison(staging, ws)
+        hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap, into=staging, ws=ws)
+        plan_checker(staging, V, errors)
+        _assert_plan_equals_oracle(staging, ref.build_plan(row, col, cap, V=V), B, w, y)
+        assert errors.tolist() == [0] * 8, errors.tolist()
+
+
+def test_plan_checker_sees_what_it_should(hip, plan_checker):
+    """The checker itself: a sound plan passes; a stale partner id, a broken permutation and a bad record slot are each reported."""
+    B, V, cap = 9000, 500, 8
+    row, col, w, y = make_batch(5, B, V)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap).compact(hip.lib, records=True)
+    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    plan_checker(plan, V, errors)
+    assert errors.tolist() == [0] * 8
+    plan.r_partner[17] = V + 1
+    plan.c_perm[5], plan.c_perm[6] = plan.c_perm[6].clone(), plan.c_perm[6].clone()
+    plan.c_crec[4 + 1] = -1                              # second partner slot of chunk 0 (a padding slot counts too)
+    plan_checker(plan, V, errors)
+    e = errors.tolist()
+    assert e[0] == 1 and e[4] >= 1 and e[7] == 1 and e[1] == e[2] == e[3] == 0, e
+
+
+def test_index_rebuilt_inside_a_replayed_hipgraph(hip, plan_checker):
+    """What `bench.py --dynamic` and the reshuffling runner do: index build into a staging plan + step, captured once and
+    REPLAYED — with the device-side plan check between build and step, and the staging plan and workspace poisoned
+    between replays.  The trajectory equals stepping on statically built plans, bit for bit, and no check ever fires."""
+    from trainer.hip_api import DeviceTables, Plan
+    B, V, d, cap = 131072, 10000, 64, 16
+    batches = [to_dev(*make_batch(900 + k, B, V)) for k in range(3)]
+    a, b = DeviceTables(V, d, "Adagrad", seed=4), DeviceTables(V, d, "Adagrad", seed=4)
+    h = _hyper(ref.Hyper(learning_rate=0.05), B, step_form=1)
+    static = [hip.build_plan(*bt, V, chunk_cap=cap) for bt in batches]
+    staging = Plan(B, V, cap, "cuda:0")
+    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
+    step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, a.d), dtype=torch.uint8, device="cuda:0")
+    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+
+    def burst():
+        for bt in batches:
+            hip.build_plan(*bt, V, chunk_cap=cap, into=staging, ws=ws)
+            plan_checker(staging, V, errors)
+            hip.step_adagrad(staging, b, h, lb, step_ws)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        burst()                                          # warm the launch paths outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        burst()
+    for rnd in range(4):                                 # the warm-up burst + 3 replays
+        if rnd:
+            _poison(staging, ws)
+            graph.replay()
+        for p in static:
+            hip.step_adagrad(p, a, h, la, step_ws)
+        torch.cuda.synchronize()
+        assert errors.tolist() == [0] * 8, (rnd, errors.tolist())
+        _assert_same_bits(a, b, "round %d" % rnd)
+        assert torch.equal(la, lb)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("GLOVE_FUZZ_CASES", "40"))))
 def test_randomized_plan_is_bit_exact(hip, seed):
     """Seeded random batches through both index builders (one workgroup / tiled): every array of the plan equals
