@@ -29,6 +29,20 @@ __device__ inline void stamp(int slot)
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Small device buffers are zeroed by a KERNEL, never by hipMemsetAsync: captured into a hipGraph, a memset node of a few
+// words came back wrong on replay (ROCm 7.2: counts[4..7] of a plan held host-pointer-like garbage after the second
+// replay, tools/dbg_dyn_graph.py) — the cause of the GPU memory faults of the replayed dynamic index build.
+static __global__ void zero_words_kernel(uint32_t *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+inline hipError_t zero_words(void *p, int n_words, hipStream_t st)
+{
+    hipLaunchKernelGGL(zero_words_kernel, dim3((n_words + 63) / 64), dim3(64), 0, st, (uint32_t *)p, n_words);
+    return hipGetLastError();
+}
+
 // ---- per-chunk records (glove_plan.r_crec / c_crec) --------------------------------------------------
 // A record is 4 + 3 * capP dwords, capP = rec_cap(chunk_cap): the header, then capP / kRecPad blocks of kRecPad pairs,
 // each block {partner[8] | w[8] | y[8]} — so that what a chunk of n pairs needs is the PREFIX of 4 + 24 ceil(n / 8)

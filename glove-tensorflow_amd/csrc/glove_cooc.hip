@@ -136,7 +136,7 @@ int glove_cooccurrence_i32(const int32_t *tokens, int64_t n, int32_t V, int32_t 
     if ((double)V * (double)V * (double)context >= 9.0e18) return GLOVE_E_BADARG;      // key must fit 63 bits
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        HIP_TRY(hipMemsetAsync(out_nnz, 0, sizeof(int64_t), st));
+        HIP_TRY(zero_words(out_nnz, 2, st));
         return 0;
     }
     if (!tokens || !out_row || !out_col || !out_count || !out_value) return GLOVE_E_BADARG;

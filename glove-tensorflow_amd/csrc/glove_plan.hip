@@ -54,7 +54,9 @@ struct SortIn {
     int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
     int ntiles;
     int32_t *count;             // [ntiles][1 << db]
-    int32_t *n_mapped;          // plan counts[5]
+    int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (row ids: radix_hist of the first pass;
+                                // col ids: the row side's last radix_scatter).  Every entry is written by every build —
+                                // no counter to zero, no atomics; emit_uniq_rec adds them up into plan counts[5]
 };
 
 struct SortOut {
@@ -73,6 +75,20 @@ struct SortOut {
     int32_t *c_perm, *c_partner, *r_to_c;
     float *c_w, *c_y;
 };
+
+// *out = sum of v over the workgroup (kSortThreads threads; called by all of them)
+__device__ inline void block_store_sum(int v, int32_t *out)
+{
+    __shared__ int part[kSortWaves];
+    v = wave_sum_int(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int wv = 0; wv < kSortWaves; ++wv) s += part[wv];
+        *out = s;
+    }
+}
 
 // lanes of the wave that hold the same digit as this one (valid lanes only); db ballots
 __device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
@@ -123,10 +139,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
     __syncthreads();
     if ((int)threadIdx.x < nd) in.count[(size_t)blockIdx.x * nd + threadIdx.x] = hist[threadIdx.x];
     // ids the cleaning mapped to 0 are reported once, by the pass that first sees the raw ids
-    if (in.clean_below > 0) {
-        mapped = wave_sum_int(mapped);
-        if (lane == 0 && mapped) atomicAdd(in.n_mapped, mapped);
-    }
+    if (in.clean_below > 0) block_store_sum(mapped, in.mapped + blockIdx.x);
 }
 
 template <int E, int LAST /* 0 no, 1 row side, 2 col side */>
@@ -229,10 +242,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
             out.c_y[dest] = out.in_y[p];
         }
     }
-    if (LAST == 1) {                                      // col ids mapped to 0 (row ids: radix_hist of the first pass)
-        mapped = wave_sum_int(mapped);
-        if (lane == 0 && mapped) atomicAdd(in.n_mapped, mapped);
-    }
+    if (LAST == 1) block_store_sum(mapped, in.mapped + in.ntiles + blockIdx.x);     // col ids mapped to 0
 }
 
 // ---- chunk / id numbering of BOTH sides in two launches --------------------------------------------------
@@ -412,6 +422,9 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
             uniq_slot[ui] = ci;
             out.counts[2 * side] = ci;
             out.counts[2 * side + 1] = ui;
+            // the heavy-id counter emit_uniq_rec (the next launch) appends behind starts at zero, the spare words are
+            // zero: no word of `counts` depends on what the buffer held before this build
+            if (side == 0) out.counts[4] = out.counts[6] = out.counts[7] = 0;
         }
     }
 }
@@ -423,9 +436,23 @@ struct UniqRecArgs {
     int32_t *rec[2];
 };
 __global__ void emit_uniq_rec(const int32_t *__restrict__ counts, UniqRecArgs a, int heavy_chunks, int cap_heavy,
-                              int32_t *__restrict__ heavy, int32_t *__restrict__ n_heavy)
+                              int32_t *__restrict__ heavy, int32_t *__restrict__ n_heavy,
+                              const int32_t *__restrict__ mapped, int n_mapped_entries, int32_t *__restrict__ n_mapped_out)
 {
     const int side = blockIdx.y;
+    if (blockIdx.x == 0 && side == 0) {                    // ids mapped to 0, over the sort tiles of both kinds -> counts[5]
+        __shared__ int part[4];
+        int v = 0;
+        for (int i = threadIdx.x; i < n_mapped_entries; i += blockDim.x) v += mapped[i];
+        v = wave_sum_int(v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += part[wv];
+            *n_mapped_out = s;
+        }
+    }
     const int nu = counts[2 * side + 1];
     const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *uniq_slot = a.uniq_slot[side];
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nu; q += gridDim.x * blockDim.x) {
@@ -503,6 +530,7 @@ struct PlanWs {
     int32_t *row_sorted;             // row ids in row-side order
     int32_t *col_sorted;             // col ids in col-side order
     int32_t *count;                  // [sort tiles][digits] of the pass in flight
+    int32_t *mapped;                 // [2][sort tiles] ids mapped to 0 per tile (row ids, col ids)
     int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
     int2 *tile_sums;                 // [2][ntiles] (ids, chunks) opened inside a tile
     int ntiles;                      // tiles of the numbering kernels (kTile positions)
@@ -531,6 +559,7 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     const size_t per_tile = (size_t)kSortThreads * p.sort_e;
     p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
     p.count = (int32_t *)take((size_t)p.sort_tiles * kMaxDigits * 4);
+    p.mapped = (int32_t *)take((size_t)2 * p.sort_tiles * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
     p.tile_sums = (int2 *)take((size_t)2 * p.ntiles * 8);
@@ -550,7 +579,7 @@ static int ceil_log2(int32_t v)
 // pass; side = 1 row, 2 col.
 template <int E>
 static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t B, int bits, const PlanWs &pw, SortOut last,
-                        int side, int32_t *n_mapped, hipStream_t st)
+                        int side, hipStream_t st)
 {
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P;
     for (int p = 0; p < P; ++p) {
@@ -563,7 +592,7 @@ static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t 
         in.db = db;
         in.ntiles = pw.sort_tiles;
         in.count = pw.count;
-        in.n_mapped = n_mapped;
+        in.mapped = pw.mapped;
         hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
         if (p < P - 1) {
             SortOut out = last;
@@ -599,7 +628,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (!plan || !ws || B < 0 || V <= 0 || plan->chunk_cap <= 0 || plan->B != B || !plan->counts) return GLOVE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
-        HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
+        HIP_TRY(zero_words(plan->counts, 8, st));
         return 0;
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
@@ -616,7 +645,6 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
         if (int rc = plan_build_small(row, col, w, y, B, V, plan, st)) return rc;
         return plan->r_crec ? launch_fill_records(plan, st) : 0;
     }
-    HIP_TRY(hipMemsetAsync(plan->counts, 0, 8 * sizeof(int32_t), st));
     const PlanWs pw = carve_plan_ws(ws, B);
     if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
 
@@ -635,8 +663,8 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     co.c_perm = plan->c_perm; co.c_partner = plan->c_partner; co.r_to_c = plan->r_to_c;
     co.c_w = plan->c_w; co.c_y = plan->c_y;
 #define SORTS(E)                                                                                              \
-    launch_sort<E>(row, Vr, B, bits, pw, ro, 1, plan->counts + 5, st);                                        \
-    launch_sort<E>(plan->r_partner, 0, B, bits, pw, co, 2, plan->counts + 5, st)
+    launch_sort<E>(row, Vr, B, bits, pw, ro, 1, st);                                                          \
+    launch_sort<E>(plan->r_partner, 0, B, bits, pw, co, 2, st)
     if (pw.sort_e == 4) { SORTS(4); } else if (pw.sort_e == 8) { SORTS(8); } else { SORTS(16); }
 #undef SORTS
 
@@ -652,7 +680,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                             {plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_uniq_rec, plan->c_uniq_rec}};
     hipLaunchKernelGGL(emit_uniq_rec, dim3(blocks_for(plan->cap_uniq, kBlock), 2), dim3(kBlock), 0, st,
                        (const int32_t *)plan->counts, ua, plan->heavy_chunks, plan->cap_heavy, plan->heavy,
-                       plan->counts + 4);
+                       plan->counts + 4, (const int32_t *)pw.mapped, 2 * pw.sort_tiles, plan->counts + 5);
     if (plan->r_crec) return launch_fill_records(plan, st);
     return (int)hipGetLastError();
 }

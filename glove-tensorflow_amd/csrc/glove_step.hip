@@ -2003,7 +2003,7 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
 #undef CALL
     }
     if (scratch) {
-        hipError_t e = hipMemsetAsync(scratch, 0, 4 * sizeof(float), st);      // the tail is all zero between steps
+        hipError_t e = zero_words(scratch, 4, st);      // the tail is all zero between steps
         if (e != hipSuccess) return (int)e;
     }
     return (int)hipGetLastError();
