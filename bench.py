@@ -406,7 +406,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 
     log("  %.1f ms per index; warm-up and capture" % plan_build_ms)
     # One hipGraph holds `spg` consecutive steps, a divisor of --steps: the timed region is a whole number of replays.
-    use_graph = mode == "single" and not no_graph
+    # (a multi-rank step is captured with its collectives when the transport is RCCL; a gloo rehearsal launches eagerly)
+    from trainer.stepper import transport_is_capturable
+    use_graph = not no_graph and (mode == "single" or transport_is_capturable(dist, getattr(stepper, "_multi", False)))
     graph, spg = None, steps_per_graph(steps)
     if use_graph:
         side = torch.cuda.Stream()

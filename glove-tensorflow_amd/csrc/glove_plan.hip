@@ -30,10 +30,10 @@ __device__ inline int wave_sum_int(int v)
 // the ROW-SORTED pairs by col id.  Keys are ids below V, i.e. ceil(log2 V) bits: P = ceil(bits / 8) passes over digits of
 // db = ceil(bits / P) bits (V = 10 k: two passes of 7 bits; V = 2 M: three of 7), least significant digit first, every pass
 // stable.  A pass is two launches over tiles of kSortThreads x E consecutive positions, one workgroup each:
-//   radix_hist     count[tile][digit] = keys of the tile with that digit (every entry written: nothing relies on zeroed memory)
+//   radix_hist     count[digit][tile] = keys of the tile with that digit (every entry written: nothing relies on zeroed memory)
 //   radix_scatter  position of a key = keys of smaller digits anywhere + keys of its digit in earlier tiles (both summed
-//                  from the count table by the workgroup itself: thread d walks column d) + keys of its digit earlier in
-//                  its own tile (its stable local rank)
+//                  from the count table by the workgroup itself: thread d reads row d, 128 tiles per round trip) + keys of
+//                  its digit earlier in its own tile (its stable local rank)
 // Local ranks come from wave ballots: a wave takes 64 consecutive positions per round, the lanes holding the same digit
 // find each other with db ballots, the group's first lane fetches-and-adds the group's size to the wave's running count of
 // that digit (LDS atomic with return: rounds and peers are ordered by construction) and hands the old value round.
@@ -45,6 +45,7 @@ __device__ inline int wave_sum_int(int v)
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kMaxDigits = 256;
+constexpr int kWalk = 16;                                 // 16-byte loads of a count-table row in flight per thread (= 128 tiles)
 
 struct SortIn {
     const int32_t *keys;        // [n] keys of this pass, in the order the previous pass left them
@@ -53,7 +54,8 @@ struct SortIn {
     int32_t clean_below;        // > 0: first pass over raw ids: anything outside [0, clean_below) counts as id 0
     int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
     int ntiles;
-    int32_t *count;             // [ntiles][1 << db]
+    uint16_t *count;            // [1 << db][tile_stride]: row d = every tile's count of digit d (a tile holds < 65536 keys);
+    int tile_stride;            // ntiles rounded up to a multiple of 8 (16-byte rows); the padding is never written or used
     int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (row ids: radix_hist of the first pass;
                                 // col ids: the row side's last radix_scatter).  Every entry is written by every build —
                                 // no counter to zero, no atomics; emit_uniq_rec adds them up into plan counts[5]
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
         if (valid && lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[digit], __popcll(peers));
     }
     __syncthreads();
-    if ((int)threadIdx.x < nd) in.count[(size_t)blockIdx.x * nd + threadIdx.x] = hist[threadIdx.x];
+    if ((int)threadIdx.x < nd) in.count[(size_t)threadIdx.x * in.tile_stride + blockIdx.x] = (uint16_t)hist[threadIdx.x];
     // ids the cleaning mapped to 0 are reported once, by the pass that first sees the raw ids
     if (in.clean_below > 0) block_store_sum(mapped, in.mapped + blockIdx.x);
 }
@@ -148,20 +150,41 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
     __shared__ int wcnt[kSortWaves][kMaxDigits];          // a wave's running digit counts; then every wave's bases
     __shared__ int scan_red[kSortWaves];
     const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < kSortWaves * kMaxDigits; i += kSortThreads) (&wcnt[0][0])[i] = 0;
-    __syncthreads();
+    // The kernel is a chain of short memory round trips on a few hundred workgroups: everything that does not depend on
+    // the keys is requested up front, in the order it is needed (vector loads return in order), and consumed later.
     const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
-    int32_t key[E], rank[E];
+    int32_t key[E], rank[E], val[E];
     int mapped = 0;
     sort_load_keys<E>(in, base, key, mapped);
     mapped = 0;                                           // (row ids mapped to 0 are counted by radix_hist)
-    int32_t val[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t i = base + j * 64 + lane;
         val[j] = in.vals ? (i < in.n ? in.vals[i] : 0) : (int32_t)i;
     }
-    // ---- stable rank of every key among the keys of its digit in this wave's range
+    // row d of the count table (thread d; 16-bit counts, one row = the tiles' counts of digit d): the first kWalk x 8 tiles
+    const int d_mine = (int)threadIdx.x < nd ? (int)threadIdx.x : 0;
+    const uint4 *rowp = reinterpret_cast<const uint4 *>(in.count + (size_t)d_mine * in.tile_stride);
+    const int nq = in.tile_stride / 8;                    // uint4 per row
+    uint4 cw[kWalk];
+#pragma unroll
+    for (int x = 0; x < kWalk; ++x) cw[x] = rowp[x < nq ? x : 0];
+    // what the last pass pulls through the permutation (depends on the values only)
+    int32_t g_id[E];
+    float g_w[E], g_y[E];
+    if (LAST != 0) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool valid = base + j * 64 + lane < in.n;
+            const int32_t p = valid ? val[j] : 0;
+            g_id[j] = LAST == 1 ? out.col[p] : out.row_sorted[p];
+            g_w[j] = LAST == 1 ? out.w[p] : out.in_w[p];
+            g_y[j] = LAST == 1 ? out.y[p] : out.in_y[p];
+        }
+    }
+    // ---- stable rank of every key among the keys of its digit in this wave's range (a wave zeroes and uses its own
+    // counters: LDS operations of one wave complete in order, no barrier)
+    for (int i = lane; i < kMaxDigits; i += 64) wcnt[wave][i] = 0;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const bool valid = base + j * 64 + lane < in.n;
@@ -173,26 +196,27 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
         before = __shfl(before, leader, 64);
         rank[j] = before + __popcll(peers & ((1ull << lane) - 1ull));
     }
-    __syncthreads();
-    // ---- thread d: column d of the count table -> where the keys of digit d of this tile start
+    // ---- thread d: keys of digit d in all tiles / in the tiles before this one
     int all = 0, earlier = 0;
-    if ((int)threadIdx.x < nd) {
-        const int32_t *colp = in.count + threadIdx.x;
-        const int me = blockIdx.x;
-        int t = 0;
-        for (; t + 8 <= in.ntiles; t += 8) {              // eight independent loads in flight
-            int c[8];
+    const int me = blockIdx.x;
+    for (int q0 = 0; q0 < nq; q0 += kWalk) {
+        if (q0 > 0) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x) c[x] = colp[(size_t)(t + x) * nd];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) { all += c[x]; earlier += (t + x < me) ? c[x] : 0; }
+            for (int x = 0; x < kWalk; ++x) cw[x] = rowp[q0 + x < nq ? q0 + x : 0];
         }
-        for (; t < in.ntiles; ++t) {
-            const int c = colp[(size_t)t * nd];
-            all += c;
-            earlier += (t < me) ? c : 0;
+#pragma unroll
+        for (int x = 0; x < kWalk; ++x) {
+            const uint32_t wd[4] = {cw[x].x, cw[x].y, cw[x].z, cw[x].w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int t = (q0 + x) * 8 + h;
+                const int c = (int)((wd[h >> 1] >> (16 * (h & 1))) & 0xffffu);
+                all += (q0 + x < nq && t < in.ntiles) ? c : 0;      // (the row's padding behind the last tile is never written)
+                earlier += (q0 + x < nq && t < me) ? c : 0;
+            }
         }
     }
+    if ((int)threadIdx.x >= nd) all = earlier = 0;
     // exclusive scan of `all` over the digits (threads): wave scan, then the four wave totals
     int incl = all;
 #pragma unroll
@@ -228,18 +252,18 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
             out.vals[dest] = p;
         } else if (LAST == 1) {
             out.sorted_keys[dest] = key[j];
-            int32_t c = out.col[p];
+            int32_t c = g_id[j];
             if ((uint32_t)c >= (uint32_t)out.V) { c = 0; ++mapped; }
             out.r_partner[dest] = c;
-            out.r_w[dest] = out.w[p];
-            out.r_y[dest] = out.y[p];
+            out.r_w[dest] = g_w[j];
+            out.r_y[dest] = g_y[j];
         } else {
             out.sorted_keys[dest] = key[j];
             out.c_perm[dest] = p;
             out.r_to_c[p] = dest;
-            out.c_partner[dest] = out.row_sorted[p];
-            out.c_w[dest] = out.in_w[p];
-            out.c_y[dest] = out.in_y[p];
+            out.c_partner[dest] = g_id[j];
+            out.c_w[dest] = g_w[j];
+            out.c_y[dest] = g_y[j];
         }
     }
     if (LAST == 1) block_store_sum(mapped, in.mapped + in.ntiles + blockIdx.x);     // col ids mapped to 0
@@ -529,7 +553,8 @@ struct PlanWs {
     int32_t *keys[2], *vals[2];      // ping-pong buffers of the sort passes
     int32_t *row_sorted;             // row ids in row-side order
     int32_t *col_sorted;             // col ids in col-side order
-    int32_t *count;                  // [sort tiles][digits] of the pass in flight
+    uint16_t *count;                 // [digits][tile_stride] of the pass in flight
+    int tile_stride;
     int32_t *mapped;                 // [2][sort tiles] ids mapped to 0 per tile (row ids, col ids)
     int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
     int2 *tile_sums;                 // [2][ntiles] (ids, chunks) opened inside a tile
@@ -558,7 +583,8 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.sort_e = sort_e_for(B);
     const size_t per_tile = (size_t)kSortThreads * p.sort_e;
     p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
-    p.count = (int32_t *)take((size_t)p.sort_tiles * kMaxDigits * 4);
+    p.tile_stride = (p.sort_tiles + 7) / 8 * 8;
+    p.count = (uint16_t *)take((size_t)p.tile_stride * kMaxDigits * 2);
     p.mapped = (int32_t *)take((size_t)2 * p.sort_tiles * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
@@ -592,6 +618,7 @@ static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t 
         in.db = db;
         in.ntiles = pw.sort_tiles;
         in.count = pw.count;
+        in.tile_stride = pw.tile_stride;
         in.mapped = pw.mapped;
         hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
         if (p < P - 1) {

@@ -61,10 +61,13 @@ FLAGS = (
     Flag("save-checkpoints-secs", float, 300.0, "seconds between checkpoints (each followed by an eval pass)"),
     Flag("keep-checkpoint-max", int, 5, "checkpoints kept in the job directory"),
     Flag("skip-eval", None, False, "checkpoint without the eval pass"),
-    Flag("epoch-shuffle", str, "static", "static: the pairs are permuted once, cut into batches whose dedup index is "
-                                         "built at load, and every epoch visits the batches in a new order; full: a "
-                                         "new permutation of the pairs every epoch (single GPU), indexes built as "
-                                         "the batches are used"),
+    Flag("epoch-shuffle", str, "full", "full (default, what the reference's input_fn does — make_csv_dataset reshuffles every "
+                                       "epoch): every rank draws a new permutation of its pairs every epoch, the dedup "
+                                       "index of a batch is built when the batch is used; static: the pairs are permuted "
+                                       "once, cut into batches whose index is built at load, and every epoch visits the "
+                                       "same batches in a new order (faster: no index build per step)"),
+    Flag("no-graphs", None, False, "with --epoch-shuffle full: launch every build and step from Python instead of replaying "
+                                   "captured hipGraphs"),
     Flag("build-ahead", int, 4, "index builds in flight with --epoch-shuffle full"),
     Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
                                      "nonzero to the rank that owns its row, instead of replicating all tables "

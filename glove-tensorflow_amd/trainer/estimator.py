@@ -88,11 +88,9 @@ class Estimator:
         self.ckpt.restore(self.model.tables, shard=(self.world, self.rank) if self.row_sharded else None)
         self._stream = None
         self._events = {}
-        self.reshuffling = params.get("epoch_shuffle", "static") == "full"
-        if params.get("epoch_shuffle", "static") not in ("static", "full"):
+        self.reshuffling = params.get("epoch_shuffle", "full") == "full"
+        if params.get("epoch_shuffle", "full") not in ("static", "full"):
             raise ValueError("--epoch-shuffle must be static or full, got %r" % (params["epoch_shuffle"],))
-        if self.reshuffling and (self.world > 1 or not hasattr(self.backend, "hip")):
-            raise ValueError("--epoch-shuffle full runs on one GPU (the data-parallel stream is static)")
         self.logistic = params.get("head", "regression") == "logistic"
 
     # ---- input_fn
@@ -145,22 +143,31 @@ class Estimator:
         if self.logistic:       # logistic_matrix_factorisation.py:50-54: the stream's (w, y) are (pos, neg) weights
             hyper_kwargs.update(head=1, neg_factor=p.get("neg_factor", 1.0))
         log_every = max(1, int(p.get("log_every", 100)))
-        if self.reshuffling:
-            from trainer.stepper import ReshufflingRunner
-            stepper = ReshufflingRunner(self.backend.hip, stream, tables,
-                                        self.backend.make_hyper(batch_size=p["batch_size"], **hyper_kwargs),
-                                        chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4),
-                                        burst=min(log_every, 100))      # graphs of ~100 steps replay fastest (measured)
-        elif self.row_sharded:
+        # a reshuffled stream has no resident plans: the exchange is agreed from the batch size (prepare(batch_size=...))
+        plans_or_size = dict(batch_size=p["batch_size"]) if self.reshuffling else dict(plans=stream.plans)
+        if self.row_sharded:
             from trainer.stepper import RowShardedStepper
             stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
                                         exchange=p.get("exchange", "auto"))
-            stepper.prepare(stream.plans)           # collective: the ranks agree on the col-side exchange
-        else:
+            stepper.prepare(**plans_or_size)        # collective: the ranks agree on the col-side exchange
+        elif self.world > 1 or not self.reshuffling:
             stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
                               exchange=p.get("exchange", "auto"))
             if self.world > 1:
-                stepper.prepare(stream.plans)       # collective: dense all-reduce or touched-rows all-gather
+                stepper.prepare(**plans_or_size)    # collective: dense all-reduce or touched-rows all-gather
+        else:
+            stepper = None
+        if stepper is not None and not self.reshuffling and not p.get("no_graphs", False):
+            stepper.enable_graphs()                 # a resident batch's step (kernels + RCCL collectives) replayed from a hipGraph
+        if self.reshuffling:
+            # every rank re-permutes ITS shard of the stream each epoch (reference data_utils.py:12-21 reshuffles every
+            # epoch); on one GPU the runner steps by itself, on several through the stepper above
+            from trainer.stepper import ReshufflingRunner
+            stepper = ReshufflingRunner(getattr(self.backend, "hip", None), stream, tables,
+                                        self.backend.make_hyper(batch_size=p["batch_size"] * self.world, **hyper_kwargs),
+                                        chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4),
+                                        burst=min(log_every, 100),      # graphs of ~100 steps replay fastest (measured)
+                                        stepper=stepper, graphs=not p.get("no_graphs", False))
         fresh = self.ckpt.latest() is None
         if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
             flag = torch.tensor([1 if fresh else 0], device=self.device)

@@ -187,7 +187,48 @@ def all_gather_rows(dist, recv, send, async_op=False):
         return dist.all_gather([recv[r] for r in range(recv.shape[0])], send, async_op=async_op)
 
 
-class Stepper:
+def transport_is_capturable(dist, multi: bool) -> bool:
+    """Can a step be captured into a hipGraph?  Its kernels always; its collectives only on RCCL ("nccl" backend)."""
+    return not multi or (dist is not None and dist.get_backend() == "nccl")
+
+
+class GraphedSteps:
+    """Steps of a static stream replayed from hipGraphs: ONE graph per resident batch holds every launch of its step —
+    the kernels and, on RCCL, the collectives (an asynchronous all-to-all is captured on its side stream, joined where
+    the step waits for it) — so a multi-rank step costs one graph launch instead of six or more launches plus a
+    collective from Python.  A batch's step is captured the third time the batch comes round (short runs never pay for
+    captures they do not replay); until then, and on a transport that cannot be captured (gloo), steps run eagerly.
+    Same launches in the same order either way: same bits."""
+
+    def enable_graphs(self, limit=4096, after=2):
+        if self.tables.device.type == "cuda" and transport_is_capturable(self.dist, self._multi):
+            self._graphs, self._seen, self._graph_limit, self._graph_after = {}, {}, int(limit), int(after)
+
+    def step(self, item):
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None:
+            return self.step_eager(item)
+        key = item if isinstance(item, int) else id(item)
+        g = graphs.get(key)
+        if g is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self._graph_after or len(graphs) >= self._graph_limit:
+                return self.step_eager(item)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step_eager(item)
+            graphs[key] = (g, item)             # the graph holds raw pointers into the plan: keep the plan alive
+            g = graphs[key]
+        g[0].replay()
+
+    def step_eager(self, item):
+        for _, fn in self.phases():
+            fn(item)
+
+
+class Stepper(GraphedSteps):
     """`exchange`: "dense" = all-reduce of the flat dense gradient buffer; "rows" = all-gather of packed touched-row
     lists (Adagrad); "auto" = rows when `prepare(plans)` finds the ranks' lists together shorter than the dense
     buffer, else dense."""
@@ -213,14 +254,19 @@ class Stepper:
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(self.G.numel()) if self.G is not None else 0
 
-    def prepare(self, plans, force_world=None):
-        """Static stream: agree (collectively) on the exchange from the id counts of every rank's resident plans."""
+    def prepare(self, plans=None, force_world=None, batch_size=None):
+        """Agree (collectively) on the exchange.  Static stream: from the id counts of every rank's resident plans.
+        Stream whose batches are indexed as they are used (`plans` None, `batch_size` given: reshuffled epochs): from the
+        most ids a batch of that size can touch — the lists' capacity has to hold any batch."""
         world = self.world if force_world is None else force_world
         if self.tables.optimizer != "Adagrad" or self.exchange == "dense" or (world == 1 and not self._multi and self.exchange != "rows"):
             return
         if self.G is None:
             self.G, self.dense = self.backend.dense_grad_buffer(self.tables), True
-        most = max(sum(self.backend.id_counts(p)) for p in plans)
+        if plans is None:
+            most = min(int(batch_size), self.tables.V_row) + min(int(batch_size), self.tables.V)
+        else:
+            most = max(sum(self.backend.id_counts(p)) for p in plans)
         if self._multi:
             t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -252,10 +298,6 @@ class Stepper:
         ph.append(("dense_apply", lambda p: b.apply_dense(t, h, self.G, self.loss_out)))
         return ph
 
-    def step(self, plan):
-        for _, fn in self.phases():
-            fn(plan)
-
     def step_many(self, plans):
         """Several consecutive steps; on one GPU they are issued by one C call."""
         if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
@@ -263,10 +305,8 @@ class Stepper:
         elif (not self._multi and self.tables.optimizer == "Adam" and not self.rows and hasattr(self.backend, "steps_dense_adam")):
             self.backend.steps_dense_adam(plans, self.tables, self.hyper, self.G, self.loss_out)
         else:
-            ph = self.phases()
             for plan in plans:
-                for _, fn in ph:
-                    fn(plan)
+                self.step(plan)
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
@@ -303,7 +343,7 @@ def route_by_row_owner(coo: dict, world: int, rank: int, dist) -> dict:
     return out
 
 
-class RowShardedStepper:
+class RowShardedStepper(GraphedSteps):
     """Model-parallel form of BASELINE config 5.  The row table R / br (and their Adagrad accumulators) are
     sharded by row id % world; the col table, the global bias and their slots are replicated.  Every rank
     steps on nonzeros whose rows it owns (see route_by_row_owner), so
@@ -338,11 +378,12 @@ class RowShardedStepper:
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(backend.col_half(tables, self.G).numel()) if self.G is not None else 0
 
-    def prepare(self, plans):
-        """Static stream: agree (collectively) on the col-side exchange from the col id counts of all resident plans."""
+    def prepare(self, plans=None, batch_size=None):
+        """Agree (collectively) on the col-side exchange: from the col id counts of all resident plans (static stream) or,
+        for batches indexed as they are used (`plans` None), from the most col ids a batch of `batch_size` pairs can touch."""
         if not self._multi or self.exchange == "dense":
             return
-        most = max(self.backend.id_counts(p)[1] for p in plans)
+        most = min(int(batch_size), self.tables.V) if plans is None else max(self.backend.id_counts(p)[1] for p in plans)
         t = torch.tensor([most], dtype=torch.int64, device=self.tables.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         capacity = 1 + int(t.item())
@@ -389,10 +430,6 @@ class RowShardedStepper:
                    ("dense_adagrad_cols", lambda p: b.apply_dense(t, self.hyper_cols, self.G, self.loss_out))]
         return ph
 
-    def step(self, plan):
-        for _, fn in self.phases():
-            fn(plan)
-
     def finish_async(self):
         """Waits for the collective a phase started (for callers that time the phases one by one)."""
         if self._gather is not None:
@@ -400,17 +437,15 @@ class RowShardedStepper:
             self._gather = None
 
     def step_many(self, plans):
-        ph = self.phases()
         for plan in plans:
-            for _, fn in ph:
-                fn(plan)
+            self.step(plan)
 
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
         return {"loss": loss, "weighted_mse": L, "regularization_loss": reg}
 
 
-class ShardedStepper:
+class ShardedStepper(GraphedSteps):
     """BASELINE config 5 with BOTH tables sharded ("row-embedding table sharded across 8 GPUs with all-to-all token-id
     routing", SURVEY.md §8e): row u and col v live on ranks u % world and v % world at local index // world, with their
     Adagrad accumulators; only the global bias is replicated.  Nonzeros are routed to the owners of their ROWS
@@ -437,7 +472,7 @@ class ShardedStepper:
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
-        self.batches, self.bufs, self.view, self.owner_state = [], None, None, {}
+        self.batches, self.bufs, self.view, self.owner_state, self._caps, self._dirty = [], None, None, {}, (0, 0), True
         self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials, summed over ranks
         self._push = None                       # the col gradients' all-to-all while it is in flight
         if hasattr(backend, "shard_rows"):
@@ -468,13 +503,25 @@ class ShardedStepper:
         n_uc = int(uc.numel())
         plan = self.backend.build_plan(row, compact, w, y, max(n_uc, self.tables.V_row), chunk_cap)
         self.batches.append(dict(plan=plan, want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l)))
-        self.bufs = None                                                 # capacities may have grown
+        self._dirty = True                                               # capacities may have grown
         return len(self.batches) - 1
 
+    def clear_batches(self):
+        """Forgets the prepared batches (a reshuffled epoch prepares its own); the fetch buffers are kept while they fit."""
+        self.batches = []
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs, self._seen = {}, {}       # graphs of the old batches point at their plans
+
     def _ready(self):
-        if self.bufs is None:
-            cap = max(b["n"] for b in self.batches)
-            self.bufs = self.backend.fetch_buffers(self.tables, cap, max(b["ns"] for b in self.batches))
+        if not self._dirty:
+            return
+        self._dirty = False
+        cap, scap = max(b["n"] for b in self.batches), max(b["ns"] for b in self.batches)
+        if self.bufs is None or cap > self._caps[0] or scap > self._caps[1]:
+            self._caps = (cap, scap)
+            if getattr(self, "_graphs", None) is not None:
+                self._graphs, self._seen = {}, {}   # captured steps point into the old buffers
+            self.bufs = self.backend.fetch_buffers(self.tables, cap, scap)
             self.view = self.backend.col_view(self.tables, self.bufs, cap)
             self.payload_floats = 2 * cap * (self.tables.d + 1)
 
@@ -526,10 +573,6 @@ class ShardedStepper:
                 ("owner_apply_cols", lambda i: b.owner_apply(t, self.owner_state, f["recv"], bt[i]["serve_idx"], bt[i]["serve"],
                                                              self.hyper, self.tail, self.loss_out))]
 
-    def step(self, i: int):
-        for _, fn in self.phases():
-            fn(i)
-
     def finish_async(self):
         """Waits for the collective a phase started (for callers that time the phases one by one)."""
         if self._push is not None:
@@ -542,46 +585,84 @@ class ShardedStepper:
 
 
 class ReshufflingRunner:
-    """Single-GPU training over a stream whose pairs are re-permuted every epoch (`--epoch-shuffle full`): the
-    batches are new every epoch, so their dedup index is built when they are used — like an input pipeline that
-    prefetches batches, `ahead` index builds are in flight on their own streams and staging plans while earlier
-    steps run.  A burst of consecutive batches [first, first + count) is captured ONCE as a hipGraph (builds,
-    steps and their cross-stream dependencies) and replayed in every later epoch: the graph reads the batch
-    positions of the stream's buffers, which `NonzeroStream.reshuffle_in_place` refills.
+    """Training over a stream whose pairs are re-permuted every epoch (`--epoch-shuffle full`, the reference's
+    `make_csv_dataset(shuffle=True, num_epochs=None)`, data_utils.py:12-21): the batches are new every epoch, so their
+    dedup index is built when they are used.  One GPU, or any of the multi-GPU forms through its `stepper`:
+
+      * single GPU / data parallel / row-sharded (`Stepper`, `RowShardedStepper`): every rank permutes ITS shard of the
+        stream (no pair changes rank) and indexes each batch into a staging plan just before the step — like an input
+        pipeline that prefetches batches, `ahead` index builds are in flight on their own streams and staging plans while
+        earlier steps run.  A burst of consecutive batches [first, first + count) is captured ONCE as a hipGraph (builds,
+        steps, their cross-stream dependencies and — on RCCL — the collectives) and replayed in every later epoch: the
+        graph reads the batch positions of the stream's buffers, which `NonzeroStream.reshuffle_in_place` refills;
+      * both tables sharded (`ShardedStepper`): a batch also needs its fetch lists agreed between the ranks
+        (`add_batch`, collective), so the epoch's batches are prepared together when the epoch starts and stepped through
+        in order.
+
+    With a test backend (no `hip`: the gloo tests on CPU) the same sequence runs eagerly, one synchronous build per step.
+    On one rank every form gives exactly what the single-GPU runner gives.
     """
 
-    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128):
+    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True):
         from trainer.hip_api import auto_chunk_cap
-        self.hip, self.stream, self.tables, self.hyper = hip, stream, tables, hyper
+        self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
         self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
+        self.graphs_on = bool(graphs) and hip is not None and (
+            stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
+        self.sharded = isinstance(stepper, ShardedStepper)
+        self.loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, dtype=torch.float32, device=tables.device)
+        self.graphs = {}
+        self.position = 0                      # next batch of the current epoch
+        self.handles = None                    # both tables sharded: the epoch's prepared batches
+        # batches per epoch: the ranks' shards differ in length (by one pair data parallel, by the ownership of the rows
+        # when routed), epochs end together: everybody steps through as many batches as the shortest shard has — the
+        # pairs behind them wait for the next permutation, like the `nnz mod B` behind a rank's last full batch
+        self.nb = stream.batches_per_epoch
+        if stepper is not None and stepper._multi:
+            t = torch.tensor([self.nb], dtype=torch.int64, device=tables.device)
+            stepper.dist.all_reduce(t, op=stepper.dist.ReduceOp.MIN)
+            self.nb = int(t.item())
+        stream.reshuffle_in_place()
+        if self.sharded:
+            self._prepare_epoch()
+            return
+        if hip is None:
+            return
         dev, B, V = tables.device, stream.B, stream.V
-        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap) for _ in range(self.ahead)]
+        shard_rows = tables.V_row if tables.V_row < tables.V else 0          # row-sharded: the stream carries shard-local row ids
+        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows) for _ in range(self.ahead)]
         self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
                         for _ in range(self.ahead)]
         self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
-        self.G = hip.dense_grad_buffer(tables) if tables.optimizer == "Adam" else None
-        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.graphs = {}
-        self.position = 0                      # next batch of the current epoch
-        stream.reshuffle_in_place()
-        # every kernel of the sequence is launched once outside any capture (on throw-away tables of the same shape)
+        self.G = hip.dense_grad_buffer(tables) if stepper is None and tables.optimizer == "Adam" else None
+        # every kernel (and collective) of the sequence runs once outside any capture, on throw-away tables of the same shape
         from trainer.hip_api import DeviceTables
         real = self.tables
-        self.tables = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
+        scratch = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
+        self._swap_tables(scratch)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._issue(0, min(self.ahead + 1, stream.batches_per_epoch))
+            self._issue(0, min(self.ahead + 1, self.nb))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.tables = real
+        self._swap_tables(real)
         if self.G is not None:
             self.G.zero_()
+        if stepper is not None and getattr(stepper, "G", None) is not None:
+            stepper.G.zero_()
+
+    def _swap_tables(self, tables):
+        self.tables = tables
+        if self.stepper is not None:
+            self.stepper.tables = tables
 
     def _step(self, plan):
-        if self.G is None:
+        if self.stepper is not None:
+            self.stepper.step(plan)
+        elif self.G is None:
             self.hip.step_adagrad(plan, self.tables, self.hyper, self.loss_out, self.step_ws)
         else:
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
@@ -611,25 +692,39 @@ class ReshufflingRunner:
             if i + self.ahead < count:
                 launch_build(i + self.ahead)
 
+    def _prepare_epoch(self):
+        """Both tables sharded: the fetch lists and indexes of all batches of the epoch (collective)."""
+        self.stepper.clear_batches()
+        self.handles = [self.stepper.add_batch(*self.stream.batch(b), self.cap) for b in range(self.nb)]
+
     def run(self, n_steps: int) -> int:
         """Up to `n_steps` steps, never across an epoch boundary or a burst boundary; returns the number done."""
-        nb = self.stream.batches_per_epoch
+        nb = self.nb
         if self.position >= nb:
             self.stream.reshuffle_in_place()
             self.position = 0
+            if self.sharded:
+                self._prepare_epoch()
         first = self.position
         count = min(n_steps, nb - first, self.burst - first % self.burst)
-        key = (first, count)
-        if key not in self.graphs and len(self.graphs) < 256:
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._issue(first, count)
-            self.graphs[key] = graph
-        if key in self.graphs:
-            self.graphs[key].replay()
+        if self.sharded:
+            for b in range(first, first + count):
+                self.stepper.step(self.handles[b])
+        elif self.hip is None:                     # a test backend: one synchronous build per step
+            for b in range(first, first + count):
+                self.stepper.step(self.stepper.backend.build_plan(*self.stream.batch(b), self.stream.V, self.cap))
         else:
-            self._issue(first, count)              # cache full: same sequence, launched eagerly
+            key = (first, count)
+            if self.graphs_on and key not in self.graphs and len(self.graphs) < 256:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._issue(first, count)
+                self.graphs[key] = graph
+            if key in self.graphs:
+                self.graphs[key].replay()
+            else:
+                self._issue(first, count)              # no graphs, or cache full: same sequence, launched eagerly
         self.position += count
         return count
 

@@ -216,3 +216,123 @@ def test_every_nonzero_lands_on_exactly_one_rank(tmp_path, routed):
     assert sum(int(p["nnz"]) for p in parts) == 1001
     if routed:
         assert int(parts[0]["nnz"]) != int(parts[1]["nnz"])    # unbalanced ownership, and still nothing dropped
+
+
+# ---- reshuffled epochs (--epoch-shuffle full, the reference's make_csv_dataset(shuffle=True, num_epochs=None)) on several ranks
+RB, RN, RSTEPS = 40, 403, 24            # 201 / 202 pairs per rank -> 5 batches per epoch: 24 steps cross four epoch boundaries
+
+
+class _Recorder:
+    """Wraps a kernel provider: remembers the batch of every index it builds (the order the steps consume them in)."""
+
+    def __init__(self, inner):
+        self.inner, self.seen = inner, []
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def build_plan(self, row, col, w, y, V, chunk_cap):
+        self.seen.append(tuple(np.array(a) for a in (row, col, w, y)))
+        return self.inner.build_plan(row, col, w, y, V, chunk_cap)
+
+
+def _reshuffle_worker(rank, port, out_dir, form):
+    for p in (HERE.parent, HERE.parent / "oracle", HERE):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    import glove_ref as ref
+    from oracle_backend import OracleBackend, OracleTables
+    from trainer.data_utils import NonzeroStream
+    from trainer.stepper import ReshufflingRunner, RowShardedStepper, ShardedStepper, Stepper
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    rng = np.random.default_rng(0)
+    coo = dict(row=rng.integers(0, V, RN).astype(np.int32), col=rng.integers(0, V, RN).astype(np.int32),
+               w=np.arange(RN, dtype=np.float32) + 1.0, y=rng.normal(size=RN).astype(np.float32))    # w = the pair's serial number
+    full = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    shard = full.copy()
+    sharded_names = {"dp_dense": (), "dp_rows": (), "rowsharded": ("R", "br", "A_R", "A_br"),
+                     "sharded": ("R", "br", "A_R", "A_br", "C", "bc", "A_C", "A_bc")}[form]
+    for n in sharded_names:
+        setattr(shard, n, getattr(full, n)[rank::WORLD].copy())
+    tables = OracleTables(shard)
+    backend = _Recorder(OracleBackend())
+    stream = NonzeroStream(coo, RB, V, backend, "cpu", rank=rank, world=WORLD, seed=11, static_plans=False,
+                           route=dist if sharded_names else None)
+    kw = dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05)
+    if form == "sharded":
+        stepper = ShardedStepper(backend, tables, kw, RB, WORLD, rank, dist)
+    elif form == "rowsharded":
+        stepper = RowShardedStepper(backend, tables, kw, RB, WORLD, dist, exchange="rows")
+        stepper.prepare(batch_size=RB)
+    else:
+        stepper = Stepper(backend, tables, kw, RB, WORLD, dist, exchange="rows" if form == "dp_rows" else "dense")
+        stepper.prepare(batch_size=RB)
+        assert stepper.rows == (form == "dp_rows")
+    # routed streams differ in length between the ranks: the ranks agree on the number of steps, each cycles through its own epochs
+    runner = ReshufflingRunner(None, stream, tables, stepper.hyper, chunk_cap=8, burst=7, stepper=stepper)
+    done = 0
+    while done < RSTEPS:
+        done += runner.run(min(3, RSTEPS - done))         # bursts end at epoch / burst boundaries: all of them get crossed
+    # (both tables sharded: the epoch's batches are prepared together with renumbered col ids: no per-step record)
+    seen = backend.seen[-RSTEPS:] if form != "sharded" else None
+    np.savez(os.path.join(out_dir, "re%d.npz" % rank), R=shard.R, C=shard.C, br=shard.br, bc=shard.bc, g=shard.g, step=shard.step,
+             nnz=stream.nnz, bpe=runner.nb,
+             **({"b%d_%d" % (i, j): a for i, bt in enumerate(seen) for j, a in enumerate(bt)} if seen is not None else {}))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form", ["dp_dense", "dp_rows", "rowsharded"])
+def test_reshuffled_epochs_on_two_ranks_equal_one_rank_on_the_joint_stream(tmp_path, form):
+    """Every rank re-permutes ITS shard each epoch and indexes each batch when it is used; per step the ranks' batches
+    together are one global batch: two ranks == the oracle stepping on the joint stream, step by step.  Every epoch of a
+    rank visits each of its pairs at most once (the `nnz mod B` behind the last full batch wait for the next permutation)
+    and the batches of two epochs differ."""
+    sys.path.insert(0, str(HERE.parent / "oracle"))
+    import glove_ref as ref
+    port = 37500 + os.getpid() % 2000 + ["dp_dense", "dp_rows", "rowsharded"].index(form)
+    mp.spawn(_reshuffle_worker, args=(port, str(tmp_path), form), nprocs=WORLD, join=True)
+    ranks = [np.load(tmp_path / ("re%d.npz" % r)) for r in range(WORLD)]
+    t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
+    hp = ref.Hyper(learning_rate=0.05)
+    for s in range(RSTEPS):
+        parts = []
+        for r, rk in enumerate(ranks):
+            row, col, w, y = (rk["b%d_%d" % (s, j)] for j in range(4))
+            if form == "rowsharded":
+                row = row * WORLD + r                      # the routed stream carries shard-local row ids
+            parts.append((row, col, w, y))
+        ref.train_step(t, *[np.concatenate([p[i] for p in parts]) for i in range(4)], hp)
+    for r, rk in enumerate(ranks):
+        sl = slice(r, None, WORLD) if form == "rowsharded" else slice(None)
+        np.testing.assert_allclose(rk["R"], t.R[sl], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(rk["br"], t.br[sl], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(rk["C"], t.C, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(rk["g"], t.g, rtol=1e-10)
+        assert int(rk["step"]) == RSTEPS
+        # epochs: bpe batches each; within an epoch no pair twice, and the first batches of two epochs differ
+        bpe = int(rk["bpe"])
+        for e in range(RSTEPS // bpe):
+            serial = np.concatenate([rk["b%d_2" % s] for s in range(e * bpe, (e + 1) * bpe)])
+            assert len(np.unique(serial)) == len(serial) == bpe * RB
+        assert not np.array_equal(np.sort(rk["b0_2"]), np.sort(rk["b%d_2" % bpe]))
+    if form != "rowsharded":
+        np.testing.assert_array_equal(ranks[0]["C"], ranks[1]["C"])
+        np.testing.assert_array_equal(ranks[0]["R"], ranks[1]["R"])
+
+
+def test_reshuffled_epochs_with_both_tables_sharded(tmp_path):
+    """ShardedStepper under the reshuffling runner: the epoch's batches (fetch lists, renumbered col ids) are prepared
+    collectively when the epoch starts.  The model after 24 steps over four epoch boundaries is finite, every rank made
+    the same number of steps, and re-running gives the same bits (the permutations are seeded)."""
+    port = 39500 + os.getpid() % 2000
+    outs = []
+    for attempt in range(2):
+        d = tmp_path / ("run%d" % attempt)
+        d.mkdir()
+        mp.spawn(_reshuffle_worker, args=(port + attempt, str(d), "sharded"), nprocs=WORLD, join=True)
+        outs.append([np.load(d / ("re%d.npz" % r)) for r in range(WORLD)])
+    for r in range(WORLD):
+        for n in ("R", "C", "br", "bc", "g"):
+            assert np.isfinite(outs[0][r][n]).all()
+            np.testing.assert_array_equal(outs[0][r][n], outs[1][r][n])
+        assert int(outs[0][r]["step"]) == RSTEPS
