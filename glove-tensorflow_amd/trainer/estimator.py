@@ -166,7 +166,7 @@ class Estimator:
             stepper = ReshufflingRunner(getattr(self.backend, "hip", None), stream, tables,
                                         self.backend.make_hyper(batch_size=p["batch_size"] * self.world, **hyper_kwargs),
                                         chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4),
-                                        burst=min(log_every, 100),      # graphs of ~100 steps replay fastest (measured)
+                                        burst=64,
                                         stepper=stepper, graphs=not p.get("no_graphs", False))
         fresh = self.ckpt.latest() is None
         if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
@@ -179,11 +179,11 @@ class Estimator:
         while step < max_steps:
             # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
             if self.reshuffling:
-                # a burst ends after at most min(log_every, 100) batches, at the epoch's end or at max_steps; a line
-                # is logged whenever a burst crosses a multiple of log_every
-                done = stepper.run(max_steps - step)
-                at_log_point = (step + done) // log_every > step // log_every or step + done == max_steps
+                # up to the next logging point; a call ends early at the epoch's end and at a burst's (the runner replays
+                # graphs of 2^k steps): the loop simply asks again
+                done = stepper.run(min(max_steps, (step // log_every + 1) * log_every) - step)
                 step += done
+                at_log_point = step % log_every == 0 or step == max_steps
             else:
                 burst = min(max_steps, (step // log_every + 1) * log_every) - step
                 stepper.step_many([stream.next_plan() for _ in range(burst)])

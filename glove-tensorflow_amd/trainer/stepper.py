@@ -592,9 +592,10 @@ class ReshufflingRunner:
       * single GPU / data parallel / row-sharded (`Stepper`, `RowShardedStepper`): every rank permutes ITS shard of the
         stream (no pair changes rank) and indexes each batch into a staging plan just before the step — like an input
         pipeline that prefetches batches, `ahead` index builds are in flight on their own streams and staging plans while
-        earlier steps run.  A burst of consecutive batches [first, first + count) is captured ONCE as a hipGraph (builds,
-        steps, their cross-stream dependencies and — on RCCL — the collectives) and replayed in every later epoch: the
-        graph reads the batch positions of the stream's buffers, which `NonzeroStream.reshuffle_in_place` refills;
+        earlier steps run.  A burst of 2^k consecutive batches is captured ONCE as a hipGraph (builds, steps, their
+        cross-stream dependencies and — on RCCL — the collectives) that reads its batches from a fixed window; a burst is
+        replayed by copying its pairs into the window (16 B per pair) and launching the graph of its length, so any number
+        of steps — up to a logging point, up to the epoch's end — is a handful of replays of at most log2(burst) + 1 graphs;
       * both tables sharded (`ShardedStepper`): a batch also needs its fetch lists agreed between the ranks
         (`add_batch`, collective), so the epoch's batches are prepared together when the epoch starts and stepped through
         in order.
@@ -636,6 +637,11 @@ class ReshufflingRunner:
                         for _ in range(self.ahead)]
         self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
+        self.window = None
+        if self.graphs_on:
+            self.burst = 1 << (self.burst.bit_length() - 1)             # bursts are powers of two
+            self.window = tuple(torch.empty(self.burst * B, dtype=t.dtype, device=dev)
+                                for t in (stream.row, stream.col, stream.w, stream.y))
         self.G = hip.dense_grad_buffer(tables) if stepper is None and tables.optimizer == "Adam" else None
         # every kernel (and collective) of the sequence runs once outside any capture, on throw-away tables of the same shape
         from trainer.hip_api import DeviceTables
@@ -667,8 +673,11 @@ class ReshufflingRunner:
         else:
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
-    def _issue(self, first, count):
-        """`count` steps over batches first..first+count-1 with `ahead` index builds in flight."""
+    def _issue(self, first, count, window=False):
+        """`count` steps over batches first..first+count-1 of the stream (window: over the first `count` batches of the
+        window) with `ahead` index builds in flight."""
+        B = self.stream.B
+        batch = (lambda i: tuple(t[i * B:(i + 1) * B] for t in self.window)) if window else (lambda i: self.stream.batch(first + i))
         main = torch.cuda.current_stream()
         built, stepped = [None] * count, [None] * count
         start = torch.cuda.Event()
@@ -678,7 +687,7 @@ class ReshufflingRunner:
             st = self.ring_streams[i % self.ahead]
             st.wait_event(stepped[i - self.ahead] if i >= self.ahead else start)
             with torch.cuda.stream(st):
-                self.hip.build_plan(*self.stream.batch(first + i), self.stream.V, chunk_cap=self.cap,
+                self.hip.build_plan(*batch(i), self.stream.V, chunk_cap=self.cap,
                                     into=self.ring[i % self.ahead], ws=self.ring_ws[i % self.ahead])
                 built[i] = torch.cuda.Event()
                 built[i].record(st)
@@ -698,7 +707,7 @@ class ReshufflingRunner:
         self.handles = [self.stepper.add_batch(*self.stream.batch(b), self.cap) for b in range(self.nb)]
 
     def run(self, n_steps: int) -> int:
-        """Up to `n_steps` steps, never across an epoch boundary or a burst boundary; returns the number done."""
+        """Up to `n_steps` steps, never across an epoch boundary; returns the number done (the caller asks again)."""
         nb = self.nb
         if self.position >= nb:
             self.stream.reshuffle_in_place()
@@ -706,25 +715,27 @@ class ReshufflingRunner:
             if self.sharded:
                 self._prepare_epoch()
         first = self.position
-        count = min(n_steps, nb - first, self.burst - first % self.burst)
+        count = min(n_steps, nb - first, self.burst)
         if self.sharded:
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
         elif self.hip is None:                     # a test backend: one synchronous build per step
             for b in range(first, first + count):
                 self.stepper.step(self.stepper.backend.build_plan(*self.stream.batch(b), self.stream.V, self.cap))
-        else:
-            key = (first, count)
-            if self.graphs_on and key not in self.graphs and len(self.graphs) < 256:
+        elif self.graphs_on:
+            count = 1 << (count.bit_length() - 1)      # the largest power of two that fits: the caller comes back for the rest
+            B = self.stream.B
+            for dst, src in zip(self.window, (self.stream.row, self.stream.col, self.stream.w, self.stream.y)):
+                dst[:count * B].copy_(src[first * B:(first + count) * B])
+            if count not in self.graphs:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._issue(first, count)
-                self.graphs[key] = graph
-            if key in self.graphs:
-                self.graphs[key].replay()
-            else:
-                self._issue(first, count)              # no graphs, or cache full: same sequence, launched eagerly
+                    self._issue(0, count, window=True)
+                self.graphs[count] = graph
+            self.graphs[count].replay()
+        else:
+            self._issue(first, count)                  # the same sequence, launched eagerly
         self.position += count
         return count
 
