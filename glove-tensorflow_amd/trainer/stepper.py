@@ -187,6 +187,39 @@ def all_gather_rows(dist, recv, send, async_op=False):
         return dist.all_gather([recv[r] for r in range(recv.shape[0])], send, async_op=async_op)
 
 
+class SideCollective:
+    """A collective that runs BESIDE the compute stream: started after what the compute stream has enqueued so far, awaited
+    where its result is needed.  On a GPU it is issued — as an ordinary blocking-on-its-stream call — from a side stream
+    forked off and joined back with events, which is also a shape a hipGraph capture records (a work handle awaited
+    inside a capture is not: `async_op=True` + `wait()` under capture crashes in this torch / RCCL, tools/dbg_rccl_graph.py).
+    On a CPU transport (the gloo tests) it is the transport's asynchronous form."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.done, self.work = None, None
+
+    def start(self, issue):
+        """issue(async_op) launches the collective."""
+        if self.stream is None:
+            self.work = issue(True)
+            return
+        fork = torch.cuda.Event()
+        fork.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(fork)
+            issue(False)
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+            self.done = None
+
+
 def transport_is_capturable(dist, multi: bool) -> bool:
     """Can a step be captured into a hipGraph?  Its kernels always; its collectives only on RCCL ("nccl" backend)."""
     return not multi or (dist is not None and dist.get_backend() == "nccl")
@@ -373,7 +406,7 @@ class RowShardedStepper(GraphedSteps):
         self.hyper_cols = backend.make_hyper(batch_size=gb, sides=2, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials over the ranks
-        self._gather = None                     # the lists' all-gather while it is in flight
+        self._gather = SideCollective(tables.device)        # the lists' all-gather while it is in flight
         self.G = backend.dense_grad_buffer(tables) if self._multi else None
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(backend.col_half(tables, self.G).numel()) if self.G is not None else 0
@@ -408,12 +441,10 @@ class RowShardedStepper(GraphedSteps):
             # enqueued — the list is complete) and awaited after the row side; the loss partials, which the row pass
             # leaves, follow in a 4-float all-reduce
             def gather(p):
-                self._gather = all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"], async_op=True)
+                self._gather.start(lambda a: all_gather_rows(self.dist, self.bufs["recv"], self.bufs["send"], async_op=a))
 
             def loss_tail(p):
-                if self._gather is not None:
-                    self._gather.wait()
-                    self._gather = None
+                self._gather.wait()
                 b.loss_partials(p, t, self.tail)
                 self.dist.all_reduce(self.tail)
 
@@ -432,9 +463,7 @@ class RowShardedStepper(GraphedSteps):
 
     def finish_async(self):
         """Waits for the collective a phase started (for callers that time the phases one by one)."""
-        if self._gather is not None:
-            self._gather.wait()
-            self._gather = None
+        self._gather.wait()
 
     def step_many(self, plans):
         for plan in plans:
@@ -474,7 +503,7 @@ class ShardedStepper(GraphedSteps):
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.batches, self.bufs, self.view, self.owner_state, self._caps, self._dirty = [], None, None, {}, (0, 0), True
         self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials, summed over ranks
-        self._push = None                       # the col gradients' all-to-all while it is in flight
+        self._push = SideCollective(tables.device)          # the col gradients' all-to-all while it is in flight
         if hasattr(backend, "shard_rows"):
             backend.shard_rows = tables.V_row       # local row ids: anything outside the shard counts as id 0, like a bad col id
 
@@ -547,15 +576,13 @@ class ShardedStepper(GraphedSteps):
             # this stream has enqueued so far — the packed list is complete — and runs on the transport's own stream)
             n, ns = bt[i]["n"], bt[i]["ns"]
             if self._multi:
-                self._push = dist.all_to_all_single(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"], bt[i]["want"],
-                                                    async_op=True)
+                self._push.start(lambda a: dist.all_to_all_single(f["recv"][:ns], f["packed"][1:1 + n], bt[i]["serve"],
+                                                                  bt[i]["want"], async_op=a))
             else:
                 f["recv"][:ns].copy_(f["packed"][1:1 + n])
 
         def loss_tail(i):
-            if self._push is not None:
-                self._push.wait()
-                self._push = None
+            self._push.wait()
             # the loss partials come from the row pass, which ran after the list left: handed to the owners' apply apart
             b.loss_partials(bt[i]["plan"], self.view, self.tail)
             if self._multi:
@@ -575,9 +602,7 @@ class ShardedStepper(GraphedSteps):
 
     def finish_async(self):
         """Waits for the collective a phase started (for callers that time the phases one by one)."""
-        if self._push is not None:
-            self._push.wait()
-            self._push = None
+        self._push.wait()
 
     def read_loss(self) -> dict:
         loss, L, reg, _ = self.loss_out.tolist()
