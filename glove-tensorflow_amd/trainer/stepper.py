@@ -189,10 +189,11 @@ def all_gather_rows(dist, recv, send, async_op=False):
 
 class SideCollective:
     """A collective that runs BESIDE the compute stream: started after what the compute stream has enqueued so far, awaited
-    where its result is needed.  On a GPU it is issued — as an ordinary blocking-on-its-stream call — from a side stream
-    forked off and joined back with events, which is also a shape a hipGraph capture records (a work handle awaited
-    inside a capture is not: `async_op=True` + `wait()` under capture crashes in this torch / RCCL, tools/dbg_rccl_graph.py).
-    On a CPU transport (the gloo tests) it is the transport's asynchronous form."""
+    where its result is needed.  On a GPU it is issued — as an ordinary call, blocking on its stream only — from a side
+    stream forked off and joined back with events.  INSIDE a hipGraph capture it is issued in line on the capturing stream
+    instead (no overlap in a replayed step): in this torch / RCCL a collective on a stream forked off a capturing one, like a
+    work handle awaited under capture, crashes the process (tools/dbg_rccl_graph.py), while collectives on the capturing
+    stream itself capture and replay correctly.  On a CPU transport (the gloo tests) it is the transport's asynchronous form."""
 
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
@@ -202,6 +203,9 @@ class SideCollective:
         """issue(async_op) launches the collective."""
         if self.stream is None:
             self.work = issue(True)
+            return
+        if torch.cuda.is_current_stream_capturing():
+            issue(False)
             return
         fork = torch.cuda.Event()
         fork.record(torch.cuda.current_stream())
