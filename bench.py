@@ -419,7 +419,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             if ahead > 1:
                 sweep_pipelined(spg)
             else:

@@ -224,6 +224,8 @@ class SideCollective:
             self.done = None
 
 
+# Captures use capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives, which a
+# capture in the default (global) mode turns into an error in that thread ("operation not permitted when stream is capturing").
 def transport_is_capturable(dist, multi: bool) -> bool:
     """Can a step be captured into a hipGraph?  Its kernels always; its collectives only on RCCL ("nccl" backend)."""
     return not multi or (dist is not None and dist.get_backend() == "nccl")
@@ -254,7 +256,7 @@ class GraphedSteps:
                 return self.step_eager(item)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.step_eager(item)
             graphs[key] = (g, item)             # the graph holds raw pointers into the plan: keep the plan alive
             g = graphs[key]
@@ -759,7 +761,7 @@ class ReshufflingRunner:
             if count not in self.graphs:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._issue(0, count, window=True)
                 self.graphs[count] = graph
             self.graphs[count].replay()
