@@ -698,6 +698,9 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        import gc
+        gc.collect()                 # no captured collective may outlive the communicator: RCCL's teardown waits for them
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

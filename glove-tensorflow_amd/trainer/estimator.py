@@ -211,6 +211,11 @@ class Estimator:
                 if not p.get("skip_eval"):
                     self.evaluate()
         torch.cuda.synchronize() if self.device.type == "cuda" else None
+        if hasattr(stepper, "release_graphs"):
+            stepper.release_graphs()        # captured RCCL collectives must be gone before the process group is
+            inner = getattr(stepper, "stepper", None)
+            if hasattr(inner, "release_graphs"):
+                inner.release_graphs()
 
     def _save_checkpoint(self):
         """Rank 0 writes; a row-sharded run first gathers the whole model (collective: every rank calls this)."""

@@ -266,6 +266,13 @@ class GraphedSteps:
         for _, fn in self.phases():
             fn(item)
 
+    def release_graphs(self):
+        """Drops the captured steps.  Call before torch.distributed.destroy_process_group(): RCCL does not finish tearing a
+        communicator down while hipGraphs that captured its collectives exist (the call hangs)."""
+        if getattr(self, "_graphs", None) is not None:
+            torch.cuda.synchronize()
+            self._graphs, self._seen = {}, {}
+
 
 class Stepper(GraphedSteps):
     """`exchange`: "dense" = all-reduce of the flat dense gradient buffer; "rows" = all-gather of packed touched-row
@@ -769,6 +776,12 @@ class ReshufflingRunner:
             self._issue(first, count)                  # the same sequence, launched eagerly
         self.position += count
         return count
+
+    def release_graphs(self):
+        """Drops the captured bursts (before the process group is destroyed: see GraphedSteps.release_graphs)."""
+        if self.graphs:
+            torch.cuda.synchronize()
+            self.graphs = {}
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""
