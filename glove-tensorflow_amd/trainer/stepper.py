@@ -562,7 +562,7 @@ class ShardedStepper(GraphedSteps):
         if self.bufs is None or cap > self._caps[0] or scap > self._caps[1]:
             self._caps = (cap, scap)
             if getattr(self, "_graphs", None) is not None:
-                self._graphs, self._seen = {}, {}   # captured steps point into the old buffers
+                self._graphs = {}                   # captured steps point into the old buffers
             self.bufs = self.backend.fetch_buffers(self.tables, cap, scap)
             self.view = self.backend.col_view(self.tables, self.bufs, cap)
             self.payload_floats = 2 * cap * (self.tables.d + 1)

@@ -90,7 +90,7 @@ def run(hip):
         # RCCL does not finish tearing a communicator down while hipGraphs that captured its collectives exist
         import gc
         for obj in gc.get_objects():
-            if hasattr(obj, "release_graphs") and not isinstance(obj, type):
+            if isinstance(obj, (Stepper, RowShardedStepper, ShardedStepper, ReshufflingRunner)):
                 obj.release_graphs()
         gc.collect()
         dist.destroy_process_group()
