@@ -685,6 +685,8 @@ class ReshufflingRunner:
         from trainer.hip_api import DeviceTables
         real = self.tables
         scratch = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
+        if getattr(real, "R_ver", None) is not None:
+            scratch.enable_twin()           # the same step forms are legal on the scratch tables
         self._swap_tables(scratch)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
