@@ -409,6 +409,10 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     # (a multi-rank step is captured with its collectives when the transport is RCCL; a gloo rehearsal launches eagerly)
     from trainer.stepper import transport_is_capturable
     use_graph = not no_graph and (mode == "single" or transport_is_capturable(dist, getattr(stepper, "_multi", False)))
+    if use_graph and mode in ("sharded", "rowsharded") and getattr(stepper, "_multi", False) and B > 65536:
+        # a captured step issues its collectives in line (SideCollective): a big batch gains more from the push / gather
+        # overlapping the row side (eager launches, far ahead of a millisecond step) than from saving launches
+        use_graph = False
     graph, spg = None, steps_per_graph(steps)
     if use_graph:
         side = torch.cuda.Stream()
