@@ -29,10 +29,8 @@ __device__ inline int wave_sum_int(int v)
 // Both sides need their pairs in (id, earlier order) order: the row side sorts the batch by row id, the col side sorts
 // the ROW-SORTED pairs by col id.  Keys are ids below V, i.e. ceil(log2 V) bits: P = ceil(bits / 8) passes over digits of
 // db = ceil(bits / P) bits (V = 10 k: two passes of 7 bits; V = 2 M: three of 7), least significant digit first, every pass
-// stable.  A pass is one launch over tiles of kSortThreads x E consecutive positions, one workgroup each (plus ONE
-// histogram launch in front of the build's first pass: every later pass's table is filled by the pass before it):
-//   radix_hist     count[digit][tile] = keys of the tile with that digit, for the first pass of the build; zeroes the tables
-//                  the scatter passes add into (inside the build, on its stream: nothing relies on how memory was left)
+// stable.  A pass is two launches over tiles of kSortThreads x E consecutive positions, one workgroup each:
+//   radix_hist     count[digit][tile] = keys of the tile with that digit (every entry written: nothing relies on zeroed memory)
 //   radix_scatter  position of a key = keys of smaller digits anywhere + keys of its digit in earlier tiles (both summed
 //                  from the count table by the workgroup itself: thread d reads row d, 128 tiles per round trip) + keys of
 //                  its digit earlier in its own tile (its stable local rank)
@@ -47,7 +45,6 @@ __device__ inline int wave_sum_int(int v)
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kMaxDigits = 256;
-constexpr int kMaxSortPasses = 8;                         // 2 sorts x ceil(31 bits / 8)
 constexpr int kWalk = 16;                                 // 16-byte loads of a count-table row in flight per thread (= 128 tiles)
 
 struct SortIn {
@@ -62,14 +59,6 @@ struct SortIn {
     int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (row ids: radix_hist of the first pass;
                                 // col ids: the row side's last radix_scatter).  Every entry is written by every build —
                                 // no counter to zero, no atomics; emit_uniq_rec adds them up into plan counts[5]
-    // The count table of the NEXT pass is filled by this pass's radix_scatter: a key that moves to position `dest` adds one
-    // to (its next digit, tile of dest) — so only the very first pass of a build needs a radix_hist launch.  Two 16-bit
-    // counts share a dword: the add is a 32-bit atomic of 1 << 16 (tile & 1); no half can overflow into its neighbour
-    // (a tile holds fewer than 65536 keys).  radix_hist (the first launch of the build) zeroes all later tables.
-    uint32_t *next_count;       // nullptr: nothing follows (the col side's last pass)
-    int next_shift;             // the next pass's digit of the next pass's key (the row side's last pass: of the col id)
-    uint32_t *zero_from;        // radix_hist: the words of the later passes' tables ...
-    int zero_words;             // ... and how many
 };
 
 struct SortOut {
@@ -137,8 +126,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
     __shared__ int hist[kMaxDigits];
     const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hist[threadIdx.x] = 0;
-    // the tables the scatter passes of this build are going to add into start at zero (this is the build's first launch)
-    for (int i = blockIdx.x * kSortThreads + threadIdx.x; i < in.zero_words; i += gridDim.x * kSortThreads) in.zero_from[i] = 0u;
     __syncthreads();
     const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
     int32_t key[E];
@@ -253,16 +240,13 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
     }
     __syncthreads();
     // ---- every pair to its place
-    int next_slot[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t i = base + j * 64 + lane;
-        next_slot[j] = 0;
         if (i >= in.n) continue;
         const int digit = (key[j] >> in.shift) & (nd - 1);
         const int dest = wcnt[wave][digit] + rank[j];
         const int32_t p = val[j];
-        int32_t next_key = key[j];
         if (LAST == 0) {
             out.keys[dest] = key[j];
             out.vals[dest] = p;
@@ -270,7 +254,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
             out.sorted_keys[dest] = key[j];
             int32_t c = g_id[j];
             if ((uint32_t)c >= (uint32_t)out.V) { c = 0; ++mapped; }
-            next_key = c;                                 // the col side sorts the row-sorted pairs by col id
             out.r_partner[dest] = c;
             out.r_w[dest] = g_w[j];
             out.r_y[dest] = g_y[j];
@@ -281,26 +264,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
             out.c_partner[dest] = g_id[j];
             out.c_w[dest] = g_w[j];
             out.c_y[dest] = g_y[j];
-        }
-        next_slot[j] = ((next_key >> in.next_shift) & (nd - 1)) * in.tile_stride + dest / (kSortThreads * E);
-    }
-    if (LAST != 2 && in.next_count) {
-        // the keys in the next pass's count table: slot = (next digit, tile of dest).  Same-address atomics serialise in
-        // L2 (one add per key took a 131 k batch of Zipf ids 96 us instead of 9), and the 64 keys of a wave round mostly
-        // share a few slots — a frequent id's pairs travel together — so the round's lanes are peeled by slot: one add,
-        // of the slot's lane count, per distinct slot
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool valid = base + j * 64 + lane < in.n;
-            unsigned long long todo = __ballot(valid);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int slot = __shfl(next_slot[j], leader, 64);
-                const unsigned long long same = __ballot(valid && next_slot[j] == slot) & todo;
-                if (lane == leader)
-                    atomicAdd(in.next_count + slot / 2, (uint32_t)__popcll(same) << (16 * (slot & 1)));
-                todo &= ~same;
-            }
         }
     }
     if (LAST == 1) block_store_sum(mapped, in.mapped + in.ntiles + blockIdx.x);     // col ids mapped to 0
@@ -621,7 +584,7 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     const size_t per_tile = (size_t)kSortThreads * p.sort_e;
     p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
     p.tile_stride = (p.sort_tiles + 7) / 8 * 8;
-    p.count = (uint16_t *)take((size_t)kMaxSortPasses * p.tile_stride * kMaxDigits * 2);     // one table per pass of both sorts
+    p.count = (uint16_t *)take((size_t)p.tile_stride * kMaxDigits * 2);
     p.mapped = (int32_t *)take((size_t)2 * p.sort_tiles * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
@@ -637,18 +600,15 @@ static int ceil_log2(int32_t v)
     return b;
 }
 
-// One stable sort by id: P passes.  first_keys: the ids as they arrive (row side: raw row ids, cleaned against
-// clean_below; col side: r_partner, already clean).  `last` carries the destination arrays of the last pass; side = 1 row
-// (its launches: radix_hist, then P x radix_scatter, the last of which fills the col side's first count table), 2 col
-// (P x radix_scatter).  Table k of the workspace belongs to pass k of the build (row passes first).
+// One stable sort by id: P passes of (radix_hist, radix_scatter).  first_keys: the ids as they arrive (row side: raw row
+// ids, cleaned against clean_below; col side: r_partner, already clean).  `last` carries the destination arrays of the last
+// pass; side = 1 row, 2 col.
 template <int E>
 static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t B, int bits, const PlanWs &pw, SortOut last,
                         int side, hipStream_t st)
 {
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P;
-    const size_t table_halves = (size_t)pw.tile_stride * kMaxDigits;
     for (int p = 0; p < P; ++p) {
-        const int k = (side == 1 ? 0 : P) + p;                  // pass number within the build
         SortIn in;
         in.keys = p == 0 ? first_keys : pw.keys[(p - 1) & 1];
         in.vals = p == 0 ? nullptr : pw.vals[(p - 1) & 1];
@@ -657,15 +617,10 @@ static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t 
         in.shift = p * db;
         in.db = db;
         in.ntiles = pw.sort_tiles;
-        in.count = pw.count + k * table_halves;
+        in.count = pw.count;
         in.tile_stride = pw.tile_stride;
         in.mapped = pw.mapped;
-        const bool follows = k + 1 < 2 * P;
-        in.next_count = follows ? reinterpret_cast<uint32_t *>(pw.count + (k + 1) * table_halves) : nullptr;
-        in.next_shift = p + 1 < P ? (p + 1) * db : 0;           // behind a sort's last pass: digit 0 of the other key
-        in.zero_from = reinterpret_cast<uint32_t *>(pw.count + table_halves);
-        in.zero_words = (int)((2 * P - 1) * table_halves / 2);
-        if (k == 0) hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
+        hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
         if (p < P - 1) {
             SortOut out = last;
             out.keys = pw.keys[p & 1];
