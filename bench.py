@@ -676,6 +676,10 @@ def main(argv=None):
                   ("text8_d64_index_rebuilt_every_step_6_in_flight", 5, dict(workload="text8_d64", B=131072, steps=100, warmup=10,
                                                                              dynamic=True, build_ahead=6)),
                   ("c2_text8_d64", 4, dict(workload="text8_d64", B=131072, steps=200, warmup=20, max_batches=64)),
+                  # the headline workload with the index rebuilt every step (four builds in flight, as the trainer's default
+                  # --epoch-shuffle full runs it)
+                  ("c4_zipf_v400k_d300_index_rebuilt_every_step_4_in_flight", 12,
+                   dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4, dynamic=True, build_ahead=4)),
                   ("c3_text8_v50k_d300", 6, dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
                   ("c5_zipf_v2m_d128_one_gpu_shard", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4))]
                  if world == 1 else
