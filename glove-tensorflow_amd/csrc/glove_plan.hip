@@ -58,7 +58,7 @@ struct SortIn {
     int tile_stride;            // ntiles rounded up to a multiple of 8 (16-byte rows); the padding is never written or used
     int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (row ids: radix_hist of the first pass;
                                 // col ids: the row side's last radix_scatter).  Every entry is written by every build —
-                                // no counter to zero, no atomics; emit_uniq_rec adds them up into plan counts[5]
+                                // no counter to zero, no atomics; side_tiles adds them up into plan counts[5]
 };
 
 struct SortOut {
@@ -289,6 +289,10 @@ struct SideKeys { const int32_t *keys[2]; };
 struct SideOut {
     int32_t *chunk_id[2], *chunk_start[2], *uniq_slot[2];
     int32_t *counts;                                      // plan counts: [0],[1] row side, [2],[3] col side
+    int32_t *uniq_rec[2];                                 // {id, first chunk, chunks, pairs} per distinct id
+    const int64_t *tile_re;                               // [2][ntiles] end of the run crossing a tile's right edge (side_tiles)
+    int32_t *heavy;                                       // ids with more than heavy_chunks chunks: (side << 30) | position, any order
+    int heavy_chunks, cap_heavy;
 };
 
 // flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
@@ -367,8 +371,42 @@ __device__ inline int64_t run_start_of(const int32_t *__restrict__ keys, int64_t
     return lo;
 }
 
+// end of the run that position `pos` lies in: first index in (pos, B) whose key differs (is larger), or B.  One whole wave,
+// the same 64-ary search forwards.
+__device__ inline int64_t run_end_of(const int32_t *__restrict__ keys, int64_t B, int64_t pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int32_t key = keys[pos];
+    int64_t lo = pos + 1, hi = B;                          // answer in [lo, hi]; everything below lo holds the key
+    while (lo < hi) {
+        const int64_t n = hi - lo, step = (n + 63) / 64;
+        int64_t q = lo + step * lane;
+        if (q > hi - 1) q = hi - 1;
+        const bool gt = keys[q] > key;
+        const unsigned long long m = __ballot(gt);
+        if (m == 0) {                                      // every probe still holds the key: the answer lies behind the last one
+            lo = __shfl(q, 63, 64) + 1;
+            continue;
+        }
+        const int first = __ffsll((long long)m) - 1;       // first probe with a larger key
+        const int64_t q_first = __shfl(q, first, 64);
+        const int64_t q_before = __shfl(q, first > 0 ? first - 1 : 0, 64);
+        lo = first == 0 ? lo : q_before + 1;
+        hi = first == 0 ? lo : q_first;
+    }
+    return lo;
+}
+
+struct TileExtra {
+    int64_t *tile_re;           // [2][ntiles] end of the run that crosses a tile's right edge
+    int32_t *counts;            // plan counts
+    const int32_t *mapped;      // per sort tile: ids mapped to 0 (row ids, then col ids)
+    int n_mapped;
+};
+
 __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
-                                                           int64_t *__restrict__ tile_rs, int2 *__restrict__ tile_sums)
+                                                           int64_t *__restrict__ tile_rs, int2 *__restrict__ tile_sums,
+                                                           TileExtra ex)
 {
     __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
     __shared__ int red[2][kTileThreads / 64];
@@ -378,6 +416,10 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
     if (threadIdx.x < 64) {                                // wave 0 searches together
         const int64_t r = begin > 0 ? run_start_of(keys, begin) : 0;
         if (threadIdx.x == 0) lds_rs[kTileThreads / 64] = r;
+    } else if (threadIdx.x < 128) {                        // wave 1, meanwhile: where the tile's last run ends (side_emit's id records)
+        const int64_t end = begin + kTile < B ? begin + kTile : B;
+        const int64_t r = end < B ? run_end_of(keys, B, end - 1) : B;
+        if (threadIdx.x == 64) ex.tile_re[(size_t)side * ntiles + t] = r;
     }
     __syncthreads();
     const int64_t frs = lds_rs[kTileThreads / 64];
@@ -394,6 +436,23 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
         tile_sums[(size_t)side * ntiles + t] = make_int2(su, sc);
         tile_rs[(size_t)side * ntiles + t] = frs;
     }
+    if (t == 0 && side == 0) {                             // (block-uniform)
+        // The words of `counts` no later kernel of the build writes whole: the heavy-id counter side_emit (the next
+        // launch) appends behind starts at zero, the spare words are zero, the ids mapped to 0 are the sum over the sort
+        // tiles — no word of `counts` depends on what the buffer held before this build.
+        int v = 0;
+        for (int i = threadIdx.x; i < ex.n_mapped; i += kTileThreads) v += ex.mapped[i];
+        v = wave_sum_int(v);
+        __syncthreads();                                   // red[] of the tile sums has been read
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int wv = 0; wv < kTileThreads / 64; ++wv) total += red[0][wv];
+            ex.counts[5] = total;
+            ex.counts[4] = ex.counts[6] = ex.counts[7] = 0;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
@@ -401,6 +460,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
                                                           const int2 *__restrict__ tile_sums, SideOut out)
 {
     __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
+    __shared__ int64_t lds_open[kTileThreads / 64];
     __shared__ int red[2][kTileThreads / 64];
     __shared__ int wave_tot[2][kTileThreads / 64];
     const int side = blockIdx.y, t = blockIdx.x;
@@ -436,9 +496,16 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
     for (int wv = 0; wv < wave; ++wv) { ui += wave_tot[0][wv]; ci += wave_tot[1][wv]; }
     const int64_t k0 = begin + (int64_t)threadIdx.x * kTilePer;
     int32_t *chunk_id = out.chunk_id[side], *chunk_start = out.chunk_start[side], *uniq_slot = out.uniq_slot[side];
+    int open_ui[kTilePer], open_ci[kTilePer];              // number and first chunk of the id a position opens
+    int64_t my_first_open = INT64_MAX;                     // first position of mine that opens an id
+#pragma unroll
+    for (int i = kTilePer - 1; i >= 0; --i)
+        if (flag[i] & 2u) my_first_open = k0 + i;
 #pragma unroll
     for (int i = 0; i < kTilePer; ++i) {
         const int64_t k = k0 + i;
+        open_ui[i] = ui;
+        open_ci[i] = ci;
         if (flag[i] & 2u) uniq_slot[ui++] = ci;
         if (flag[i] & 1u) { chunk_id[ci] = keys[k]; chunk_start[ci] = (int32_t)k; ++ci; }   // keys[k]: L1-hot, read by tile_flags
         if (k == B - 1) {                                  // closing entries and totals
@@ -446,46 +513,36 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
             uniq_slot[ui] = ci;
             out.counts[2 * side] = ci;
             out.counts[2 * side + 1] = ui;
-            // the heavy-id counter emit_uniq_rec (the next launch) appends behind starts at zero, the spare words are
-            // zero: no word of `counts` depends on what the buffer held before this build
-            if (side == 0) out.counts[4] = out.counts[6] = out.counts[7] = 0;
         }
     }
-}
-
-// {id, first chunk, chunks, pairs} per distinct id, from the arrays side_emit wrote (blockIdx.y = side);
-// also appends the ids with more than heavy_chunks chunks to the plan's heavy list (any order)
-struct UniqRecArgs {
-    const int32_t *chunk_id[2], *chunk_start[2], *uniq_slot[2];
-    int32_t *rec[2];
-};
-__global__ void emit_uniq_rec(const int32_t *__restrict__ counts, UniqRecArgs a, int heavy_chunks, int cap_heavy,
-                              int32_t *__restrict__ heavy, int32_t *__restrict__ n_heavy,
-                              const int32_t *__restrict__ mapped, int n_mapped_entries, int32_t *__restrict__ n_mapped_out)
-{
-    const int side = blockIdx.y;
-    if (blockIdx.x == 0 && side == 0) {                    // ids mapped to 0, over the sort tiles of both kinds -> counts[5]
-        __shared__ int part[4];
-        int v = 0;
-        for (int i = threadIdx.x; i < n_mapped_entries; i += blockDim.x) v += mapped[i];
-        v = wave_sum_int(v);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int s = 0;
-            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += part[wv];
-            *n_mapped_out = s;
-        }
+    // ---- {id, first chunk, chunks, pairs} of every id that opens in this tile.  An id's pairs end where the next id opens:
+    // further on in this thread, in a thread to the right (suffix minimum of the threads' first openings), or beyond the
+    // tile (tile_re: side_tiles searched the end of the run that crosses the right edge).  The chunks of an id restart
+    // with it, so it has ceil(pairs / chunk_cap) of them.
+    int64_t sfx = my_first_open;                           // min over lanes >= mine of this wave
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int64_t o = __shfl_down(sfx, dlt, 64);
+        if (lane + dlt < 64) sfx = o < sfx ? o : sfx;
     }
-    const int nu = counts[2 * side + 1];
-    const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *uniq_slot = a.uniq_slot[side];
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nu; q += gridDim.x * blockDim.x) {
-        const int x = uniq_slot[q], y = uniq_slot[q + 1];
-        reinterpret_cast<int4 *>(a.rec[side])[q] = make_int4(chunk_id[x], x, y - x, chunk_start[y] - chunk_start[x]);
-        if (y - x > heavy_chunks) {
-            const int slot = atomicAdd(n_heavy, 1);
-            if (slot < cap_heavy) heavy[slot] = (side << 30) | q;
+    if (lane == 0) lds_open[wave] = sfx;
+    __syncthreads();
+    int64_t next_open = out.tile_re[(size_t)side * ntiles + t];
+    for (int wv = kTileThreads / 64 - 1; wv > wave; --wv) next_open = lds_open[wv] < next_open ? lds_open[wv] : next_open;
+    int64_t right = __shfl_down(sfx, 1, 64);               // min over the lanes to my right in this wave
+    if (lane == 63) right = INT64_MAX;
+    next_open = right < next_open ? right : next_open;
+#pragma unroll
+    for (int i = kTilePer - 1; i >= 0; --i) {
+        if (!(flag[i] & 2u)) continue;
+        const int64_t k = k0 + i;
+        const int pairs = (int)(next_open - k), chunks = (pairs + chunk_cap - 1) / chunk_cap;
+        reinterpret_cast<int4 *>(out.uniq_rec[side])[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
+        if (chunks > out.heavy_chunks) {
+            const int slot = atomicAdd(out.counts + 4, 1);  // zeroed by side_tiles, the launch before this one
+            if (slot < out.cap_heavy) out.heavy[slot] = (side << 30) | open_ui[i];
         }
+        next_open = k;
     }
 }
 
@@ -557,6 +614,7 @@ struct PlanWs {
     int tile_stride;
     int32_t *mapped;                 // [2][sort tiles] ids mapped to 0 per tile (row ids, col ids)
     int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
+    int64_t *tile_re;                // [2][ntiles] end of the run that crosses a tile's right edge
     int2 *tile_sums;                 // [2][ntiles] (ids, chunks) opened inside a tile
     int ntiles;                      // tiles of the numbering kernels (kTile positions)
     int sort_e, sort_tiles;          // positions per thread and tiles of the sort passes
@@ -588,6 +646,7 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.mapped = (int32_t *)take((size_t)2 * p.sort_tiles * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
+    p.tile_re = (int64_t *)take((size_t)2 * p.ntiles * 8);
     p.tile_sums = (int2 *)take((size_t)2 * p.ntiles * 8);
     p.bytes = off;
     return p;
@@ -698,16 +757,13 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
     const SideKeys sk = {{pw.row_sorted, pw.col_sorted}};
     const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
-                        {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts};
+                        {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
+                        (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy};
+    const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles};
     hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
-                       pw.tile_rs, pw.tile_sums);
+                       pw.tile_rs, pw.tile_sums, ex);
     hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
-    const UniqRecArgs ua = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
-                            {plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_uniq_rec, plan->c_uniq_rec}};
-    hipLaunchKernelGGL(emit_uniq_rec, dim3(blocks_for(plan->cap_uniq, kBlock), 2), dim3(kBlock), 0, st,
-                       (const int32_t *)plan->counts, ua, plan->heavy_chunks, plan->cap_heavy, plan->heavy,
-                       plan->counts + 4, (const int32_t *)pw.mapped, 2 * pw.sort_tiles, plan->counts + 5);
     if (plan->r_crec) return launch_fill_records(plan, st);
     return (int)hipGetLastError();
 }
