@@ -4,13 +4,12 @@
 // reference's default batch of 1,024 nonzeros, where one step of the kernels takes ~10 us.  A caller
 // that hands over a fresh batch every step (the reference's input_fn does: data_utils.py:12-21) needs
 // the index in a few microseconds, so batches up to 4,096 pairs are indexed by ONE workgroup entirely
-// in LDS: two stable block radix sorts by id (rocPRIM's block primitive, 8 bits per pass: two passes for a
-// 10^4-id vocabulary; the first form, a bitonic sort of 64-bit (id, position) keys, spent 70 of its 110 us at
-// B = 4,096 in its 78 LDS-bound sub-stages) and three block scans per side.  The result is identical to the
-// general path and to oracle/glove_ref.py:build_plan.
+// in LDS: two stable block radix sorts by id (hand-written, the ballot-rank scheme of glove_plan.hip's tiled sort on one
+// workgroup of 16 waves: passes of up to 8 bits, two for a 10^4-id vocabulary; earlier forms: rocPRIM's block primitive,
+// and before it a bitonic sort of 64-bit (id, position) keys that spent 70 of its 110 us at B = 4,096 in its 78
+// LDS-bound sub-stages) and three block scans per side.  The result is identical to the general path and to
+// oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
-
-#include <rocprim/block/block_radix_sort.hpp>
 
 namespace glove {
 
@@ -107,17 +106,115 @@ __device__ inline void small_side(const int *ids, int B, int cap, int heavy_chun
     __syncthreads();
 }
 
+// ---- stable sort of up to kSmallThreads x E (id, position) pairs by id, one workgroup, in LDS -------------------------
+// LSD radix, P = ceil(bits / 8) passes of ceil(bits / P)-bit digits.  A pass: every wave takes 64 E consecutive positions,
+// 64 per round; the lanes of a round that hold the same digit find each other with `db` ballots, the group's first lane
+// fetch-adds the wave's running count of that digit (LDS atomic with return) and hands the old value round: a key's stable
+// rank inside its wave.  Thread d then turns column d of the 16 wave counters into the waves' starting offsets, a scan over
+// the digits gives where each digit starts, and every pair moves to its place through LDS.  Four barriers per pass.
+constexpr int kSmallWaves = kSmallThreads / 64;
+constexpr int kSmallDigits = 256;
+
+struct SmallSortLds {
+    int wcnt[kSmallWaves][kSmallDigits];     // per wave: running digit counts, then the wave's offset inside the digit
+    int dig[kSmallDigits];                   // where the keys of a digit start
+    int red[kSmallWaves];
+};
+
 template <int E>
-using SmallSort = rocprim::block_radix_sort<uint32_t, kSmallThreads, E, int32_t>;
+constexpr size_t small_sort_bytes() { return (size_t)2 * kSmallThreads * E * 4 + sizeof(SmallSortLds); }
+
+// key / pos: blocked arrangement in and out (thread t holds positions t E .. t E + E - 1); n = valid pairs (the first n
+// positions); the others keep their place behind them
+template <int E>
+__device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&pos)[E], int n, int bits, unsigned char *scratch)
+{
+    constexpr int np = kSmallThreads * E;
+    uint32_t *kbuf = reinterpret_cast<uint32_t *>(scratch);
+    int32_t *vbuf = reinterpret_cast<int32_t *>(kbuf + np);
+    SmallSortLds &L = *reinterpret_cast<SmallSortLds *>(vbuf + np);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        kbuf[threadIdx.x * E + e] = key[e];
+        vbuf[threadIdx.x * E + e] = pos[e];
+    }
+    __syncthreads();
+    const int P = (bits + 7) / 8, db = (bits + P - 1) / P, nd = 1 << db;
+    for (int p = 0; p < P; ++p) {
+        const int shift = p * db;
+        uint32_t k[E];
+        int32_t v[E];
+        int rank[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int i = wave * 64 * E + j * 64 + lane;
+            k[j] = kbuf[i];
+            v[j] = vbuf[i];
+        }
+        for (int i = lane; i < nd; i += 64) L.wcnt[wave][i] = 0;          // a wave's own counters: LDS ops of one wave are ordered
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool valid = wave * 64 * E + j * 64 + lane < n;
+            const int digit = (int)(k[j] >> shift) & (nd - 1);
+            unsigned long long peers = __ballot(valid);
+            for (int b = 0; b < db; ++b) {
+                const bool bit = (digit >> b) & 1;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const int leader = valid ? __ffsll((long long)peers) - 1 : lane;
+            int before = 0;
+            if (valid && lane == leader) before = atomicAdd(&L.wcnt[wave][digit], __popcll(peers));
+            before = __shfl(before, leader, 64);
+            rank[j] = before + __popcll(peers & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        int total = 0;
+        if ((int)threadIdx.x < nd) {
+#pragma unroll
+            for (int wv = 0; wv < kSmallWaves; ++wv) {
+                const int c = L.wcnt[wv][threadIdx.x];
+                L.wcnt[wv][threadIdx.x] = total;
+                total += c;
+            }
+        }
+        int incl = total;                                                   // exclusive scan over the digits (threads)
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int o = __shfl_up(incl, dlt, 64);
+            if (lane >= dlt) incl += o;
+        }
+        if (lane == 63) L.red[wave] = incl;
+        __syncthreads();
+        int start = incl - total;
+        for (int wv = 0; wv < wave; ++wv) start += L.red[wv];
+        if ((int)threadIdx.x < nd) L.dig[threadIdx.x] = start;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (wave * 64 * E + j * 64 + lane >= n) continue;
+            const int digit = (int)(k[j] >> shift) & (nd - 1);
+            const int dest = L.dig[digit] + L.wcnt[wave][digit] + rank[j];
+            kbuf[dest] = k[j];
+            vbuf[dest] = v[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        key[e] = kbuf[threadIdx.x * E + e];
+        pos[e] = vbuf[threadIdx.x * E + e];
+    }
+    __syncthreads();                                                        // the scratch area is free again
+}
 
 // dynamic LDS: four int arrays of np (row ids / col ids / w / y in sorted order) followed by a scratch area that is
 // the sort's storage during the sorts and three int arrays of np (scan scratch) between them
 template <int E>
 constexpr size_t small_scratch_bytes()
 {
-    return sizeof(typename SmallSort<E>::storage_type) > (size_t)3 * kSmallThreads * E * 4
-               ? sizeof(typename SmallSort<E>::storage_type)
-               : (size_t)3 * kSmallThreads * E * 4;
+    return small_sort_bytes<E>() > (size_t)3 * kSmallThreads * E * 4 ? small_sort_bytes<E>() : (size_t)3 * kSmallThreads * E * 4;
 }
 
 template <int E>
@@ -132,14 +229,13 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     float *sw = reinterpret_cast<float *>(scol + np);                    // [np] w, row-sorted
     float *sy = sw + np;                                                 // [np]
     unsigned char *scratch = reinterpret_cast<unsigned char *>(sy + np);
-    auto &sort_storage = *reinterpret_cast<typename SmallSort<E>::storage_type *>(scratch);
     int *sa = reinterpret_cast<int *>(scratch);                          // scan scratch, live between the sorts
     int *sb = sa + np;
     int *sc = sb + np;
     __shared__ int wave_tot[16];
     if (threadIdx.x < 8) plan.counts[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t pad_key = 1u << (key_bits - 1);                       // sorts behind every id: ids < 2^(key_bits-1)
+    const uint32_t pad_key = 1u << (key_bits - 1);                       // positions behind the batch (never moved by the sorts)
 
     // ---- row side: stable sort by row id (blocked arrangement: thread t holds positions t E .. t E + E - 1);
     // ids outside [0, V) count as id 0 (see prepare_ids in glove_plan.hip)
@@ -157,8 +253,7 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
             key[e] = r;
         }
     }
-    SmallSort<E>().sort(key, pos, sort_storage, 0, key_bits);
-    __syncthreads();
+    block_sort_pairs<E>(key, pos, B, key_bits - 1, scratch);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = threadIdx.x * E + e;
@@ -185,8 +280,7 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         pos[e] = i;
     }
     __syncthreads();                                                     // scol read, scan scratch dead: storage free
-    SmallSort<E>().sort(key, pos, sort_storage, 0, key_bits);
-    __syncthreads();
+    block_sort_pairs<E>(key, pos, B, key_bits - 1, scratch);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int j = threadIdx.x * E + e;
