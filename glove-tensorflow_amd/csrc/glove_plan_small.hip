@@ -14,16 +14,30 @@
 
 namespace glove {
 
-constexpr int kSmallThreads = 256;
-constexpr int kSmallWaves = kSmallThreads / 64;
+// ---- diagnostic build only (-DGLOVE_STAMPS): wall-clock stamps of this kernel's phases, per wave
+#ifdef GLOVE_STAMPS
+__device__ unsigned long long *g_small_stamps = nullptr;     // [waves][16], set by glove_debug_set_small_stamps
+#define SMALL_STAMP(slot)                                                                                          \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
+        if ((threadIdx.x & 63) == 0 && g_small_stamps) g_small_stamps[(threadIdx.x >> 6) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define SMALL_STAMP(slot) ((void)0)
+#endif
+
+// Workgroup size by batch: 4 waves x 4 pairs per thread up to 1,024 pairs (the reference's default batch: barriers among
+// four waves are cheap), 16 waves above it (the ranking rounds of a pass run on every wave at once: B = 4,096 measured
+// 85 us per dynamic step with 4 waves x 16 pairs, 73 with 16 x 4).
+constexpr int kSmallMaxWaves = 16;
 constexpr int kSmallDigits = 256;
 
 struct SmallLds {
-    int wcnt[kSmallWaves][kSmallDigits];     // sort: per wave running digit counts, then the wave's offset inside the digit
+    int wcnt[kSmallMaxWaves][kSmallDigits];     // sort: per wave running digit counts, then the wave's offset inside the digit
     int dig[kSmallDigits];                   // sort: where the keys of a digit start
-    int red[kSmallWaves];                    // sort: wave totals of the digit scan
-    int s_max[kSmallWaves], s_sum[kSmallWaves], s_min[kSmallWaves];     // side numbering: wave results of its three scans
-    int s_mapped[kSmallWaves];
+    int red[kSmallMaxWaves];                 // sort: wave totals of the digit scan
+    int s_max[kSmallMaxWaves], s_sum[kSmallMaxWaves], s_min[kSmallMaxWaves];     // side numbering: wave results of its three scans
+    int s_mapped[kSmallMaxWaves];
 };
 
 // ---- stable sort of n <= kSmallThreads x E (id, position) pairs by id, in LDS ------------------------------------------
@@ -34,10 +48,11 @@ struct SmallLds {
 // counters into the waves' starting offsets, a scan over the digits gives where each digit starts, every pair moves to
 // its place in kbuf / vbuf, the next pass reads its positions from there.  Four barriers per pass.  On return kbuf / vbuf
 // hold the pairs in sorted order (positions behind n: untouched).
-template <int E>
+template <int T, int E>
 __device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], int n, int bits, uint32_t *kbuf, int32_t *vbuf,
                                         SmallLds &L)
 {
+    constexpr int NW = T / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P, nd = 1 << db;
     for (int p = 0; p < P; ++p) {
@@ -72,7 +87,7 @@ __device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], i
         int total = 0;
         if ((int)threadIdx.x < nd) {
 #pragma unroll
-            for (int wv = 0; wv < kSmallWaves; ++wv) {
+            for (int wv = 0; wv < NW; ++wv) {
                 const int c = L.wcnt[wv][threadIdx.x];
                 L.wcnt[wv][threadIdx.x] = total;
                 total += c;
@@ -111,10 +126,11 @@ struct SmallSideOut {
 // Three scans over the threads: the start of the run open at a thread's first position (max), the numbers of its first id
 // and chunk (sum of both counts, packed), the next id opening behind its last position (min: where its last id's pairs
 // end).
-template <int E>
+template <int T, int E>
 __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_chunks, int cap_heavy, int side,
                                   SmallLds &L, const SmallSideOut &o, int32_t *counts, int32_t *heavy)
 {
+    constexpr int NW = T / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k0 = threadIdx.x * E;
     int32_t id[E + 1];
@@ -154,7 +170,7 @@ __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_
     for (int wv = 0; wv < wave; ++wv) run_start = L.s_max[wv] > run_start ? L.s_max[wv] : run_start;
     int next_open = __shfl_down(sfx, 1, 64);
     if (lane == 63) next_open = INT32_MAX;
-    for (int wv = wave + 1; wv < kSmallWaves; ++wv) next_open = L.s_min[wv] < next_open ? L.s_min[wv] : next_open;
+    for (int wv = wave + 1; wv < NW; ++wv) next_open = L.s_min[wv] < next_open ? L.s_min[wv] : next_open;
     if (next_open > B) next_open = B;                                       // the last id's pairs end with the batch
     // ---- my flags and counts
     unsigned chunk = 0;
@@ -213,15 +229,15 @@ __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_
     __syncthreads();                                                        // the scan slots are free again
 }
 
-template <int E>
-constexpr size_t small_lds_bytes() { return (size_t)6 * kSmallThreads * E * 4 + sizeof(SmallLds); }
+template <int T, int E>
+constexpr size_t small_lds_bytes() { return (size_t)6 * T * E * 4 + sizeof(SmallLds); }
 
-template <int E>
-__global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
+template <int T, int E>
+__global__ __launch_bounds__(T) void plan_small_kernel(
     const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
     const float *__restrict__ y, int B, int V, int bits, glove_plan plan)
 {
-    constexpr int np = kSmallThreads * E;
+    constexpr int np = T * E, NW = T / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *kbuf = reinterpret_cast<uint32_t *>(smem);                 // [np] sorted ids of the sort in flight
     int32_t *vbuf = reinterpret_cast<int32_t *>(kbuf + np);              // [np] their positions before the sort
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     if (threadIdx.x == 0) plan.counts[4] = 0;
     const uint32_t Vr = (uint32_t)(plan.V_row > 0 ? plan.V_row : V);
     int mapped = 0;
+    SMALL_STAMP(0);
 
     // ---- row side: stable sort by row id; ids outside [0, V_row) count as id 0 (the reference's unknown-token id,
     // estimator.py:26-28; see glove_plan.hip)
@@ -251,7 +268,9 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         key[j] = r;
         val[j] = i;
     }
-    block_sort_pairs<E>(key, val, B, bits, kbuf, vbuf, L);
+    SMALL_STAMP(1);                                                      // row ids arrived
+    block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
+    SMALL_STAMP(2);                                                      // row sort done
     // col / w / y pulled through the permutation: the row side's pair fields, kept in LDS for the col side
     {
         int32_t p[E], c[E];
@@ -275,9 +294,11 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         }
     }
     __syncthreads();                                                     // (counts[4] = 0 is also ordered before the appends)
-    small_side<E>(srow, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 0, L,
+    SMALL_STAMP(3);                                                      // pair fields gathered, row arrays stored
+    small_side<T, E>(srow, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 0, L,
                   SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts, plan.heavy);
 
+    SMALL_STAMP(4);                                                      // row side numbered and stored
     // ---- col side: stable sort of the row-sorted pairs by col id
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -285,7 +306,8 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         key[j] = i < B ? (uint32_t)scol[i] : 0u;
         val[j] = i;
     }
-    block_sort_pairs<E>(key, val, B, bits, kbuf, vbuf, L);
+    block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
+    SMALL_STAMP(5);                                                      // col sort done
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int j = threadIdx.x * E + e;
@@ -297,9 +319,11 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
         plan.c_w[j] = sw[p];
         plan.c_y[j] = sy[p];
     }
-    small_side<E>(reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 1, L,
+    SMALL_STAMP(6);                                                      // col arrays stored
+    small_side<T, E>(reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 1, L,
                   SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec}, plan.counts, plan.heavy);
 
+    SMALL_STAMP(7);                                                      // col side numbered and stored
     // ---- ids mapped to 0, and the spare words
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) mapped += __shfl_xor(mapped, dlt, 64);
@@ -307,35 +331,40 @@ __global__ __launch_bounds__(kSmallThreads) void plan_small_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = 0;
-        for (int wv = 0; wv < kSmallWaves; ++wv) total += L.s_mapped[wv];
+        for (int wv = 0; wv < NW; ++wv) total += L.s_mapped[wv];
         plan.counts[5] = total;
         plan.counts[6] = plan.counts[7] = 0;
     }
+    SMALL_STAMP(8);
 }
 
-template <int E>
+template <int T, int E>
 static int launch_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                         const glove_plan *plan, hipStream_t st)
 {
-    const size_t smem = small_lds_bytes<E>();
+    const size_t smem = small_lds_bytes<T, E>();
     int bits = 1;                                                        // ids < 2^bits
     while (bits < 31 && (1u << bits) < (uint32_t)V) ++bits;
     // above the 64 KiB default of dynamic LDS: the limit is raised explicitly
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<E>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plan_small_kernel<E>, dim3(1), dim3(kSmallThreads), smem, st, row, col, w, y, (int)B, (int)V,
+    hipLaunchKernelGGL((plan_small_kernel<T, E>), dim3(1), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
                        bits, *plan);
     return (int)hipGetLastError();
 }
 
-// host side: called from glove_plan_build for B <= kSmallPlanMax (4,096 = kSmallThreads x 16)
+#ifdef GLOVE_STAMPS
+extern "C" int glove_debug_set_small_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &p, sizeof(p)); }
+#endif
+
+// host side: called from glove_plan_build for B <= kSmallPlanMax (4,096)
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st)
 {
-    if (B <= 4 * kSmallThreads) return launch_small<4>(row, col, w, y, B, V, plan, st);
-    if (B <= 8 * kSmallThreads) return launch_small<8>(row, col, w, y, B, V, plan, st);
-    return launch_small<16>(row, col, w, y, B, V, plan, st);
+    if (B <= 1024) return launch_small<256, 4>(row, col, w, y, B, V, plan, st);
+    if (B <= 2048) return launch_small<1024, 2>(row, col, w, y, B, V, plan, st);
+    return launch_small<1024, 4>(row, col, w, y, B, V, plan, st);
 }
 
 }  // namespace glove
