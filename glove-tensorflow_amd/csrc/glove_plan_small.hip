@@ -5,11 +5,10 @@
 // reference's input_fn does: data_utils.py:12-21) needs the index in a few microseconds, so batches up to 4,096 pairs
 // are indexed by ONE workgroup entirely in LDS: two stable radix sorts by id (hand-written, the ballot-rank scheme of
 // glove_plan.hip's tiled sort on one workgroup; passes of up to 8 bits: two for a 10^4-id vocabulary) and, per side,
-// three scans over the threads that number the chunks and ids and close the id records.  Four waves: a barrier among four
-// waves costs a fraction of one among sixteen, and this kernel is a chain of ~30 of them (the first form — 1,024
-// threads, rocPRIM's block sort, six scans and a binary search per side — took 21 us at B = 1,024; a bitonic sort of
-// 64-bit (id, position) keys before it 110 us at B = 4,096).  The result is identical to the general path and to
-// oracle/glove_ref.py:build_plan.
+// three scans over the threads that number the chunks and ids and close the id records (the first form — rocPRIM's block
+// sort, six scans and a binary search per side — took 21 us at B = 1,024 and 60 at 4,096; a bitonic sort of 64-bit
+// (id, position) keys before it 110 us at B = 4,096; this one 17 and 43 in the stamped diagnostic build).  The result is
+// identical to the general path and to oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
 
 namespace glove {
@@ -26,9 +25,10 @@ __device__ unsigned long long *g_small_stamps = nullptr;     // [waves][16], set
 #define SMALL_STAMP(slot) ((void)0)
 #endif
 
-// Workgroup size by batch: 4 waves x 4 pairs per thread up to 1,024 pairs (the reference's default batch: barriers among
-// four waves are cheap), 16 waves above it (the ranking rounds of a pass run on every wave at once: B = 4,096 measured
-// 85 us per dynamic step with 4 waves x 16 pairs, 73 with 16 x 4).
+// Workgroup size: 16 waves.  A sort pass costs ~2 us whatever the number of ranking rounds per wave (its barriers and the
+// column walk of the wave counters are the fixed part), so the rounds are spread over as many waves as a workgroup has:
+// measured per step with the index rebuilt (text8 d = 64): B = 1,024: 16 waves x 1 pair per thread 31.0 us, 4 x 4 33.7;
+// B = 4,096: 16 x 4 56.7 us, 4 x 16 85 (rocPRIM's block sort with six scans per side: 36 / 73).
 constexpr int kSmallMaxWaves = 16;
 constexpr int kSmallDigits = 256;
 
@@ -362,7 +362,7 @@ extern "C" int glove_debug_set_small_stamps(void *p) { return (int)hipMemcpyToSy
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st)
 {
-    if (B <= 1024) return launch_small<256, 4>(row, col, w, y, B, V, plan, st);
+    if (B <= 1024) return launch_small<1024, 1>(row, col, w, y, B, V, plan, st);
     if (B <= 2048) return launch_small<1024, 2>(row, col, w, y, B, V, plan, st);
     return launch_small<1024, 4>(row, col, w, y, B, V, plan, st);
 }
