@@ -423,12 +423,19 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            if ahead > 1:
-                sweep_pipelined(spg)
-            else:
-                for i in range(spg):
-                    step(i)
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                if ahead > 1:
+                    sweep_pipelined(spg)
+                else:
+                    for i in range(spg):
+                        step(i)
+        except Exception as exc:             # a transport that refuses capture: the same steps, launched eagerly
+            if mode == "single":
+                raise
+            log("  hipGraph capture of the multi-rank step failed (%s: %s): launching eagerly" % (type(exc).__name__, exc))
+            graph = None
+            torch.cuda.synchronize()
 
     def run(n_steps, first):
         done = 0
