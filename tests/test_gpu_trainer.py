@@ -297,14 +297,17 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     job = tmp_path / "job"
     argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
             "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
-            "--train-steps", "60", "--log-every", "20"]                # unseeded: rank 0 draws the seed for both
+            "--train-steps", "60", "--log-every", "10"]                # unseeded: rank 0 draws the seed for both
     mp.spawn(_two_rank_trainer, args=(29700 + os.getpid() % 200, argv, str(tmp_path)), nprocs=2, join=True)
     a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(a[n], b[n]), n
     assert a["g"] == b["g"] and a["step"] == b["step"] == 60
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
-    assert [r["global_step"] for r in log] == [20, 40, 60] and log[-1]["loss"] < log[0]["loss"]
+    assert [r["global_step"] for r in log] == [10, 20, 30, 40, 50, 60]
+    # a log line is the loss of ONE batch of 128 pairs (the run is unseeded and the batches are reshuffled): ~ 4 at step 10,
+    # ~ 2 +- 0.4 by step 50 — the mean of the last two lines against the first is far outside that noise
+    assert (log[-1]["loss"] + log[-2]["loss"]) / 2 < log[0]["loss"]
     assert (job / "model.ckpt-60.pt").exists()
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
     assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
