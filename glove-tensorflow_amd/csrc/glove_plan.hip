@@ -728,7 +728,8 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
     if (B <= kSmallPlanMax) {                                                          // launch-bound regime
-        return plan_build_small(row, col, w, y, B, V, plan, st);         // (writes the chunk records itself when the plan has them)
+        if (int rc = plan_build_small(row, col, w, y, B, V, plan, st)) return rc;
+        return plan->r_crec ? launch_fill_records(plan, st) : 0;
     }
     const PlanWs pw = carve_plan_ws(ws, B);
     if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;

@@ -119,10 +119,6 @@ __device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], i
 
 struct SmallSideOut {
     int32_t *chunk_id, *chunk_start, *uniq_slot, *uniq_rec;
-    // per-chunk records (glove_plan.r_crec / c_crec; nullptr = none) and this side's pair fields by position, in LDS
-    int32_t *crec;
-    const int32_t *partner;
-    const float *w, *y;
 };
 
 // ids[k] (sorted ids, LDS) -> chunk / id arrays of one side.  Thread t owns positions t E .. t E + E - 1.  Position k opens an
@@ -201,15 +197,12 @@ __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_
     int before = ps - packed;
     for (int wv = 0; wv < wave; ++wv) before += L.s_sum[wv];
     int ui = before >> 16, ci = before & 0xffff;
-    int open_ui[E], open_ci[E], rs_at[E];
-    rs = run_start;
+    int open_ui[E], open_ci[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = k0 + e;
         open_ui[e] = ui;
         open_ci[e] = ci;
-        if (uniq >> e & 1) rs = k;
-        rs_at[e] = rs;                                                      // start of the run position k lies in
         if (k >= B) continue;
         if (uniq >> e & 1) o.uniq_slot[ui++] = ci;
         if (chunk >> e & 1) { o.chunk_id[ci] = id[e + 1]; o.chunk_start[ci] = k; ++ci; }
@@ -220,36 +213,12 @@ __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_
             counts[2 * side + 1] = ui;
         }
     }
-    // ---- {id, first chunk, chunks, pairs} per id: its pairs end where the next id opens; its chunks restart with it.  And
-    // the per-chunk records (the layout fill_records of glove_plan.hip writes: header {id, pairs, the id's position, first
-    // chunk flag | chunks of the id behind this one}, then blocks of 8 pairs {partner[8] | w[8] | y[8]}, padding slots
-    // replaying the chunk's first pair with weight 0), straight from the pair fields in LDS: no launch of its own
-    const int capP = rec_cap(cap), rq = 1 + 3 * capP / 4;
+    // ---- {id, first chunk, chunks, pairs} per id: its pairs end where the next id opens; its chunks restart with it
 #pragma unroll
     for (int e = E - 1; e >= 0; --e) {
-        const int k = k0 + e;
-        if (k >= B) continue;
-        const int end = next_open;                                          // where the run of position k ends
-        if (o.crec && (chunk >> e & 1)) {
-            const int pairs_id = end - rs_at[e], chunks_id = (pairs_id + cap - 1) / cap, idx = (k - rs_at[e]) / cap;
-            const int n = end - k < cap ? end - k : cap;
-            const bool first = uniq >> e & 1;
-            int4 *rec = reinterpret_cast<int4 *>(o.crec) + (size_t)open_ci[e] * rq;
-            rec[0] = make_int4(id[e + 1], n, first ? open_ui[e] : open_ui[e] - 1,
-                               (int)((uint32_t)(chunks_id - idx - 1) | (first ? 0x80000000u : 0u)));
-            for (int f = 1; f < rq; ++f) {
-                const int b = (f - 1) / 6, r = (f - 1) % 6, field = r / 2, t0 = b * kRecPad + (r % 2) * 4;
-                int v[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int t = t0 + x, q = k + (t < n ? t : 0);
-                    v[x] = field == 0 ? o.partner[q] : field == 1 ? __float_as_int(t < n ? o.w[q] : 0.f) : __float_as_int(o.y[q]);
-                }
-                rec[f] = make_int4(v[0], v[1], v[2], v[3]);
-            }
-        }
         if (!(uniq >> e & 1)) continue;
-        const int pairs = end - k, chunks = (pairs + cap - 1) / cap;
+        const int k = k0 + e;
+        const int pairs = next_open - k, chunks = (pairs + cap - 1) / cap;
         reinterpret_cast<int4 *>(o.uniq_rec)[open_ui[e]] = make_int4(id[e + 1], open_ci[e], chunks, pairs);
         if (chunks > heavy_chunks) {
             const int slot = atomicAdd(counts + 4, 1);                      // zeroed at the kernel's start
@@ -327,8 +296,7 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
     __syncthreads();                                                     // (counts[4] = 0 is also ordered before the appends)
     SMALL_STAMP(3);                                                      // pair fields gathered, row arrays stored
     small_side<T, E>(srow, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 0, L,
-                  SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec, plan.r_crec, scol, sw, sy},
-                  plan.counts, plan.heavy);
+                  SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts, plan.heavy);
 
     SMALL_STAMP(4);                                                      // row side numbered and stored
     // ---- col side: stable sort of the row-sorted pairs by col id
@@ -340,35 +308,20 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
     }
     block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
     SMALL_STAMP(5);                                                      // col sort done
-    {
-        // the col side's pair fields in col order: to the plan, and into LDS (over the row-sorted col / w / y, which nobody
-        // reads any more once every thread has picked its pairs) for the col side's chunk records
-        int32_t cp[E];
-        float cw[E], cy[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int j = threadIdx.x * E + e;
-            const int p = j < B ? vbuf[j] : 0;
-            cp[e] = srow[p]; cw[e] = sw[p]; cy[e] = sy[p];
-            if (j >= B) continue;
-            plan.c_perm[j] = p;
-            plan.r_to_c[p] = j;
-            plan.c_partner[j] = cp[e];
-            plan.c_w[j] = cw[e];
-            plan.c_y[j] = cy[e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int j = threadIdx.x * E + e;
-            if (j < B) { scol[j] = cp[e]; sw[j] = cw[e]; sy[j] = cy[e]; }
-        }
-        __syncthreads();
+    for (int e = 0; e < E; ++e) {
+        const int j = threadIdx.x * E + e;
+        if (j >= B) continue;
+        const int p = vbuf[j];
+        plan.c_perm[j] = p;
+        plan.r_to_c[p] = j;
+        plan.c_partner[j] = srow[p];
+        plan.c_w[j] = sw[p];
+        plan.c_y[j] = sy[p];
     }
     SMALL_STAMP(6);                                                      // col arrays stored
     small_side<T, E>(reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 1, L,
-                  SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec, plan.c_crec, scol, sw, sy},
-                  plan.counts, plan.heavy);
+                  SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec}, plan.counts, plan.heavy);
 
     SMALL_STAMP(7);                                                      // col side numbered and stored
     // ---- ids mapped to 0, and the spare words
