@@ -2182,4 +2182,47 @@ int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_
     return 0;
 }
 
+int glove_steps_rebuilt_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t n_steps,
+                            int32_t V, const glove_build_ring *ring, const glove_tables *t, const glove_hyper *h, void *ws,
+                            size_t ws_bytes, float *G_flat, float *loss_out, void *stream)
+{
+    if (!row || !col || !w || !y || B <= 0 || n_steps < 0 || !ring || !t || !h) return GLOVE_E_BADARG;
+    if (ring->n < 1 || ring->n > 16 || !ring->plans || !ring->plan_ws || !ring->streams || !ring->built || !ring->stepped ||
+        !ring->start)
+        return GLOVE_E_BADARG;
+    for (int k = 0; k < ring->n; ++k)
+        if (!ring->plans[k] || ring->plans[k]->B != B || !ring->plan_ws[k] || !ring->built[k] || !ring->stepped[k]) return GLOVE_E_BADARG;
+    hipStream_t main = (hipStream_t)stream;
+    const int ahead = ring->n;
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+    auto launch_build = [&](int i) -> int {
+        const int k = i % ahead;
+        hipStream_t bs = (hipStream_t)ring->streams[k];
+        // the staging plan is free once the step that read it last is done; the first builds of a call wait for what the
+        // compute stream held when the call began (the previous call's steps among it)
+        HIP_OK(hipStreamWaitEvent(bs, (hipEvent_t)(i >= ahead ? ring->stepped[k] : ring->start), 0));
+        if (int rc = glove_plan_build(row + (size_t)i * B, col + (size_t)i * B, w + (size_t)i * B, y + (size_t)i * B, B, V,
+                                      ring->plans[k], ring->plan_ws[k], ring->plan_ws_bytes, bs))
+            return rc;
+        HIP_OK(hipEventRecord((hipEvent_t)ring->built[k], bs));
+        return 0;
+    };
+    HIP_OK(hipEventRecord((hipEvent_t)ring->start, main));
+    for (int i = 0; i < ahead && i < n_steps; ++i)
+        if (int rc = launch_build(i)) return rc;
+    for (int i = 0; i < n_steps; ++i) {
+        const int k = i % ahead;
+        HIP_OK(hipStreamWaitEvent(main, (hipEvent_t)ring->built[k], 0));
+        float *lo = i == n_steps - 1 ? loss_out : nullptr;
+        if (int rc = G_flat ? glove_step_adam_f32(ring->plans[k], t, h, ws, ws_bytes, G_flat, lo, stream)
+                            : glove_step_adagrad_f32(ring->plans[k], t, h, ws, ws_bytes, lo, stream))
+            return rc;
+        HIP_OK(hipEventRecord((hipEvent_t)ring->stepped[k], main));
+        if (i + ahead < n_steps)
+            if (int rc = launch_build(i + ahead)) return rc;
+    }
+#undef HIP_OK
+    return 0;
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 5
+GLOVE_ABI_VERSION = 6
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = (
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_loss_partials_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
-    "glove_count_packed_f32",
+    "glove_count_packed_f32", "glove_steps_rebuilt_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -83,6 +83,12 @@ class GlovePlan(C.Structure):
 
 class GlovePackedList(C.Structure):
     _fields_ = [("entries", _fp), ("ids", _fp), ("header", _fp), ("n", C.c_int32), ("side", C.c_int32)]
+
+
+class GloveBuildRing(C.Structure):
+    _fields_ = [("n", C.c_int32), ("plans", C.POINTER(C.POINTER(GlovePlan))), ("plan_ws", C.POINTER(C.c_void_p)),
+                ("plan_ws_bytes", C.c_size_t), ("streams", C.POINTER(C.c_void_p)), ("built", C.POINTER(C.c_void_p)),
+                ("stepped", C.POINTER(C.c_void_p)), ("start", C.c_void_p)]
 
 
 class GloveHipError(RuntimeError):
@@ -138,6 +144,8 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_fused_step_bytes": (sz, []),
         "glove_canonicalize_f32": (C.c_int, [P(GloveTables), vp]),
         "glove_rowside_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
+        "glove_steps_rebuilt_f32": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, P(GloveBuildRing), P(GloveTables), P(GloveHyper), vp, sz,
+                                              vp, vp, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
@@ -767,6 +775,42 @@ class GloveHip:
         _check(self.lib.glove_steps_adam_f32(arr, len(plans), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
                                              ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_steps_adam_f32")
+
+    # ---- steps over batches indexed as they are used (reshuffled epochs)
+    def make_build_ring(self, plans, workspaces, streams):
+        """The staging plans, build workspaces and build streams of glove_steps_rebuilt_f32 with the events it needs
+        (torch events, recorded once so that their handles exist).  Keep the returned object alive while it is in use."""
+        n = len(plans)
+        dev = self.device
+        events = [torch.cuda.Event() for _ in range(2 * n + 1)]
+        with torch.cuda.device(dev):
+            for ev in events:
+                ev.record()
+        ring = GloveBuildRing()
+        ring.n = n
+        keep = dict(plans=(C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans]),
+                    ws=(C.c_void_p * n)(*[w.data_ptr() for w in workspaces]),
+                    streams=(C.c_void_p * n)(*[s.cuda_stream for s in streams]),
+                    built=(C.c_void_p * n)(*[e.cuda_event for e in events[:n]]),
+                    stepped=(C.c_void_p * n)(*[e.cuda_event for e in events[n:2 * n]]),
+                    objects=(plans, workspaces, streams, events))
+        ring.plans, ring.plan_ws, ring.streams = keep["plans"], keep["ws"], keep["streams"]
+        ring.built, ring.stepped, ring.start = keep["built"], keep["stepped"], events[2 * n].cuda_event
+        ring.plan_ws_bytes = min(w.numel() for w in workspaces)
+        ring._keep = keep
+        return ring
+
+    def steps_rebuilt(self, row, col, w, y, B: int, n_steps: int, V: int, ring, tables, hyper, ws, G_flat=None, loss_out=None):
+        """n_steps steps over consecutive batches of B pairs of the (resident) arrays, each batch indexed on one of the
+        ring's build streams while earlier steps run on the current stream (the loop runs in C)."""
+        _require(row, torch.int32); _require(col, torch.int32); _require(w, torch.float32); _require(y, torch.float32)
+        if min(row.numel(), col.numel(), w.numel(), y.numel()) < n_steps * B:
+            raise GloveHipError("%d steps of %d pairs need %d pairs" % (n_steps, B, n_steps * B))
+        adam = G_flat is not None
+        struct = tables.struct() if adam else _step_struct(tables, [p for p in ring._keep["objects"][0]], hyper)
+        _check(self.lib.glove_steps_rebuilt_f32(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n_steps, V, C.byref(ring),
+                                                C.byref(struct), C.byref(hyper), _ptr(ws), ws.numel(), _ptr(G_flat),
+                                                _ptr(loss_out), _stream()), "glove_steps_rebuilt_f32")
 
     # ---- eval / predict
     def eval_sums(self, row, col, w, y, tables, sums=None) -> torch.Tensor:

@@ -642,13 +642,19 @@ class ReshufflingRunner:
     On one rank every form gives exactly what the single-GPU runner gives.
     """
 
-    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True):
+    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True, streamed=None):
+        """`streamed` (one GPU, default there): the loop of builds and steps runs in C on real streams
+        (glove_steps_rebuilt_f32) instead of being replayed from hipGraphs — the branches of a graph run mostly one after the
+        other on this runtime, builds on their own streams run beside the steps."""
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
         self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
         self.graphs_on = bool(graphs) and hip is not None and (
             stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
+        self.streamed = (stepper is None and hip is not None) if streamed is None else bool(streamed) and stepper is None and hip is not None
+        if self.streamed:
+            self.graphs_on = False
         self.sharded = isinstance(stepper, ShardedStepper)
         self.loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.graphs = {}
@@ -681,6 +687,7 @@ class ReshufflingRunner:
             self.window = tuple(torch.empty(self.burst * B, dtype=t.dtype, device=dev)
                                 for t in (stream.row, stream.col, stream.w, stream.y))
         self.G = hip.dense_grad_buffer(tables) if stepper is None and tables.optimizer == "Adam" else None
+        self.build_ring = hip.make_build_ring(self.ring, self.ring_ws, self.ring_streams) if self.streamed else None
         # every kernel (and collective) of the sequence runs once outside any capture, on throw-away tables of the same shape
         from trainer.hip_api import DeviceTables
         real = self.tables
@@ -755,13 +762,18 @@ class ReshufflingRunner:
             if self.sharded:
                 self._prepare_epoch()
         first = self.position
-        count = min(n_steps, nb - first, self.burst)
+        count = min(n_steps, nb - first) if self.streamed else min(n_steps, nb - first, self.burst)
         if self.sharded:
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
         elif self.hip is None:                     # a test backend: one synchronous build per step
             for b in range(first, first + count):
                 self.stepper.step(self.stepper.backend.build_plan(*self.stream.batch(b), self.stream.V, self.cap))
+        elif self.streamed:
+            B = self.stream.B
+            s0 = first * B
+            self.hip.steps_rebuilt(self.stream.row[s0:], self.stream.col[s0:], self.stream.w[s0:], self.stream.y[s0:], B, count,
+                                   self.stream.V, self.build_ring, self.tables, self.hyper, self.step_ws, self.G, self.loss_out)
         elif self.graphs_on:
             count = 1 << (count.bit_length() - 1)      # the largest power of two that fits: the caller comes back for the rest
             B = self.stream.B

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 5   /* 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 6   /* 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -312,6 +312,29 @@ int glove_canonicalize_f32(const glove_tables *t, void *stream);
  * receives the scalars of the LAST step. */
 int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
                             const glove_hyper *h, void *ws, size_t ws_bytes, float *loss_out, void *stream);
+/* ---- a stream whose batches are indexed as they are used (reshuffled epochs: reference data_utils.py:12-21) ---------------
+ * n consecutive steps over the batches row/col/w/y[i B .. (i + 1) B), i = 0 .. n-1, the dedup index of batch i built into
+ * staging plan i % ring.n on ring.streams[i % ring.n] while earlier steps run on `stream`: ring.n index builds are in flight,
+ * the way an input pipeline prefetches batches.  The build of batch i + ring.n waits for the step that read the same staging
+ * plan (event ring.stepped[i % n]), step i waits for its index (ring.built[i % n]); the first builds of a call wait for
+ * everything enqueued on `stream` before the call (ring.start).  All streams and events are the caller's (the library
+ * creates nothing); the loop of launches and event operations runs in C: from Python a step of the reference's default batch
+ * costs more host time than its kernels take.  G_flat == NULL: Adagrad (glove_step_adagrad_f32 per step); otherwise
+ * Keras-legacy Adam with G_flat as glove_step_adam_f32 uses it.  loss_out: the last step's scalars. */
+typedef struct glove_build_ring {
+    int32_t n;                      /* staging plans = build streams, 1 .. 16 */
+    const glove_plan *const *plans; /* [n] staging plans of B pairs at full capacity (cap_chunks >= B) */
+    void *const *plan_ws;           /* [n] build workspaces of plan_ws_bytes >= glove_plan_workspace_bytes(B, V) each */
+    size_t plan_ws_bytes;
+    void *const *streams;           /* [n] hipStream_t */
+    void *const *built;             /* [n] hipEvent_t */
+    void *const *stepped;           /* [n] hipEvent_t */
+    void *start;                    /* hipEvent_t */
+} glove_build_ring;
+int glove_steps_rebuilt_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
+                            int32_t n_steps, int32_t V, const glove_build_ring *ring, const glove_tables *t,
+                            const glove_hyper *h, void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
+
 /* One Keras-legacy Adam step.  G_flat (glove_dense_grad_floats floats, all zero on entry) is scratch and is all zero
  * again on return.  A batch of at most (V_row + V) / 2 pairs takes two launches: the passes also mark the batch's
  * ids (in G_flat's bias segments), then one kernel applies the marked ids and gives every other row the G = 0

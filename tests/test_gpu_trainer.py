@@ -435,10 +435,12 @@ def test_non_finite_loss_stops_training(hip, tmp_path):
         estimator.main(argv)
 
 
-@pytest.mark.parametrize("optimizer,lr,B", [("Adagrad", 0.05, 256), ("Adam", 0.001, 256), ("Adagrad", 0.05, 5000)])
-def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B):
-    """--epoch-shuffle full: cached hipGraphs of prefetched index builds + steps, replayed over re-permuted
-    buffers, give bit for bit what building and stepping batch after batch gives, across epoch boundaries."""
+@pytest.mark.parametrize("optimizer,lr,B,streamed", [("Adagrad", 0.05, 256, True), ("Adam", 0.001, 256, True), ("Adagrad", 0.05, 5000, True),
+                                                     ("Adagrad", 0.05, 256, False), ("Adam", 0.001, 256, False), ("Adagrad", 0.05, 5000, False)])
+def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B, streamed):
+    """--epoch-shuffle full: prefetched index builds + steps — issued by glove_steps_rebuilt_f32 on real streams (streamed),
+    or replayed from cached hipGraphs over a fixed window — over re-permuted buffers give bit for bit what building and
+    stepping batch after batch gives, across epoch boundaries."""
     from trainer import synthetic
     from trainer.data_utils import NonzeroStream
     from trainer.hip_api import DeviceTables, make_hyper
@@ -456,7 +458,8 @@ def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B)
         nb = stream.batches_per_epoch
         steps = 2 * nb + 7                                  # two full epochs and a bit
         if mode == "runner":
-            runner = ReshufflingRunner(hip, stream, tables, hyper, ahead=3, burst=16)
+            runner = ReshufflingRunner(hip, stream, tables, hyper, ahead=3, burst=16, streamed=streamed)
+            assert runner.streamed == streamed and runner.graphs_on == (not streamed)
             done = 0
             while done < steps:
                 done += runner.run(steps - done)
