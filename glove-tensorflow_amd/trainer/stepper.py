@@ -643,16 +643,17 @@ class ReshufflingRunner:
     """
 
     def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True, streamed=None):
-        """`streamed` (one GPU, default there): the loop of builds and steps runs in C on real streams
-        (glove_steps_rebuilt_f32) instead of being replayed from hipGraphs — the branches of a graph run mostly one after the
-        other on this runtime, builds on their own streams run beside the steps."""
+        """`streamed` (one GPU): the loop of builds and steps runs in C on real streams (glove_steps_rebuilt_f32) instead of
+        being replayed from hipGraphs.  Not the default: at the reference's batch size it is bound by the host's launch
+        calls (Adagrad 40 k steps/s, Adam 27 k) where the replayed graphs, whose branches mostly run one after the other,
+        reach 40-47 k and 31 k."""
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
         self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
         self.graphs_on = bool(graphs) and hip is not None and (
             stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
-        self.streamed = (stepper is None and hip is not None) if streamed is None else bool(streamed) and stepper is None and hip is not None
+        self.streamed = bool(streamed) and stepper is None and hip is not None
         if self.streamed:
             self.graphs_on = False
         self.sharded = isinstance(stepper, ShardedStepper)
