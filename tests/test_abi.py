@@ -52,8 +52,10 @@ def test_struct_layout_matches_the_c_header(tmp_path):
                    'sizeof(glove_plan), offsetof(glove_tables, scalars), offsetof(glove_hyper, inv_batch), '
                    'offsetof(glove_plan, host_counts), offsetof(glove_plan, r_to_c), offsetof(glove_plan, c_crec));\n'
                    'printf("%zu %zu %zu ", offsetof(glove_tables, R), offsetof(glove_hyper, sides), offsetof(glove_tables, d_model));\n'
-                   'printf("%zu %zu %zu %zu %zu\\n", offsetof(glove_tables, R_ver), offsetof(glove_hyper, step_form), '
+                   'printf("%zu %zu %zu %zu %zu ", offsetof(glove_tables, R_ver), offsetof(glove_hyper, step_form), '
                    'offsetof(glove_plan, V_row), sizeof(glove_packed_list), offsetof(glove_packed_list, n));\n'
+                   'printf("%zu %zu %zu\\n", sizeof(glove_build_ring), offsetof(glove_build_ring, plan_ws_bytes), '
+                   'offsetof(glove_build_ring, start));\n'
                    'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(REPO / "include"), str(src), "-o", str(exe)], check=True)
@@ -62,7 +64,8 @@ def test_struct_layout_matches_the_c_header(tmp_path):
     assert got == [C.sizeof(T), C.sizeof(H), C.sizeof(P), T.scalars.offset, H.inv_batch.offset,
                    P.host_counts.offset, P.r_to_c.offset, P.c_crec.offset, T.R.offset, H.sides.offset, T.d_model.offset,
                    T.R_ver.offset, H.step_form.offset, P.V_row.offset, C.sizeof(hip_api.GlovePackedList),
-                   hip_api.GlovePackedList.n.offset]
+                   hip_api.GlovePackedList.n.offset, C.sizeof(hip_api.GloveBuildRing), hip_api.GloveBuildRing.plan_ws_bytes.offset,
+                   hip_api.GloveBuildRing.start.offset]
 
 
 def test_missing_library_is_an_error_not_a_fallback(tmp_path):
