@@ -42,7 +42,7 @@ def _assert_same_bits(a, b, info=""):
     assert torch.equal(a.scalars, b.scalars) and a.global_step == b.global_step, info
 
 
-@pytest.mark.parametrize("B", [300, 9000])        # one-workgroup builder / rocPRIM builder
+@pytest.mark.parametrize("B", [300, 9000])        # one-workgroup builder / tiled builder
 def test_plan_maps_out_of_range_ids_to_zero(hip, B):
     """Ids outside [0, V) must never reach the tables: both builders treat them as id 0 (the reference's
     unknown-token id, estimator.py:26-28) and count them in counts[5]."""
