@@ -611,6 +611,9 @@ def brief(r: dict) -> dict:
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    # a rank that hangs (a collective nobody else entered) ends with a traceback instead of holding the node
+    import faulthandler
+    faulthandler.dump_traceback_later(max(900.0, 3.0 * args.budget_seconds), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -712,6 +715,7 @@ def main(argv=None):
     out["wall_seconds"] = time.perf_counter() - T_START
     if rank == 0:
         print(json.dumps(out), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         import gc
         gc.collect()                 # no captured collective may outlive the communicator: RCCL's teardown waits for them
