@@ -611,9 +611,6 @@ def brief(r: dict) -> dict:
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    # a rank that hangs (a collective nobody else entered) ends with a traceback instead of holding the node
-    import faulthandler
-    faulthandler.dump_traceback_later(max(900.0, 3.0 * args.budget_seconds), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -626,6 +623,12 @@ def main(argv=None):
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # a rank that hangs (a collective nobody else entered) ends with a traceback instead of holding the node
+    import faulthandler
+    try:
+        faulthandler.dump_traceback_later(max(900.0, 3.0 * args.budget_seconds), exit=True)
+    except (OSError, ValueError):               # no usable stderr
+        pass
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
