@@ -123,6 +123,7 @@ __device__ inline void sort_load_keys(const SortIn &in, int64_t base, int32_t (&
 template <int E>
 __global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
 {
+    static_assert(kSortThreads == kMaxDigits, "one thread per digit zeroes and stores the histogram");
     __shared__ int hist[kMaxDigits];
     const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hist[threadIdx.x] = 0;
