@@ -23,8 +23,8 @@ tok = np.asarray(vocab, dtype=object)
 neg = (np.random.default_rng(0).random(len(row)) * 5).astype(np.float32)
 pd.DataFrame({"row_token": tok[row.numpy()], "col_token": tok[col.numpy()], "glove_weight": w.numpy(),
               "glove_value": y.numpy(), "value": np.exp(y.numpy()), "neg_weight": neg}).to_csv(tmp / "interaction.csv", index=False)
-runs = (("Adagrad", "0.05", "1024", estimator.main, steps), ("Adam", "0.001", "1024", estimator.main, steps),
-        ("Adagrad", "0.05", "131072", estimator.main, steps // 20),
+runs = (("Adagrad", "0.05", "1024", "static", steps), ("Adam", "0.001", "1024", "static", steps),
+        ("Adagrad", "0.05", "131072", "static", steps // 20), ("Adagrad", "0.05", "131072", "full", steps // 20),
         ("Adagrad", "0.05", "1024", logistic_matrix_factorisation.main, steps // 4),
         ("Adagrad", "0.05", "1024", "full", steps), ("Adam", "0.001", "4096", "full", steps // 4),
         # the fused step forms forced on (the library would take two launches at this scale): slots and twinned row table,
@@ -35,8 +35,8 @@ for opt, lr, bs, entry, n in runs:
     extra = []
     if isinstance(entry, str) and entry.startswith("form"):
         entry, extra = estimator.main, ["--step-form", entry[4:]]
-    if entry == "full":                   # a new permutation every epoch, indexes prefetched, bursts from cached graphs
-        entry, extra = estimator.main, ["--epoch-shuffle", "full"]
+    if entry in ("full", "static"):       # full (the default): a new permutation every epoch, indexes prefetched, bursts from cached graphs
+        entry, extra = estimator.main, ["--epoch-shuffle", entry]
     job = tmp / ("job_%s_%s_%s%s" % (opt, bs, entry.__module__.split(".")[-1], "_".join([""] + extra).replace("-", "")))
     torch.cuda.reset_peak_memory_stats()
     entry(["--train-csv", str(tmp / "interaction.csv"), "--vocab-txt", str(tmp / "vocab.txt"), "--job-dir", str(job),
