@@ -4,9 +4,9 @@ out=gpurun_out/table
 rm -rf $out; mkdir -p $out
 run() { name=$1; shift; timeout -k 10 400 python bench.py --single --no-cpu-baseline "$@" > $out/$name.log 2>&1 || echo "$name FAILED"; }
 timeout -k 10 600 python bench.py > $out/default.log 2>&1 || echo "default FAILED"
-run b1024 --batch-size 1024 --steps 4000 --warmup 200
-run b1m --batch-size 1048576
-run adam1024 --optimizer Adam --batch-size 1024 --steps 4000 --warmup 200 --learning-rate 0.001
+run b1024 --workload text8_d64 --batch-size 1024 --steps 4000 --warmup 200
+run b1m --workload text8_d64 --batch-size 1048576
+run adam1024 --workload text8_d64 --optimizer Adam --batch-size 1024 --steps 4000 --warmup 200 --learning-rate 0.001
 run c3_131k_two_launch --workload text8_v50k_d300 --step-form 1
 run c3_1m --workload text8_v50k_d300 --batch-size 1048576 --steps 60 --warmup 10
 run c4_1m_two_launch --workload zipf_v400k_d300 --batch-size 1048576 --steps 40 --warmup 10 --step-form 1
