@@ -1,5 +1,7 @@
 """CPU tests of the oracle itself: the float64 restatement against finite differences and
 against its scalar-C twin, and the dedup-index construction against brute force."""
+import math
+
 import numpy as np
 import pytest
 
@@ -178,3 +180,55 @@ def test_plan_treats_out_of_range_ids_as_unknown_token():
     assert p["counts"][5] == 3 and q["counts"][5] == 0
     for k in ("r_partner", "c_partner", "r_chunk_id", "c_chunk_id", "c_perm", "r_to_c"):
         np.testing.assert_array_equal(p[k], q[k])
+
+
+@pytest.mark.parametrize("optimizer,lr,steps", [("Adagrad", 0.05, 4), ("Adam", 0.001, 6)])
+def test_oracle_steps_match_an_independent_autodiff_and_optimizer(optimizer, lr, steps):
+    """The restated step against machinery the oracle shares no code with: the loss of SURVEY.md Appendix A written as a
+    torch expression (float64), gradients by torch.autograd (duplicate ids sum as Keras' dedup does), the update by
+    torch.optim.  Adagrad(initial_accumulator_value=0.1, eps=1e-7) IS the Keras-legacy rule (sum, then square; eps outside
+    the root; untouched rows do not move).  torch's Adam places eps differently (sqrt(v)/sqrt(1-b2^t) + eps where Keras has
+    sqrt(v) + eps under lr_t = lr sqrt(1-b2^t)/(1-b1^t)); handing torch eps/sqrt(1-b2^t) at step t makes the two the same
+    expression, and — like Keras' legacy sparse path, unlike a lazy Adam — torch's dense Adam moves EVERY row every step.  Not TensorFlow, so the step stays unpinned; it pins
+    the restatement's calculus and update algebra."""
+    import torch
+    B, V, d = 64, 11, 6
+    hp = ref.Hyper(learning_rate=lr, l2_reg=0.05, reg_mult=2.0)
+    t = ref.Tables(V, d, optimizer, dtype=np.float64, seed=4)
+    t.g = np.float64(0.1)
+    P = {n: torch.tensor(np.array(getattr(t, n)), dtype=torch.float64, requires_grad=True) for n in ("R", "C", "br", "bc")}
+    P["g"] = torch.tensor(float(t.g), dtype=torch.float64, requires_grad=True)
+    params = list(P.values())
+    f32 = lambda v: float(np.float32(v))              # Keras holds the hyper-parameters in float32 (oracle apply_update)
+    opt = (torch.optim.Adagrad(params, lr=f32(lr), initial_accumulator_value=0.1, eps=f32(1e-7)) if optimizer == "Adagrad"
+           else torch.optim.Adam(params, lr=f32(lr), betas=(f32(0.9), f32(0.999)), eps=f32(1e-7)))
+    untouched_moved = False
+    for s in range(steps):
+        row, col, w, y = make_batch(30 + s, B, V)
+        r_, c_ = torch.from_numpy(row).long(), torch.from_numpy(col).long()
+        wt, yt = torch.from_numpy(w).double(), torch.from_numpy(y).double()
+        r, c = P["R"][r_], P["C"][c_]
+        p = (r * c).sum(-1) + P["br"][r_] + P["bc"][c_] + P["g"]
+        L = (wt * (p - yt) ** 2).sum() / B
+        reg = hp.l2_reg / (d * B) * ((r ** 2).sum() + (c ** 2).sum()) + hp.l2_reg / B * ((P["br"][r_] ** 2).sum() + (P["bc"][c_] ** 2).sum()) \
+            + hp.l2_reg * P["g"] ** 2
+        loss = L + hp.reg_mult * reg
+        opt.zero_grad()
+        loss.backward()
+        if optimizer == "Adam":
+            opt.param_groups[0]["eps"] = f32(1e-7) / math.sqrt(1.0 - f32(0.999) ** (s + 1))
+        before = P["R"].detach().clone()
+        opt.step()
+        want_loss, want_L, want_reg = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss.item(), want_loss, rtol=1e-12)
+        np.testing.assert_allclose(L.item(), want_L, rtol=1e-12)
+        rest = np.setdiff1d(np.arange(V), row)
+        if len(rest):
+            moved = bool((P["R"].detach()[rest] != before[rest]).any())
+            untouched_moved |= moved
+            assert moved == (optimizer == "Adam" and s > 0)          # Keras-legacy Adam decays every row once it has momentum
+        tol = dict(rtol=1e-10, atol=1e-13) if optimizer == "Adagrad" else dict(rtol=1e-9, atol=1e-13)
+        for n in ("R", "C", "br", "bc"):
+            np.testing.assert_allclose(P[n].detach().numpy(), getattr(t, n), err_msg="%s after step %d" % (n, s + 1), **tol)
+        np.testing.assert_allclose(P["g"].item(), t.g, **tol)
+    assert untouched_moved == (optimizer == "Adam")
