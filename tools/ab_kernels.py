@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batches", type=int, default=8, help="resident batches cycled through (1: the plan stays cache-warm)")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--check", action="store_true", help="one step per build from equal tables: report the largest difference to the first build")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [x for x in args.libs.split(",") if x] or [None]
@@ -68,6 +69,19 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     res[(cap, v)][name].append(a.elapsed_time(b) * 1e3 / args.reps)
+    if args.check:
+        outs = []
+        for v in range(len(hips)):
+            t2 = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
+            if args.twin:
+                t2.enable_twin()
+            plans = [c[2] for c in configs if c[1] == v][0]
+            for b in range(min(nb, 2)):
+                hips[v].step_adagrad(plans[b], t2, hyper, loss, ws)
+            torch.cuda.synchronize()
+            outs.append([x.clone() for x in (t2.R, t2.C, t2.br, t2.bc, t2.s1["R"], t2.s1["C"], loss)])
+        for v in range(1, len(hips)):
+            print("check lib=%s vs %s: max |diff| %s" % (libs[v], libs[0], ["%.3g" % (a - b).abs().max().item() for a, b in zip(outs[0], outs[v])]))
     print("%s B=%d d=%d  (us per launch incl. launch gaps; median / min over %d rounds)" % (args.workload, B, d, args.rounds))
     for (cap, v), r in res.items():
         print("cap=%-3d lib=%s  " % (cap, libs[v] or "shipped") + "  ".join(
