@@ -361,12 +361,15 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, tables.d) for p in plans) if not dynamic
                          else hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
 
-    staging = hip.build_plan(*batches[0], V, chunk_cap=cap) if dynamic else None   # refilled every step
+    # refilled every step; on big tables with chunk records, so that the rebuilt index is stepped in the fused form too
+    from trainer.hip_api import staging_records
+    rec_kw = dict(records=staging_records(B, tables.V_row, V, tables.d) if mode == "single" and not adam else None)
+    staging = hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) if dynamic else None
     ahead = max(1, build_ahead) if dynamic else 1
     if ahead > 1:
         # a ring of staging plans, scratch buffers and streams: the index of batch i is built on stream i % ahead
         # while earlier steps run; it may start once step i - ahead, the previous reader of its staging plan, is done
-        ring = [staging] + [hip.build_plan(*batches[0], V, chunk_cap=cap) for _ in range(ahead - 1)]
+        ring = [staging] + [hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) for _ in range(ahead - 1)]
         ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev) for _ in range(ahead)]
         ring_streams = [torch.cuda.Stream() for _ in range(ahead)]
 

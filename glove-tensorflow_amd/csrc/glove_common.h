@@ -10,6 +10,11 @@ using f4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
+// Workgroups of a fused (run-merged) pass, whose lane groups take `per` consecutive chunks each instead of striding:
+// the ids of the Zipf head fill consecutive chunks, so a head group's `per` full chunks are a serial chain of per x
+// chunk_cap / 4 partner-row trips — the launch's critical path once `per` is large (V = 400 k, d = 300, B = 1 M, per 27:
+// 407 us per pass; per 23: 290; per 7: 285).  More workgroups keep `per` small for big batches.
+constexpr int kMaxPassBlocks = 8192;
 constexpr int kPartials = 4;       // per-block loss partials: sum w diff^2, sum |r|^2+|c|^2, sum b^2, sum e
 
 // ---- diagnostic build only (-DGLOVE_STAMPS): per-wave wall-clock stamps (s_memrealtime, 100 MHz)
@@ -114,7 +119,7 @@ struct StepWs {
     float *gp_c;     // [cap_chunks*d] col-side
     float *gb_r;     // [cap_chunks]   row-side chunk partial bias gradients (sum e)
     float *gb_c;     // [cap_chunks]
-    float *blockpart;  // [kMaxBlocks*kPartials]
+    float *blockpart;  // [kMaxPassBlocks*kPartials]
     int32_t *work;     // [4 + 2*cap_chunks] fused step forms: count + positions of the ids the apply launch still has to do
     size_t bytes;
 };
@@ -134,7 +139,7 @@ inline StepWs carve_step_ws(void *ws, int64_t B, int32_t cap_chunks, int32_t d)
     s.gp_c = take((size_t)cap_chunks * d);
     s.gb_r = take((size_t)cap_chunks);
     s.gb_c = take((size_t)cap_chunks);
-    s.blockpart = take((size_t)kMaxBlocks * kPartials);
+    s.blockpart = take((size_t)kMaxPassBlocks * kPartials);
     s.work = (int32_t *)take((size_t)4 + 2 * (size_t)cap_chunks);
     s.bytes = off;
     return s;
@@ -148,6 +153,18 @@ inline int blocks_for(int64_t items, int per_block)
     return (int)b;
 }
 
+// The most chunks a side can have: the count itself for a resident plan; for a plan refilled on the device (its counts
+// are not read back) one chunk per distinct id plus one per full chunk_cap pairs — far fewer than the B the arrays are
+// sized for, and `per` below must not grow with the capacity: the ids of the Zipf head sit in consecutive chunks, so a
+// group's `per` full chunks are the launch's critical path (V = 400 k, B = 1 M: per 62 instead of 23 ran a pass in 800
+// instead of 290 us).
+inline int64_t most_chunks(const glove_plan *p, bool row)
+{
+    const int32_t known = p->host_counts[row ? 0 : 2];
+    if (known >= 0) return known;
+    const int64_t bound = (int64_t)p->cap_uniq + p->B / (p->chunk_cap > 0 ? p->chunk_cap : 1) + 1;
+    return bound < p->cap_chunks ? bound : p->cap_chunks;
+}
 // (lanes per row, float4 per lane) covering d4 = d/4 float4 per embedding row with the least
 // idle lanes; a wave64 holds 64/LPR rows at a time.
 struct RowShape { int lpr, nv; };

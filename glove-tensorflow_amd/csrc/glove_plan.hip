@@ -294,6 +294,8 @@ struct SideOut {
     const int64_t *tile_re;                               // [2][ntiles] end of the run crossing a tile's right edge (side_tiles)
     int32_t *heavy;                                       // ids with more than heavy_chunks chunks: (side << 30) | position, any order
     int heavy_chunks, cap_heavy;
+    int32_t *crec[2];                                     // per-chunk records (or nullptr): side_emit writes their headers
+    int rec_dwords;
 };
 
 // flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
@@ -533,11 +535,21 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
     int64_t right = __shfl_down(sfx, 1, 64);               // min over the lanes to my right in this wave
     if (lane == 63) right = INT64_MAX;
     next_open = right < next_open ? right : next_open;
+    int32_t *crec = out.crec[side];
 #pragma unroll
     for (int i = kTilePer - 1; i >= 0; --i) {
-        if (!(flag[i] & 2u)) continue;
+        if (!(flag[i] & 1u)) continue;                     // (a position that opens an id opens a chunk)
         const int64_t k = k0 + i;
-        const int pairs = (int)(next_open - k), chunks = (pairs + chunk_cap - 1) / chunk_cap;
+        const int pairs = (int)(next_open - k), chunks = (pairs + chunk_cap - 1) / chunk_cap;   // from k to the end of its id
+        if (crec) {
+            // the chunk's record header {id, pairs, position of the id among the side's ids, first chunk of its id << 31 |
+            // chunks of the id behind this one}: everything is at hand here (fill_records would bisect uniq_slot for it)
+            const bool opens = (flag[i] & 2u) != 0;
+            reinterpret_cast<int4 *>(crec + (size_t)open_ci[i] * out.rec_dwords)[0] =
+                make_int4(keys[k], pairs < chunk_cap ? pairs : chunk_cap, opens ? open_ui[i] : open_ui[i] - 1,
+                          (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
+        }
+        if (!(flag[i] & 2u)) continue;
         reinterpret_cast<int4 *>(out.uniq_rec[side])[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
         if (chunks > out.heavy_chunks) {
             const int slot = atomicAdd(out.counts + 4, 1);  // zeroed by side_tiles, the launch before this one
@@ -554,56 +566,65 @@ struct RecordArgs {
     const float *w[2], *y[2];
     int32_t *crec[2];
 };
-__global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP)
+__global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP, bool headers)
 {
+    // 32 lanes per chunk: lane f writes float4 f of the record (the header, then the blocks of 8 pairs).  A chunk of n
+    // pairs is read up to its last block of 8: the blocks behind it are never looked at (the pass kernels may copy
+    // them, they use slots below the next multiple of 8 only) and stay unwritten — at V = 400 k, B = 1 M (2.8 pairs per
+    // 32-slot chunk) that is 72 % of the record bytes.
     const int side = blockIdx.y;
     const int n_chunks = counts[2 * side];
     const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *partner = a.partner[side];
     const float *w = a.w[side], *y = a.y[side];
     const int rq = 1 + 3 * capP / 4;                       // float4 per record
-    const int64_t total = (int64_t)n_chunks * rq;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i / rq), f = (int)(i - (int64_t)j * rq);
+    const int lane = threadIdx.x & 31;
+    const int ngrp = (int)((gridDim.x * blockDim.x) >> 5);
+    for (int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5); j < n_chunks; j += ngrp) {
         const int s = chunk_start[j], n = chunk_start[j + 1] - s;
-        int4 v;
-        if (f == 0) {
-            // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
-            // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
-            const int32_t id = chunk_id[j];
-            const int32_t *slot = a.uniq_slot[side];
-            int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (slot[mid] <= j) lo = mid; else hi = mid;
+        const int nq = 1 + 6 * ((n + kRecPad - 1) / kRecPad);
+        int4 *dst = reinterpret_cast<int4 *>(a.crec[side]) + (size_t)j * rq;
+        for (int f = lane; f < nq; f += 32) {
+            int4 v;
+            if (f == 0) {
+                if (!headers) continue;                    // the tiled builder's side_emit has written them
+                // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
+                // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
+                const int32_t id = chunk_id[j];
+                const int32_t *slot = a.uniq_slot[side];
+                int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (slot[mid] <= j) lo = mid; else hi = mid;
+                }
+                const uint32_t rem = (uint32_t)(slot[lo + 1] - 1 - j);
+                // word 2: the id's position among the side's distinct ids (ascending id order)
+                v = make_int4(id, n, lo, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
+            } else {
+                // blocks of kRecPad = 8 pairs, each {partner[8] | w[8] | y[8]}: float4 r of block b holds field r / 2, pairs 8 b + 4 (r % 2) ..
+                const int b = (f - 1) / 6, r = (f - 1) % 6;
+                const int field = r / 2, t0 = b * kRecPad + (r % 2) * 4;
+                int o[4];
+                for (int x = 0; x < 4; ++x) {
+                    const int t = t0 + x;
+                    const int k = s + (t < n ? t : 0);              // padding replays pair 0 with weight 0
+                    o[x] = field == 0 ? partner[k] : field == 1 ? __float_as_int(t < n ? w[k] : 0.f) : __float_as_int(y[k]);
+                }
+                v = make_int4(o[0], o[1], o[2], o[3]);
             }
-            const uint32_t rem = (uint32_t)(slot[lo + 1] - 1 - j);
-            // word 2: the id's position among the side's distinct ids (ascending id order)
-            v = make_int4(id, n, lo, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
-        } else {
-            // blocks of kRecPad = 8 pairs, each {partner[8] | w[8] | y[8]}: float4 r of block b holds field r / 2, pairs 8 b + 4 (r % 2) ..
-            const int b = (f - 1) / 6, r = (f - 1) % 6;
-            const int field = r / 2, t0 = b * kRecPad + (r % 2) * 4;
-            int o[4];
-            for (int x = 0; x < 4; ++x) {
-                const int t = t0 + x;
-                const int k = s + (t < n ? t : 0);              // padding replays pair 0 with weight 0
-                o[x] = field == 0 ? partner[k] : field == 1 ? __float_as_int(t < n ? w[k] : 0.f) : __float_as_int(y[k]);
-            }
-            v = make_int4(o[0], o[1], o[2], o[3]);
+            dst[f] = v;
         }
-        reinterpret_cast<int4 *>(a.crec[side])[i] = v;
     }
 }
 
-static int launch_fill_records(const glove_plan *plan, hipStream_t st)
+static int launch_fill_records(const glove_plan *plan, hipStream_t st, bool headers = true)
 {
     const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
-    const int64_t work = (int64_t)plan->cap_chunks * (1 + 3 * capP / 4);
+    const int64_t nr = most_chunks(plan, true), nc = most_chunks(plan, false);
     const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                           {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
                           {plan->r_crec, plan->c_crec}};
-    hipLaunchKernelGGL(fill_records, dim3(blocks_for(work, kBlock), 2), dim3(kBlock), 0, st,
-                       (const int32_t *)plan->counts, a, capP);
+    hipLaunchKernelGGL(fill_records, dim3(blocks_for(nr > nc ? nr : nc, kBlock / 32), 2), dim3(kBlock), 0, st,
+                       (const int32_t *)plan->counts, a, capP, headers);
     return (int)hipGetLastError();
 }
 
@@ -759,13 +780,14 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     const SideKeys sk = {{pw.row_sorted, pw.col_sorted}};
     const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                         {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
-                        (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy};
+                        (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
+                        {plan->r_crec, plan->c_crec}, 4 + 3 * rec_cap(plan->chunk_cap)};
     const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles};
     hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        pw.tile_rs, pw.tile_sums, ex);
     hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
-    if (plan->r_crec) return launch_fill_records(plan, st);
+    if (plan->r_crec) return launch_fill_records(plan, st, false);
     return (int)hipGetLastError();
 }
 

@@ -752,6 +752,7 @@ __device__ inline void sum_blockpart(const float *blockpart, int nblocks, float 
         const f4 v = bp[b < nblocks ? b : 0];
         acc += (b < nblocks) ? v : f4{0.f, 0.f, 0.f, 0.f};
     }
+    for (int b = threadIdx.x + kMaxBlocks; b < nblocks; b += kBlock) acc += bp[b];     // fused passes of big batches only
     tot[0] = wave_sum(acc.x); tot[1] = wave_sum(acc.y); tot[2] = wave_sum(acc.z); tot[3] = wave_sum(acc.w);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void fold_blockpart_kernel(float *__restric
         for (int i = 0; i < kPartials; ++i) keep[i] = tot[i];
     }
     __syncthreads();                        // everybody has read its share before anything is overwritten
-    for (int i = threadIdx.x; i < kMaxBlocks * kPartials; i += kBlock) blockpart[i] = i < kPartials ? keep[i] : 0.f;
+    for (int i = threadIdx.x; i < kMaxPassBlocks * kPartials; i += kBlock) blockpart[i] = i < kPartials ? keep[i] : 0.f;
 }
 
 // The loss partials of the last row pass as they travel in a packed list's header: {sum e, sum w diff^2, sum |r|^2+|c|^2, sum b^2}
@@ -1489,22 +1490,24 @@ static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_f
 // one per chunk, and an id of up to 4 chunks is usually applied by the pass itself; 1 ... 8 measured alike at V = 400 k,
 // d = 300, B = 1 M, 16 and 32 slower: fewer, longer-running groups), fewer when the side has too few chunks to fill the
 // chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 / 103 / 106), more
-// when the plan has more chunks than kMaxBlocks workgroups of such groups cover (the loss partials are kept per
+// when the plan has more chunks than kMaxPassBlocks workgroups of such groups cover (the loss partials are kept per
 // workgroup).  (Measured with a build that read the number from the environment; the library itself reads no environment.)
 static int fuse_per(const glove_plan *p, int lpr)
 {
-    const int64_t side = p->host_counts[0] >= 0 && p->host_counts[2] >= 0
-                             ? (p->host_counts[0] > p->host_counts[2] ? p->host_counts[0] : p->host_counts[2]) : p->cap_chunks;
+    const int64_t nr = most_chunks(p, true), nc = most_chunks(p, false);
+    const int64_t side = nr > nc ? nr : nc;
     int per = (int)(side / 16384);
     per = per < 1 ? 1 : per > 4 ? 4 : per;
-    const int64_t groups = (int64_t)kMaxBlocks * (kBlock / lpr);
-    const int need = (int)((p->cap_chunks + groups - 1) / groups);
+    const int64_t groups = (int64_t)kMaxPassBlocks * (kBlock / lpr);
+    const int64_t most = p->host_counts[0] >= 0 && p->host_counts[2] >= 0 ? (int64_t)p->cap_chunks : side;
+    const int need = (int)((most + groups - 1) / groups);
     return need > per ? need : per;
 }
 static inline int fusepass_blocks(const glove_plan *p, int lpr, int per, bool row)
 {
-    const int n = p->host_counts[row ? 0 : 2] >= 0 ? p->host_counts[row ? 0 : 2] : p->cap_chunks;
-    return blocks_for(n, per * (kBlock / lpr));
+    const int64_t per_block = (int64_t)per * (kBlock / lpr);
+    const int64_t b = (most_chunks(p, row) + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : b > kMaxPassBlocks ? kMaxPassBlocks : b);
 }
 
 static SideBufs side_bufs(const glove_plan *p, const StepWs &w, const glove_tables *t, bool row)
@@ -1691,14 +1694,16 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
     hipStream_t st = (hipStream_t)stream;
     const bool short_list = (pre_r == kFuseTwin && pre_c == kFuseInPlace && wk.sides == 3) ||
                             (pre_r == kFuseInPlace && wk.sides == 1);        // glove_rowside_step_adagrad_f32
-    if (short_list && w.work && wk.nu_r_host >= 0 && wk.nu_c_host >= 0) {
+    if (short_list && w.work) {
         // sort the ids out first (triage_kernel, a thread per id): the launch below then walks the list of those that
         // still need it.  Only where that list is short — the twin form, whose finished ids need a version flip at most
         // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage), and the in-place row side of the sharded forms,
         // whose finished ids need nothing.  Behind the slot form every row id still needs its
         // copy, nearly all ids go onto the list and its one counter becomes the bottleneck (V = 2 M: 51 us of triage)
         wk.work = w.work;
-        const int nbt = (int)(((int64_t)wk.nu_r_host + wk.nu_c_host + kBlock - 1) / kBlock);
+        // (a plan refilled on the device: a thread per id the arrays can hold, the kernel reads the counts)
+        const int64_t ids = wk.nu_r_host >= 0 && wk.nu_c_host >= 0 ? (int64_t)wk.nu_r_host + wk.nu_c_host : 2 * (int64_t)p->cap_uniq;
+        const int nbt = (int)((ids + kBlock - 1) / kBlock);
         if (nbt > 0) hipLaunchKernelGGL(triage_kernel, dim3(nbt), dim3(kBlock), 0, st, wk, rs, cs, w.work);
     }
 #define CALL(LPR, NV)                                                                                          \
@@ -2036,8 +2041,10 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     if (!p->r_crec || !p->c_crec) return GLOVE_STEP_TWO_LAUNCH;      // the fused forms read the id layout from the chunk records
     if (h->step_form != GLOVE_STEP_AUTO) return h->step_form;
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
-    // are only known on the host for a plan whose build has been synchronised (a resident plan)
-    const int64_t ids = (int64_t)(p->host_counts[1] >= 0 ? p->host_counts[1] : 0) + (p->host_counts[3] >= 0 ? p->host_counts[3] : 0);
+    // are known on the host for a plan whose build has been synchronised (a resident plan)
+    // (a plan refilled on the device every step — a reshuffled epoch — is judged by the most ids its batch can hold)
+    const int64_t most = (int64_t)v_row(t) + t->V < 2 * p->B ? (int64_t)v_row(t) + t->V : 2 * p->B;
+    const int64_t ids = p->host_counts[1] >= 0 && p->host_counts[3] >= 0 ? (int64_t)p->host_counts[1] + p->host_counts[3] : most;
     // (V = 50 k, d = 300, B = 131,072: 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches
     // 106 us, fused 103 - 111; V = 400 k at B = 131,072, 336 MB: 172 against 156; V = 50 k at B = 1 M, 432 MB: 378 against 314)
     if (ids * t->d * 16 < (int64_t)glove_fused_step_bytes()) return GLOVE_STEP_TWO_LAUNCH;

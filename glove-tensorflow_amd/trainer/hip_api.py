@@ -441,7 +441,7 @@ class Plan:
                   "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
-                 cap_uniq: int | None = None, V_row: int = 0):
+                 cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None):
         self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
         self.cap_chunks = int(B if cap_chunks is None else cap_chunks)
         self.cap_uniq = int(min(B, V) if cap_uniq is None else cap_uniq)
@@ -455,8 +455,9 @@ class Plan:
         self.host_counts = [-1] * 8      # unknown until the build has been synchronised
         self.heavy = torch.zeros(self.cap_heavy, **i32)
         # per-chunk records: carried by small (per-step) plans right away, added to big ones when compacted
+        # (`records=True`: a staging plan of a big batch on big tables, refilled every step and stepped in a fused form)
         self.r_crec = self.c_crec = None
-        if 0 < self.B <= RECORDS_AT_BUILD_MAX:
+        if self.B > 0 and (self.B <= RECORDS_AT_BUILD_MAX if records is None else records):
             self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
         self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
@@ -548,6 +549,13 @@ def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, bet
     return h
 
 
+def staging_records(B: int, V_row: int, V: int, d: int) -> bool | None:
+    """Whether a staging plan (refilled on the device every step: a reshuffled epoch) should carry chunk records from its
+    build: yes where the library will take a fused step form for it (glove_step.hip pick_step_form judges such a plan by
+    the most ids its batch can hold), otherwise the Plan's own rule (small batches)."""
+    return True if min(V_row + V, 2 * B) * ((d + 3) // 4 * 4) * 16 >= FUSED_STEP_BYTES else None
+
+
 def _step_struct(tables, plans, hyper):
     """The tables as the Adagrad step may see them: a twinned row table stays twinned between steps.  Marks the tables
     as possibly twinned when one of the plans can take the twin form (the rule of glove_step.hip pick_step_form), so
@@ -557,7 +565,8 @@ def _step_struct(tables, plans, hyper):
     form = hyper.step_form
     for plan in plans:
         hc = plan.host_counts
-        fused = plan.r_crec is not None and hc[1] >= 0 and (hc[1] + hc[3]) * tables.d * 16 >= FUSED_STEP_BYTES
+        ids = hc[1] + hc[3] if hc[1] >= 0 and hc[3] >= 0 else min(tables.V_row + tables.V, 2 * plan.B)
+        fused = plan.r_crec is not None and ids * tables.d * 16 >= FUSED_STEP_BYTES
         if form == STEP_FUSED_TWIN or (form == STEP_AUTO and fused):
             tables._twin_dirty = True
             break
@@ -587,12 +596,12 @@ class GloveHip:
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
                    into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None,
-                   V_row: int = 0) -> Plan:
+                   V_row: int = 0, records: bool | None = None) -> Plan:
         """Builds the dedup index of one batch on the device.  `V_row`: rows of this rank's row-table shard when the
         row ids are shard-local (ids outside it count as id 0, like col ids outside [0, V)).  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
         allocations per step this way.  `ws`: scratch of glove_plan_workspace_bytes(B, V) bytes (default: one
-        shared buffer, fine for builds issued on one stream)."""
+        shared buffer, fine for builds issued on one stream).  `records`: see Plan (default: small batches only)."""
         B = int(row.numel())
         _require(row, torch.int32, B); _require(col, torch.int32, B)
         _require(w, torch.float32, B); _require(y, torch.float32, B)
@@ -603,7 +612,7 @@ class GloveHip:
                 raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
             plan = into
         else:
-            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row)
+            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row, records=records)
         if ws is None:      # builds that run concurrently on different streams each bring their own scratch
             ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),

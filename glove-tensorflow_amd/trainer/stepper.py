@@ -677,7 +677,13 @@ class ReshufflingRunner:
             return
         dev, B, V = tables.device, stream.B, stream.V
         shard_rows = tables.V_row if tables.V_row < tables.V else 0          # row-sharded: the stream carries shard-local row ids
-        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows) for _ in range(self.ahead)]
+        # big batches on big tables (one GPU, Adagrad): the staging plans carry chunk records, the step takes its fused form
+        from trainer.hip_api import staging_records
+        records = staging_records(B, tables.V_row, V, tables.d) if stepper is None and tables.optimizer == "Adagrad" else None
+        if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
+            tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
+        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows, records=records)
+                     for _ in range(self.ahead)]
         self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
                         for _ in range(self.ahead)]
         self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]

@@ -158,7 +158,7 @@ typedef struct glove_plan {
     int32_t *heavy;
     /* Optional per-chunk records (NULL = absent): chunk j of a side owns rec_dwords = 4 + 3*capP dwords
      * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, position of the id among the side's distinct ids, (1 << 31 if it is the first chunk of its id) | chunks of the same id behind it | capP / 8 blocks of 8 pairs, each
-     * partner[8] | w[8] | y[8]}, padding slots carrying weight 0 and a valid partner id.  With them the pass kernel gets a
+     * partner[8] | w[8] | y[8]}, padding slots carrying weight 0 and a valid partner id; only the ceil(pairs / 8) blocks a chunk needs are written.  With them the pass kernel gets a
      * chunk's descriptor AND its pair fields in ONE memory round trip (contiguous 16-B loads) instead of two dependent
      * ones; what a chunk of n pairs needs is the prefix of 4 + 24 ceil(n / 8) dwords, so the bandwidth-bound fused forms
      * read the first block with the header and the rest only for longer chunks.  The layout is private to the library

@@ -134,8 +134,9 @@ def test_plan_build_bit_exact(hip, B, V, cap):
                 np.testing.assert_array_equal(blocks[j, :, 0].reshape(-1)[:n[j]], partner[sl])
                 np.testing.assert_array_equal(blocks[j, :, 1].reshape(-1)[:n[j]].view(np.float32), ww[sl])
                 np.testing.assert_array_equal(blocks[j, :, 2].reshape(-1)[:n[j]].view(np.float32), yy[sl])
-                assert (blocks[j, :, 1].reshape(-1)[n[j]:].view(np.float32) == 0).all()
-                assert ((blocks[j, :, 0] >= 0) & (blocks[j, :, 0] < V)).all()          # padding slots hold valid ids
+                nb_ = (n[j] + 7) // 8               # the blocks a reader of this chunk touches (the others stay unwritten)
+                assert (blocks[j, :nb_, 1].reshape(-1)[n[j]:].view(np.float32) == 0).all()
+                assert ((blocks[j, :nb_, 0] >= 0) & (blocks[j, :nb_, 0] < V)).all()    # their padding slots hold valid ids
     assert (plan.r_crec is not None) == (B <= 4096)
     assert (cpr.r_crec is not None) == (4 * B >= cap * max(nc_r, nc_c))     # only reasonably filled chunks
     # compacted copy describes the same index
@@ -173,6 +174,32 @@ def _assert_plan_equals_oracle(plan, want, B, w, y):
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
     np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
     np.testing.assert_array_equal(plan.c_y.cpu().numpy()[:B], y[want["perm_r"]][want["c_perm"]])
+    if plan.r_crec is None:
+        return
+    # per-chunk records: every header, every pair slot, and the padding of the blocks a reader touches (weight 0, valid id)
+    capP = (plan.chunk_cap + 7) // 8 * 8
+    rd = 4 + 3 * capP
+    wr, yr = w[want["perm_r"]], y[want["perm_r"]]
+    for side, nc, partner, ww, yy in (("r", nc_r, want["r_partner"], wr, yr), ("c", nc_c, want["c_partner"], wr[want["c_perm"]], yr[want["c_perm"]])):
+        ids, starts = np.asarray(want[side + "_chunk_id"]), np.asarray(want[side + "_chunk_start"])
+        rec = getattr(plan, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
+        n = np.diff(starts)
+        first = np.r_[True, ids[1:] != ids[:-1]]
+        run_id = np.cumsum(first) - 1
+        run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
+        np.testing.assert_array_equal(rec[:, 0], ids, err_msg=side + " record id")
+        np.testing.assert_array_equal(rec[:, 1], n, err_msg=side + " record pairs")
+        np.testing.assert_array_equal(rec[:, 2], run_id, err_msg=side + " record id position")
+        np.testing.assert_array_equal(rec[:, 3].view(np.uint32), (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31),
+                                      err_msg=side + " record chunks-behind word")
+        blocks = rec[:, 4:].reshape(nc, capP // 8, 3, 8)
+        slot = np.arange(capP)[None, :]
+        used, padding = slot < n[:, None], (slot >= n[:, None]) & (slot < ((n + 7) // 8 * 8)[:, None])
+        fields = [blocks[:, :, f, :].reshape(nc, capP) for f in range(3)]
+        np.testing.assert_array_equal(fields[0][used], partner, err_msg=side + " record partners")
+        np.testing.assert_array_equal(fields[1][used].view(np.float32), ww, err_msg=side + " record weights")
+        np.testing.assert_array_equal(fields[2][used].view(np.float32), yy, err_msg=side + " record values")
+        assert (fields[1][padding].view(np.float32) == 0).all() and ((fields[0][padding] >= 0) & (fields[0][padding] < plan.V)).all()
 
 
 @pytest.mark.parametrize("B,V,cap", [(1000, 300, 8), (4096, 12000, 16), (9000, 97, 3), (131072, 10000, 16), (70000, 300000, 32),
@@ -183,10 +210,7 @@ def test_consecutive_builds_into_a_poisoned_staging_plan(hip, plan_checker, B, V
     allocation only, leftovers of the previous batch).  Bit-exact against the oracle both times, and the device-side
     range check (every partner / perm / record slot a step kernel may read) finds nothing."""
     from trainer.hip_api import Plan
-    staging = Plan(B, V, cap, "cuda:0")
-    if staging.r_crec is None and B <= 131072:          # records filled by the build as well (the per-step form of big batches)
-        staging.r_crec, staging.c_crec = (torch.zeros(staging.cap_chunks * staging.rec_dwords, dtype=torch.int32, device="cuda:0")
-                                          for _ in range(2))
+    staging = Plan(B, V, cap, "cuda:0", records=True)   # records filled by the build as well (small batches; big batches on big tables)
     ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
     errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     for k in range(2):
@@ -1372,6 +1396,47 @@ def test_adagrad_edge_shapes(hip, B, V, d, cap):
         loss, _, _ = ref.train_step(t, row, col, w, y, hp)
         np.testing.assert_allclose(loss_out[0].item(), loss, rtol=2e-5)
     assert_tables_close(dt, t, 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("workload,B", [("text8_v50k_d300", 65536), ("zipf_v400k_d300", 1048576)])
+def test_fused_step_on_a_device_refilled_plan(hip, plan_checker, workload, B):
+    """A reshuffled epoch on big tables: the staging plan is refilled on the device every step (its counts are never read
+    back: host_counts stay -1) and carries chunk records from the build, of which only the blocks a chunk needs are
+    written (the plan is poisoned with 0xFF before each build).  The library judges such a plan by the most ids its batch
+    can hold and takes the fused form — the twin form on a twinned row table; both equal the two-launch step on a
+    resident plan of the same batch within the fp32 tolerance, and each other bit for bit."""
+    from trainer import synthetic
+    from trainer.hip_api import DeviceTables, Plan, make_hyper, staging_records
+    wl = synthetic.make_workload(workload, seed=3, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    assert staging_records(B, V, V, d) is True
+    cap = 32
+    staging = Plan(B, V, cap, "cuda:0", records=True)
+    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
+    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    lr = 0.05
+    for k in range(2):
+        row, col, w, y = (wl[n][k * B:(k + 1) * B].contiguous() for n in ("row", "col", "w", "y"))
+        a = DeviceTables(V, d, "Adagrad", seed=5)
+        hip.step_adagrad(hip.build_plan(row, col, w, y, V, chunk_cap=cap, compact=True), a,
+                         make_hyper(learning_rate=lr, batch_size=B, step_form=1))
+        _poison(staging, ws)
+        hip.build_plan(row, col, w, y, V, chunk_cap=cap, into=staging, ws=ws)
+        assert staging.host_counts[1] == -1 and staging.r_crec is not None
+        plan_checker(staging, V, errors)
+        got = []
+        for twin in (True, False):
+            c = DeviceTables(V, d, "Adagrad", seed=5)
+            if twin:
+                c.enable_twin()
+            hip.step_adagrad(staging, c, make_hyper(learning_rate=lr, batch_size=B))
+            if twin:
+                assert int(c.R_ver.sum()) > 0, "the twin form was not taken"
+            _assert_tables_agree(a, c, 2e-5, 2e-6, "batch %d twin %s" % (k, twin))
+            got.append(c)
+        _assert_same_bits(got[0], got[1], "twin form vs three launches, batch %d" % k)
+        assert errors.tolist() == [0] * 8, errors.tolist()
+        del a, got, c
 
 
 @pytest.mark.parametrize("workload,B", [("text8_d64", 131072), ("text8_v50k_d300", 131072), ("zipf_v400k_d300", 1048576),
