@@ -486,6 +486,58 @@ def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B,
         assert torch.equal(getattr(a, n), getattr(b, n)), n
 
 
+@pytest.mark.parametrize("streamed", [False, True])
+def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, streamed):
+    """--epoch-shuffle full at a scale where the step is fused (V = 60 k, d = 300, B = 65,536: the staging plans carry chunk
+    records, the row table is twinned, the library judges a device-refilled plan by the most ids its batch can hold): equal,
+    within the fp32 tolerance of summing a heavy id's pairs in another order, to building and stepping batch after batch in
+    two launches, across an epoch boundary; the twin form really ran."""
+    from trainer import synthetic
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper, staging_records
+    from trainer.stepper import HipBackend, ReshufflingRunner
+    V, d, B = 60000, 300, 65536
+    assert staging_records(B, V, V, d) is True
+    wl = synthetic.make_workload("text8_v50k_d300", seed=2, device="cuda:0", work_device="cuda:0")
+    n = 3 * B + 1234
+    g = torch.Generator(device="cpu").manual_seed(1)
+    coo = dict(row=wl["row"][:n].cpu().numpy(), col=(wl["col"][:n].cpu() + torch.randint(0, V - wl["V"], (n,), generator=g).int()).numpy(),
+               w=wl["w"][:n].cpu().numpy(), y=wl["y"][:n].cpu().numpy())
+    backend = HipBackend("cuda:0")
+    hyper = make_hyper(learning_rate=0.05, batch_size=B)
+    results = []
+    for mode in ("runner", "plain"):
+        stream = NonzeroStream(coo, B, V, backend, "cuda:0", seed=11, static_plans=False)
+        tables = DeviceTables(V, d, "Adagrad", seed=4)
+        nb = stream.batches_per_epoch
+        steps = nb + 2                                       # across an epoch boundary
+        if mode == "runner":
+            runner = ReshufflingRunner(hip, stream, tables, hyper, ahead=2, burst=4, streamed=streamed)
+            assert tables.R_ver is not None and runner.ring[0].r_crec is not None
+            done = 0
+            while done < steps:
+                done += runner.run(steps - done)
+            assert getattr(tables, "_twin_dirty", False)      # a step of the twin form was issued
+            loss = runner.read_loss()["loss"]
+            runner.release_graphs()
+        else:
+            loss_out = torch.zeros(4, device="cuda:0")
+            pos = nb
+            for _ in range(steps):
+                if pos >= nb:
+                    stream.reshuffle_in_place()
+                    pos = 0
+                hip.step_adagrad(hip.build_plan(*stream.batch(pos), V, chunk_cap=0), tables, hyper, loss_out)
+                pos += 1
+            loss = float(loss_out[0])
+        results.append((tables, loss))
+    (a, la), (b, lb) = results
+    assert a.global_step == b.global_step == steps
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    for n_ in ("R", "C", "br", "bc"):
+        np.testing.assert_allclose(getattr(a, n_).cpu().numpy(), getattr(b, n_).cpu().numpy(), rtol=5e-5, atol=5e-6, err_msg=n_)
+
+
 def test_cli_with_full_epoch_shuffle(hip, tmp_path):
     from trainer import estimator
     csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
