@@ -623,7 +623,10 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st, bool head
     const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                           {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
                           {plan->r_crec, plan->c_crec}};
-    hipLaunchKernelGGL(fill_records, dim3(blocks_for(nr > nc ? nr : nc, kBlock / 32), 2), dim3(kBlock), 0, st,
+    // a chunk per lane group where the grid allows: two dependent round trips (chunk bounds, then the fields), no loop
+    const int64_t most = nr > nc ? nr : nc, per_block = kBlock / 32;
+    const int64_t nb = (most + per_block - 1) / per_block;
+    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb > 65535 ? 65535 : nb), 2), dim3(kBlock), 0, st,
                        (const int32_t *)plan->counts, a, capP, headers);
     return (int)hipGetLastError();
 }
