@@ -11,10 +11,8 @@ using f4 = float __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
 // Workgroups of a fused (run-merged) pass, whose lane groups take `per` consecutive chunks each instead of striding:
-// the ids of the Zipf head fill consecutive chunks, so a head group's `per` full chunks are a serial chain of per x
-// chunk_cap / 4 partner-row trips — the launch's critical path once `per` is large (V = 400 k, d = 300, B = 1 M, per 27:
-// 407 us per pass; per 23: 290; per 7: 285).  More workgroups keep `per` small for big batches.
-constexpr int kMaxPassBlocks = 8192;                     // (4,096 / 16,384 / 32,768 measured alike at C4 and C5 on resident plans)
+// enough of them that `per` (glove_step.hip fuse_per, where the measurements are) stays at 12 up to 786 k chunks a side.
+constexpr int kMaxPassBlocks = 8192;
 constexpr int kPartials = 4;       // per-block loss partials: sum w diff^2, sum |r|^2+|c|^2, sum b^2, sum e
 
 // ---- diagnostic build only (-DGLOVE_STAMPS): per-wave wall-clock stamps (s_memrealtime, 100 MHz)

@@ -752,7 +752,18 @@ __device__ inline void sum_blockpart(const float *blockpart, int nblocks, float 
         const f4 v = bp[b < nblocks ? b : 0];
         acc += (b < nblocks) ? v : f4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int b = threadIdx.x + kMaxBlocks; b < nblocks; b += kBlock) acc += bp[b];     // fused passes of big batches only
+    // fused passes of big batches only (up to kMaxPassBlocks workgroups): same order, eight loads in flight at a time —
+    // one dependent load per round was 12 us of the C4 apply launch
+    for (int b0 = threadIdx.x + kMaxBlocks; b0 < nblocks; b0 += 8 * kBlock) {
+        f4 v[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int b = b0 + x * kBlock;
+            v[x] = bp[b < nblocks ? b : 0];
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc += (b0 + x * kBlock < nblocks) ? v[x] : f4{0.f, 0.f, 0.f, 0.f};
+    }
     tot[0] = wave_sum(acc.x); tot[1] = wave_sum(acc.y); tot[2] = wave_sum(acc.z); tot[3] = wave_sum(acc.w);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -1486,18 +1497,23 @@ static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
 
 static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_for(p->cap_chunks, kBlock / lpr); }
 
-// FUSE passes: consecutive chunks per lane group.  Up to 4 (a heavy id then leaves one partial row per 4 chunks instead of
-// one per chunk, and an id of up to 4 chunks is usually applied by the pass itself; 1 ... 8 measured alike at V = 400 k,
-// d = 300, B = 1 M, 16 and 32 slower: fewer, longer-running groups), fewer when the side has too few chunks to fill the
-// chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 / 103 / 106), more
-// when the plan has more chunks than kMaxPassBlocks workgroups of such groups cover (the loss partials are kept per
-// workgroup).  (Measured with a build that read the number from the environment; the library itself reads no environment.)
+// FUSE passes: consecutive chunks per lane group.  Up to 12: a heavy id then leaves one partial row per 12 chunks instead
+// of one per chunk, and an id of a few chunks is usually applied by the pass itself (an id whose chunks straddle two
+// groups goes through partial rows and the apply launch) — but the ids of the Zipf head fill consecutive FULL chunks, so
+// a head group's per x chunk_cap pairs are one serial chain of partner-row trips, the launch's critical path once per is
+// large.  One-process A/B of the whole step on resident plans, B = 1 M, chunk_cap 32 (tools/ab_kernels.py, builds with
+// a forced per): V = 400 k, d = 300: per 4 / 8 / 12 / 16 / 20 / 23 / 27 / 32 / 48 = 620 / 613 / 609 / 640 / 699 / 772 /
+// 868 / 979 / 1281 us; V = 2 M, d = 128: 516 / 509 / 520 / 536 / 541 / 572 / - / 565 / 765 (builds differ by +-1.5 % whatever
+// they hold: 12 and the former rule's 12 / 18 are not told apart).  Fewer when the side has too few
+// chunks to fill the chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 /
+// 103 / 106), more only when the plan has more chunks than kMaxPassBlocks workgroups of such groups cover (the loss
+// partials are kept per workgroup).
 static int fuse_per(const glove_plan *p, int lpr)
 {
     const int64_t nr = most_chunks(p, true), nc = most_chunks(p, false);
     const int64_t side = nr > nc ? nr : nc;
-    int per = (int)(side / 16384);
-    per = per < 1 ? 1 : per > 4 ? 4 : per;
+    int per = (int)((side + 16383) / 16384);              // <= 2,048 workgroups up to 196 k chunks a side
+    per = per < 1 ? 1 : per > 12 ? 12 : per;
     const int64_t groups = (int64_t)kMaxPassBlocks * (kBlock / lpr);
     const int64_t most = p->host_counts[0] >= 0 && p->host_counts[2] >= 0 ? (int64_t)p->cap_chunks : side;
     const int need = (int)((most + groups - 1) / groups);
