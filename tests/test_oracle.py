@@ -146,6 +146,10 @@ def test_plan_partitions_the_batch(B, V, cap):
         us = p[side + "_uniq_slot"]
         assert us[0] == 0 and us[-1] == len(cid)
         assert len(np.unique(cid[us[:-1]])) == len(us) - 1
+    # what the library sizes a fused pass by when a plan's counts were never read back (glove_common.h most_chunks):
+    # a side has at most one chunk per distinct id plus one per full chunk_cap pairs
+    assert nc_r <= min(B, V) + B // cap + 1 and nc_c <= min(B, V) + B // cap + 1
+    assert nc_r <= nu_r + B // cap and nc_c <= nu_c + B // cap
     # col side points back to the same pairs
     np.testing.assert_array_equal(p["c_partner"], row[p["perm_r"]][p["c_perm"]])
     # segment sums through the plan == np.add.at

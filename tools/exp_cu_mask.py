@@ -52,8 +52,10 @@ if share:
     main = masked_stream(lambda i: i // 8 < 32 - share)
     sides = [masked_stream(lambda i: i // 8 >= 32 - share) for _ in range(ahead)]
 else:
+    prio = int(sys.argv[5]) if len(sys.argv) > 5 else 0        # -1: the build streams get the higher queue priority
     main = torch.cuda.Stream(device=dev)
-    sides = [torch.cuda.Stream(device=dev) for _ in range(ahead)]
+    sides = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(ahead)]
+    print("stream priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?", "build streams:", prio)
 
 
 def sweep(n_steps):
