@@ -678,8 +678,18 @@ class ReshufflingRunner:
         dev, B, V = tables.device, stream.B, stream.V
         shard_rows = tables.V_row if tables.V_row < tables.V else 0          # row-sharded: the stream carries shard-local row ids
         # big batches on big tables (one GPU, Adagrad): the staging plans carry chunk records, the step takes its fused form
-        from trainer.hip_api import staging_records
+        from trainer.hip_api import FUSED_STEP_BYTES, staging_records
         records = staging_records(B, tables.V_row, V, tables.d) if stepper is None and tables.optimizer == "Adagrad" else None
+        if stepper is None and tables.optimizer == "Adagrad" and getattr(hyper, "step_form", 0) in (2, 3, 4):
+            records = True
+        if records and getattr(hyper, "step_form", 0) not in (2, 3, 4):      # (a forced fused form keeps its records)
+            # the library judges a refilled plan by the MOST ids its batch can hold; whether this stream's batches really
+            # reach the fused regime is looked up once, on the first batch (one sync, here at set-up)
+            probe = hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows)
+            counts = probe.counts.tolist()
+            if (counts[1] + counts[3]) * tables.d * 16 < FUSED_STEP_BYTES:
+                records = None
+            del probe
         if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
         self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows, records=records)

@@ -488,7 +488,7 @@ def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B,
 
 @pytest.mark.parametrize("streamed", [False, True])
 def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, streamed):
-    """--epoch-shuffle full at a scale where the step is fused (V = 60 k, d = 300, B = 65,536: the staging plans carry chunk
+    """--epoch-shuffle full at a scale where the step is fused (V = 60 k, d = 300, B = 131,072: the staging plans carry chunk
     records, the row table is twinned, the library judges a device-refilled plan by the most ids its batch can hold): equal,
     within the fp32 tolerance of summing a heavy id's pairs in another order, to building and stepping batch after batch in
     two launches, across an epoch boundary; the twin form really ran."""
@@ -496,12 +496,13 @@ def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, streamed):
     from trainer.data_utils import NonzeroStream
     from trainer.hip_api import DeviceTables, make_hyper, staging_records
     from trainer.stepper import HipBackend, ReshufflingRunner
-    V, d, B = 60000, 300, 65536
+    V, d, B = 60000, 300, 131072
     assert staging_records(B, V, V, d) is True
     wl = synthetic.make_workload("text8_v50k_d300", seed=2, device="cuda:0", work_device="cuda:0")
     n = 3 * B + 1234
     g = torch.Generator(device="cpu").manual_seed(1)
-    coo = dict(row=wl["row"][:n].cpu().numpy(), col=(wl["col"][:n].cpu() + torch.randint(0, V - wl["V"], (n,), generator=g).int()).numpy(),
+    # (Zipf rows, uniform cols: a batch touches ~75 k ids — the runner looks at its first batch before it goes fused)
+    coo = dict(row=wl["row"][:n].cpu().numpy(), col=torch.randint(0, V, (n,), generator=g).int().numpy(),
                w=wl["w"][:n].cpu().numpy(), y=wl["y"][:n].cpu().numpy())
     backend = HipBackend("cuda:0")
     hyper = make_hyper(learning_rate=0.05, batch_size=B)
