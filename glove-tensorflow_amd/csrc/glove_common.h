@@ -47,9 +47,14 @@ inline hipError_t zero_words(void *p, int n_words, hipStream_t st)
 }
 
 // ---- per-chunk records (glove_plan.r_crec / c_crec) --------------------------------------------------
-// A record is 4 + 3 * capP dwords, capP = rec_cap(chunk_cap): the header, then capP / kRecPad blocks of kRecPad pairs,
+// A record holds 4 + 3 * capP dwords, capP = rec_cap(chunk_cap): the header, then capP / kRecPad blocks of kRecPad pairs,
 // each block {partner[8] | w[8] | y[8]} — so that what a chunk of n pairs needs is the PREFIX of 4 + 24 ceil(n / 8)
 // dwords (a reader that knows n, or finds it in the header after a first 112-byte read, fetches no padding).
+// In memory a record starts on a 128-byte line of its own: header + block 0 + 16 bytes of padding fill line 0, the other
+// blocks follow packed, the stride is rounded up to whole lines (rec_stride_q).  Most chunks of a big batch hold a few pairs:
+// their reader touches ONE line (1.75 on average when records were 400 bytes apart), and their writer stores a WHOLE line
+// (fill_records; partial-line stores made the memory side fetch every line first: 80 us for 2 x 373 k chunks at V = 400 k,
+// B = 1 M).  In LDS the pass kernels keep the packed image: logical float4 f of a record sits at float4 rec_gq(f) in memory.
 // INVARIANT: a trip of the pass kernel reads U <= kRecPad consecutive pair slots of each field starting at a multiple
 // of U below the chunk's pair count, i.e. inside one block; the slots behind the chunk's pairs in the chunk's last
 // block are VALID partner ids with weight 0 (fill_records replays pair 0 there).  A record sized for the
@@ -60,6 +65,9 @@ constexpr int kRecPad = 8;
 __host__ __device__ inline int rec_cap(int chunk_cap) { return (chunk_cap + kRecPad - 1) / kRecPad * kRecPad; }
 // dword of pair q's partner id inside a record (its weight: + kRecPad, its value: + 2 kRecPad)
 __host__ __device__ inline int rec_pair(int q) { return 4 + 3 * kRecPad * (q / kRecPad) + q % kRecPad; }
+// float4 per record in memory (a multiple of 8 = whole 128-byte lines) / where logical float4 f of a record lies
+__host__ __device__ inline int rec_stride_q(int capP) { return (8 + 6 * (capP / kRecPad - 1) + 7) / 8 * 8; }
+__host__ __device__ inline int rec_gq(int f) { return f < 7 ? f : f + 1; }
 
 // ---- cross-lane sums ------------------------------------------------------------------
 // Butterfly all-reduce inside an aligned group of LPR lanes.  Strides 1,2 use quad_perm DPP;

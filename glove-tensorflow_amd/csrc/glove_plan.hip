@@ -294,8 +294,8 @@ struct SideOut {
     const int64_t *tile_re;                               // [2][ntiles] end of the run crossing a tile's right edge (side_tiles)
     int32_t *heavy;                                       // ids with more than heavy_chunks chunks: (side << 30) | position, any order
     int heavy_chunks, cap_heavy;
-    int32_t *crec[2];                                     // per-chunk records (or nullptr): side_emit writes their headers
-    int rec_dwords;
+    int2 *chunk_aux[2];                                   // per chunk (or nullptr): {position of its id among the side's ids, first chunk
+                                                          // of its id << 31 | chunks of the id behind it}: words 2, 3 of its record header
 };
 
 // flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
@@ -535,19 +535,16 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B
     int64_t right = __shfl_down(sfx, 1, 64);               // min over the lanes to my right in this wave
     if (lane == 63) right = INT64_MAX;
     next_open = right < next_open ? right : next_open;
-    int32_t *crec = out.crec[side];
+    int2 *aux = out.chunk_aux[side];
 #pragma unroll
     for (int i = kTilePer - 1; i >= 0; --i) {
         if (!(flag[i] & 1u)) continue;                     // (a position that opens an id opens a chunk)
         const int64_t k = k0 + i;
         const int pairs = (int)(next_open - k), chunks = (pairs + chunk_cap - 1) / chunk_cap;   // from k to the end of its id
-        if (crec) {
-            // the chunk's record header {id, pairs, position of the id among the side's ids, first chunk of its id << 31 |
-            // chunks of the id behind this one}: everything is at hand here (fill_records would bisect uniq_slot for it)
+        if (aux) {
+            // words 2 and 3 of the chunk's record header are at hand here (fill_records would bisect uniq_slot for them)
             const bool opens = (flag[i] & 2u) != 0;
-            reinterpret_cast<int4 *>(crec + (size_t)open_ci[i] * out.rec_dwords)[0] =
-                make_int4(keys[k], pairs < chunk_cap ? pairs : chunk_cap, opens ? open_ui[i] : open_ui[i] - 1,
-                          (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
+            aux[open_ci[i]] = make_int2(opens ? open_ui[i] : open_ui[i] - 1, (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
         }
         if (!(flag[i] & 2u)) continue;
         reinterpret_cast<int4 *>(out.uniq_rec[side])[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
@@ -565,45 +562,72 @@ struct RecordArgs {
     const int32_t *chunk_id[2], *chunk_start[2], *partner[2];
     const float *w[2], *y[2];
     int32_t *crec[2];
+    const int2 *chunk_aux[2];     // side_emit's {id position, chunks-behind word} per chunk, or nullptr: bisect uniq_slot
 };
-__global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP, bool headers)
+__global__ __launch_bounds__(kBlock) void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP)
 {
-    // 32 lanes per chunk: lane f writes float4 f of the record (the header, then the blocks of 8 pairs).  A chunk of n
-    // pairs is read up to its last block of 8: the blocks behind it are never looked at (the pass kernels may copy
-    // them, they use slots below the next multiple of 8 only) and stay unwritten — at V = 400 k, B = 1 M (2.8 pairs per
-    // 32-slot chunk) that is 72 % of the record bytes.
+    // A wave takes 32 consecutive chunks: their bounds, ids and header words arrive in three coalesced loads, then eight
+    // lanes per chunk write line 0 of its record — header | block 0 | 16 B of padding: lane g of the octet stores float4 g,
+    // the wave stores eight whole 128-byte lines per instruction — four chunks per lane, the loads of all four in flight
+    // together.  (One chunk per 32-lane group, two dependent round trips each, ran 82 us for 2 x 373 k chunks: bound by the
+    // turnover of 373 k waves.)  A chunk of n pairs is read up to its last block of 8: the blocks behind it are never
+    // looked at (the pass kernels may copy them, they use slots below the next multiple of 8 only) and stay unwritten;
+    // blocks 1 .. of the few longer chunks follow in a loop of the same eight lanes.
     const int side = blockIdx.y;
     const int n_chunks = counts[2 * side];
     const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *partner = a.partner[side];
     const float *w = a.w[side], *y = a.y[side];
-    const int rq = 1 + 3 * capP / 4;                       // float4 per record
-    const int lane = threadIdx.x & 31;
-    const int ngrp = (int)((gridDim.x * blockDim.x) >> 5);
-    for (int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5); j < n_chunks; j += ngrp) {
-        const int s = chunk_start[j], n = chunk_start[j + 1] - s;
-        const int nq = 1 + 6 * ((n + kRecPad - 1) / kRecPad);
-        int4 *dst = reinterpret_cast<int4 *>(a.crec[side]) + (size_t)j * rq;
-        for (int f = lane; f < nq; f += 32) {
+    const int2 *aux = a.chunk_aux[side];
+    const int sq = rec_stride_q(capP);                     // float4 per record in memory
+    const int lane = threadIdx.x & 63, g = lane & 7, oct = lane >> 3;
+    const int j0 = (int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32);
+    if (j0 >= n_chunks) return;
+    // lanes 0 .. 32: chunk_start[j0 + lane]; lanes 0 .. 31: the chunk's id and header words 2, 3
+    const int jl = j0 + lane < n_chunks ? j0 + lane : n_chunks;       // chunk_start[n_chunks] = B closes the last chunk
+    const int cs = lane <= 32 ? chunk_start[jl] : 0;
+    int32_t cid = 0;
+    int2 ax = make_int2(0, 0);
+    if (lane < 32 && j0 + lane < n_chunks) {
+        cid = chunk_id[j0 + lane];
+        if (aux) {
+            ax = aux[j0 + lane];
+        } else {
+            // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
+            // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
+            const int j = j0 + lane;
+            const int32_t *slot = a.uniq_slot[side];
+            int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (slot[mid] <= j) lo = mid; else hi = mid;
+            }
+            // word 2: the id's position among the side's distinct ids (ascending id order)
+            ax = make_int2(lo, (int)((uint32_t)(slot[lo + 1] - 1 - j) | (slot[lo] == j ? 0x80000000u : 0u)));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 8 + oct, j = j0 + c;
+        const int s = __shfl(cs, c, 64), n = __shfl(cs, c + 1, 64) - s;
+        const int32_t id = __shfl(cid, c, 64);
+        const int x2 = __shfl(ax.x, c, 64), x3 = __shfl(ax.y, c, 64);
+        if (j >= n_chunks) continue;
+        int4 *dst = reinterpret_cast<int4 *>(a.crec[side]) + (size_t)j * sq;
+        const int nq = 1 + 6 * ((n + kRecPad - 1) / kRecPad);   // logical float4 the chunk needs
+        // gq: float4 of the record in memory; 7 is line 0's padding; logical f = gq below 7, gq - 1 above
+        for (int gq = g; gq < (nq > 7 ? nq + 1 : 8); gq += 8) {
+            const int f = gq < 7 ? gq : gq - 1;
             int4 v;
-            if (f == 0) {
-                if (!headers) continue;                    // the tiled builder's side_emit has written them
-                // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
-                // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
-                const int32_t id = chunk_id[j];
-                const int32_t *slot = a.uniq_slot[side];
-                int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (slot[mid] <= j) lo = mid; else hi = mid;
-                }
-                const uint32_t rem = (uint32_t)(slot[lo + 1] - 1 - j);
-                // word 2: the id's position among the side's distinct ids (ascending id order)
-                v = make_int4(id, n, lo, (int)(rem | (slot[lo] == j ? 0x80000000u : 0u)));
+            if (gq == 7) {
+                v = make_int4(0, 0, 0, 0);
+            } else if (f == 0) {
+                v = make_int4(id, n, x2, x3);
             } else {
                 // blocks of kRecPad = 8 pairs, each {partner[8] | w[8] | y[8]}: float4 r of block b holds field r / 2, pairs 8 b + 4 (r % 2) ..
                 const int b = (f - 1) / 6, r = (f - 1) % 6;
                 const int field = r / 2, t0 = b * kRecPad + (r % 2) * 4;
                 int o[4];
+#pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int t = t0 + x;
                     const int k = s + (t < n ? t : 0);              // padding replays pair 0 with weight 0
@@ -611,23 +635,23 @@ __global__ void fill_records(const int32_t *__restrict__ counts, RecordArgs a, i
                 }
                 v = make_int4(o[0], o[1], o[2], o[3]);
             }
-            dst[f] = v;
+            dst[gq] = v;
         }
     }
 }
 
-static int launch_fill_records(const glove_plan *plan, hipStream_t st, bool headers = true)
+static int launch_fill_records(const glove_plan *plan, hipStream_t st, const int2 *aux_r = nullptr, const int2 *aux_c = nullptr)
 {
     const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
     const int64_t nr = most_chunks(plan, true), nc = most_chunks(plan, false);
     const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                           {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
-                          {plan->r_crec, plan->c_crec}};
-    // a chunk per lane group where the grid allows: two dependent round trips (chunk bounds, then the fields), no loop
-    const int64_t most = nr > nc ? nr : nc, per_block = kBlock / 32;
+                          {plan->r_crec, plan->c_crec}, {aux_r, aux_c}};
+    // 32 chunks per wave, four waves per workgroup
+    const int64_t most = nr > nc ? nr : nc, per_block = (kBlock / 64) * 32;
     const int64_t nb = (most + per_block - 1) / per_block;
-    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb > 65535 ? 65535 : nb), 2), dim3(kBlock), 0, st,
-                       (const int32_t *)plan->counts, a, capP, headers);
+    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb), 2), dim3(kBlock), 0, st,
+                       (const int32_t *)plan->counts, a, capP);
     return (int)hipGetLastError();
 }
 
@@ -641,6 +665,7 @@ struct PlanWs {
     int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
     int64_t *tile_re;                // [2][ntiles] end of the run that crosses a tile's right edge
     int2 *tile_sums;                 // [2][ntiles] (ids, chunks) opened inside a tile
+    int2 *chunk_aux[2];              // [B] per side: record header words 2, 3 of every chunk (plans with chunk records)
     int ntiles;                      // tiles of the numbering kernels (kTile positions)
     int sort_e, sort_tiles;          // positions per thread and tiles of the sort passes
     size_t bytes;
@@ -673,6 +698,7 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
     p.tile_re = (int64_t *)take((size_t)2 * p.ntiles * 8);
     p.tile_sums = (int2 *)take((size_t)2 * p.ntiles * 8);
+    for (int i = 0; i < 2; ++i) p.chunk_aux[i] = (int2 *)take(n * 8);
     p.bytes = off;
     return p;
 }
@@ -784,13 +810,13 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                         {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
                         (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
-                        {plan->r_crec, plan->c_crec}, 4 + 3 * rec_cap(plan->chunk_cap)};
+                        {plan->r_crec ? pw.chunk_aux[0] : nullptr, plan->r_crec ? pw.chunk_aux[1] : nullptr}};
     const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles};
     hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        pw.tile_rs, pw.tile_sums, ex);
     hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
-    if (plan->r_crec) return launch_fill_records(plan, st, false);
+    if (plan->r_crec) return launch_fill_records(plan, st, pw.chunk_aux[0], pw.chunk_aux[1]);
     return (int)hipGetLastError();
 }
 

@@ -273,8 +273,8 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
         if (!have) {
         } else if (REC) {
             // the record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
-            const int rq = 1 + 3 * capP / 4;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rq;
+            const int rq = 1 + 3 * capP / 4;                // float4 of the packed record (the LDS image)
+            const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * rec_stride_q(capP);   // line 0: header | block 0 | pad
             uint4 *lrec = reinterpret_cast<uint4 *>(rec);
             if (FUSE != 0 && NV >= 3) {
                 // run-merged passes over wide rows (bound by bytes): header + first block of 8 pairs (112 B, one round
@@ -288,10 +288,10 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
                 if (lg < kHead) lrec[lg] = rp[lg];
                 const int n1 = (int)lrec[0].y;
                 const int nq = 1 + 6 * ((n1 + kRecPad - 1) / kRecPad);
-                for (int f = kHead + lg; f < nq; f += LPR) lrec[f] = rp[f];
+                for (int f = kHead + lg; f < nq; f += LPR) lrec[f] = rp[f + 1];     // blocks 1 ..: behind line 0's padding
             } else {
                 // latency-bound forms: ONE round trip for the whole record
-                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[f];
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[rec_gq(f)];
             }
             const uint4 hdr = lrec[0];          // same wave wrote it: LDS ops of one wave complete in order
             u = (int32_t)hdr.x;

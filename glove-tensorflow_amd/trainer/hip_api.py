@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 6
+GLOVE_ABI_VERSION = 7
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
@@ -470,7 +470,17 @@ class Plan:
 
     @property
     def rec_dwords(self) -> int:
-        return 4 + 3 * ((self.chunk_cap + 7) // 8 * 8)
+        """int32 per chunk record in memory (glove_common.h rec_stride_q): whole 128-byte lines — header + block 0 of 8 pairs
+        + 16 bytes of padding fill the first, the other blocks follow packed."""
+        capP = (self.chunk_cap + 7) // 8 * 8
+        return (8 + 6 * (capP // 8 - 1) + 7) // 8 * 8 * 4
+
+    def records(self, side: str, n_chunks: int) -> torch.Tensor:
+        """The first n_chunks records of a side ('r' / 'c') in their packed form [n_chunks, 4 + 3 capP]: header {id, pairs, position
+        of the id, first-chunk flag | chunks behind}, then capP / 8 blocks of {partner[8] | w[8] | y[8]} (tests and tools)."""
+        capP = (self.chunk_cap + 7) // 8 * 8
+        raw = getattr(self, side + "_crec")[:n_chunks * self.rec_dwords].view(n_chunks, self.rec_dwords)
+        return torch.cat([raw[:, :28], raw[:, 32:32 + 24 * (capP // 8 - 1)]], dim=1)
 
     def struct(self) -> GlovePlan:
         if self._struct is None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 6   /* 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed); 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -156,7 +156,7 @@ typedef struct glove_plan {
      * particular order: (side << 30) | q with side 0 = row, 1 = col.  The apply kernels give each of
      * them a whole workgroup that starts ahead of the per-lane-group work on the light ids. */
     int32_t *heavy;
-    /* Optional per-chunk records (NULL = absent): chunk j of a side owns rec_dwords = 4 + 3*capP dwords
+    /* Optional per-chunk records (NULL = absent): chunk j of a side holds 4 + 3*capP dwords
      * (capP = chunk_cap rounded up to a multiple of 8: a trip reads up to 8 pair slots) laid out {id, pairs, position of the id among the side's distinct ids, (1 << 31 if it is the first chunk of its id) | chunks of the same id behind it | capP / 8 blocks of 8 pairs, each
      * partner[8] | w[8] | y[8]}, padding slots carrying weight 0 and a valid partner id; only the ceil(pairs / 8) blocks a chunk needs are written.  With them the pass kernel gets a
      * chunk's descriptor AND its pair fields in ONE memory round trip (contiguous 16-B loads) instead of two dependent
@@ -164,7 +164,9 @@ typedef struct glove_plan {
      * read the first block with the header and the rest only for longer chunks.  The layout is private to the library
      * (glove_plan_build / glove_plan_fill_records write it, the step kernels read it).
      * Filled by glove_plan_build when non-NULL, or later by glove_plan_fill_records for an exact-size
-     * (compacted) plan.  Capacity: cap_chunks * rec_dwords int32 each. */
+     * (compacted) plan.  In memory a record starts on a 128-byte line: header, block 0 and 16 bytes of padding fill the
+     * first line, the other blocks follow packed; capacity: cap_chunks records of
+     * rec_dwords = 32 * ceil((8 + 6 * (capP / 8 - 1)) / 8) int32 each (128 for chunk_cap 32). */
     int32_t *r_crec;
     int32_t *c_crec;
 } glove_plan;

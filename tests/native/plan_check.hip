@@ -41,7 +41,7 @@ __global__ void check_sides(glove_plan p, int32_t V, int32_t Vr, int32_t *errors
     if (nch < 0 || nch > p.cap_chunks || nu < 0 || nu > p.cap_uniq) return;
     const int32_t *chunk_id = side ? p.c_chunk_id : p.r_chunk_id, *chunk_start = side ? p.c_chunk_start : p.r_chunk_start;
     const int32_t *uniq_rec = side ? p.c_uniq_rec : p.r_uniq_rec, *crec = side ? p.c_crec : p.r_crec;
-    const int capP = (p.chunk_cap + 7) / 8 * 8, rd = 4 + 3 * capP;
+    const int capP = (p.chunk_cap + 7) / 8 * 8, rd = 4 * ((8 + 6 * (capP / 8 - 1) + 7) / 8 * 8);   // whole 128-byte lines per record
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nch; j += gridDim.x * blockDim.x) {
         const int s = chunk_start[j], e = chunk_start[j + 1];
         if ((uint32_t)chunk_id[j] >= (uint32_t)own_V || s < 0 || e <= s || e - s > p.chunk_cap || e > p.B) flag(errors, 6);
@@ -52,7 +52,7 @@ __global__ void check_sides(glove_plan p, int32_t V, int32_t Vr, int32_t *errors
             const int blocks = (r[1] + 7) / 8;                          // what a reader of this chunk may touch
             for (int b = 0; b < blocks && !bad; ++b)
                 for (int t = 0; t < 8; ++t)
-                    if ((uint32_t)r[4 + 24 * b + t] >= (uint32_t)partner_V) bad = true;
+                    if ((uint32_t)r[(b == 0 ? 4 : 32 + 24 * (b - 1)) + t] >= (uint32_t)partner_V) bad = true;   // block 0 shares line 0 with the header
             if (bad) flag(errors, 7);
         }
     }

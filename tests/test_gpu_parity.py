@@ -114,7 +114,7 @@ def test_plan_build_bit_exact(hip, B, V, cap):
             ("c", nc_c, want["c_chunk_id"], want["c_chunk_start"], want["c_partner"],
              w[want["perm_r"]][want["c_perm"]], y[want["perm_r"]][want["c_perm"]])):
         for p_ in [q_ for q_ in (plan, cpr) if q_.r_crec is not None]:
-            rec = getattr(p_, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
+            rec = p_.records(side, nc).cpu().numpy()
             n = np.diff(starts)
             ids = np.asarray(ids)
             np.testing.assert_array_equal(rec[:, 0], ids)
@@ -182,7 +182,7 @@ def _assert_plan_equals_oracle(plan, want, B, w, y):
     wr, yr = w[want["perm_r"]], y[want["perm_r"]]
     for side, nc, partner, ww, yy in (("r", nc_r, want["r_partner"], wr, yr), ("c", nc_c, want["c_partner"], wr[want["c_perm"]], yr[want["c_perm"]])):
         ids, starts = np.asarray(want[side + "_chunk_id"]), np.asarray(want[side + "_chunk_start"])
-        rec = getattr(plan, side + "_crec").cpu().numpy()[:nc * rd].reshape(nc, rd)
+        rec = plan.records(side, nc).cpu().numpy()
         n = np.diff(starts)
         first = np.r_[True, ids[1:] != ids[:-1]]
         run_id = np.cumsum(first) - 1

@@ -39,7 +39,9 @@ timeit("real partners")
 for M in (65536, 8192, 1024):
     for p in plans:
         capP = (p.chunk_cap + 7) // 8 * 8
-        rd = 4 + 3 * capP
+        rd = p.rec_dwords                                     # in memory: line 0 = header | block 0 | pad, then the other blocks
         for rec, n in ((p.r_crec, p.host_counts[0]), (p.c_crec, p.host_counts[2])):
-            rec[:n * rd].view(n, rd)[:, 4:].reshape(n, capP // 8, 3, 8)[:, :, 0] %= M       # the partner ids of every block
+            raw = rec[:n * rd].view(n, rd)
+            raw[:, 4:12] %= M                                   # the partner ids of block 0
+            raw[:, 32:32 + 24 * (capP // 8 - 1)].reshape(n, capP // 8 - 1, 3, 8)[:, :, 0] %= M     # ... and of the other blocks
     timeit("partners folded into [0, %d)" % M)
