@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
                 // round trip for the long chunks only) — the padding up to the cap, 3/4 of a record on average, is
                 // never read.  Measured in one process against whole-record reads: V = 400 k, d = 300, B = 1 M
                 // 574 vs 579 us per step; V = 2 M, d = 128 495.6 vs 492.6 (512-B rows: bound by requests in flight,
-                // not by bytes — hence NV >= 3); V = 400 k at B = 131,072 139.0 vs 139.6
+                // not by bytes — hence NV >= 3; again with records on lines of their own: 532.6 vs 527.2); V = 400 k at B = 131,072 139.0 vs 139.6
                 constexpr int kHead = 1 + 6;
                 static_assert(LPR >= kHead, "one load per lane covers the header and the first block");
                 if (lg < kHead) lrec[lg] = rp[lg];
