@@ -26,56 +26,55 @@ __device__ inline int wave_sum_int(int v)
 }
 
 // ---- stable LSD radix sort of (id, position), B > kSmallPlanMax ------------------------------------------------
-// Both sides need their pairs in (id, earlier order) order: the row side sorts the batch by row id, the col side sorts
-// the ROW-SORTED pairs by col id.  Keys are ids below V, i.e. ceil(log2 V) bits: P = ceil(bits / 8) passes over digits of
-// db = ceil(bits / P) bits (V = 10 k: two passes of 7 bits; V = 2 M: three of 7), least significant digit first, every pass
-// stable.  A pass is two launches over tiles of kSortThreads x E consecutive positions, one workgroup each:
-//   radix_hist     count[digit][tile] = keys of the tile with that digit (every entry written: nothing relies on zeroed memory)
+// Both sides need the batch's pairs in (id, arrival order) order: the row side sorted by row id, the col side by col id.
+// The two sorts are independent, so they share their launches: grid.y = 2 picks the side, every launch has twice the
+// workgroups instead of the build having twice the launches (these kernels are short latency chains: V = 400 k, B = 1 M:
+// one workgroup per SIMD row either way).  Keys are ids below V, i.e. ceil(log2 V) bits: P = ceil(bits / 8) passes over
+// digits of db = ceil(bits / P) bits (V = 10 k: two passes of 7 bits; V = 2 M: three of 7), least significant digit first,
+// every pass stable.  A pass is two launches over tiles of kSortThreads x E consecutive positions, one workgroup each:
+//   radix_hist     count[side][digit][tile] = keys of the tile with that digit (every entry written: nothing relies on
+//                  zeroed memory)
 //   radix_scatter  position of a key = keys of smaller digits anywhere + keys of its digit in earlier tiles (both summed
 //                  from the count table by the workgroup itself: thread d reads row d, 128 tiles per round trip) + keys of
 //                  its digit earlier in its own tile (its stable local rank)
 // Local ranks come from wave ballots: a wave takes 64 consecutive positions per round, the lanes holding the same digit
 // find each other with db ballots, the group's first lane fetches-and-adds the group's size to the wave's running count of
 // that digit (LDS atomic with return: rounds and peers are ordered by construction) and hands the old value round.
-// The LAST pass of a sort writes the plan's arrays itself (no gather launches): the row side's pass pulls col / w / y
-// through the permutation and maps col ids outside [0, V) to 0; the col side's writes c_perm, its inverse r_to_c, the
-// partner row ids and w / y in col order.  The first pass of the row side maps row ids outside the table to 0 on the
-// fly — id 0 is what the reference's vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) —
-// so that no later kernel can index outside the tables whatever the caller hands over; counts[5] reports how many.
+// The LAST pass writes the side's plan arrays itself (no gather launches): the sorted ids, the partner id / w / y of every
+// pair pulled through the permutation (partner ids outside their table mapped to 0), and where the pair went — the row
+// side its row-sorted position by arrival index (rpos), the col side the arrival index by col-sorted position (c_orig);
+// side_tiles joins the two into c_perm / r_to_c.  The first pass maps ids outside their table to 0 on the fly — id 0 is
+// what the reference's vocabulary lookup gives an unknown token (reference src/models/estimator.py:26-28) — so that no
+// later kernel can index outside the tables whatever the caller hands over; counts[5] reports how many.
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kMaxDigits = 256;
 constexpr int kWalk = 16;                                 // 16-byte loads of a count-table row in flight per thread (= 128 tiles)
 
-struct SortIn {
-    const int32_t *keys;        // [n] keys of this pass, in the order the previous pass left them
-    const int32_t *vals;        // [n] original positions travelling with them; nullptr = the position itself (first pass)
-    int64_t n;
-    int32_t clean_below;        // > 0: first pass over raw ids: anything outside [0, clean_below) counts as id 0
-    int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
-    int ntiles;
-    uint16_t *count;            // [1 << db][tile_stride]: row d = every tile's count of digit d (a tile holds < 65536 keys);
-    int tile_stride;            // ntiles rounded up to a multiple of 8 (16-byte rows); the padding is never written or used
-    int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (row ids: radix_hist of the first pass;
-                                // col ids: the row side's last radix_scatter).  Every entry is written by every build —
-                                // no counter to zero, no atomics; side_tiles adds them up into plan counts[5]
+struct SortSide {
+    const int32_t *keys;        // [n] keys of this pass, in the order the previous pass left them (first pass: the raw ids)
+    const int32_t *vals;        // [n] arrival indices travelling with them; nullptr = the position itself (first pass)
+    int32_t clean_below;        // first pass: anything outside [0, clean_below) counts as id 0 (0: keys are clean)
+    int32_t *out_keys, *out_vals;   // not the last pass: the pair at its new position
+    // last pass: the side's plan arrays
+    int32_t *sorted_keys;       // [n] the sorted ids (the tile kernels below read them)
+    const int32_t *other;       // the other side's raw ids by arrival index
+    int32_t other_below;        // partner ids outside [0, other_below) count as id 0
+    int32_t *partner;           // [n] partner id of the pair at each sorted position
+    float *w_out, *y_out;       // [n]
+    int32_t *where;             // row side: rpos[arrival index] = sorted position; col side: c_orig[sorted position] = arrival index
 };
 
-struct SortOut {
-    int32_t *keys, *vals;       // not the last pass: the pair at its new position
-    // last pass: the sorted keys (the tile kernels below read them) and this side's plan arrays
-    int32_t *sorted_keys;
-    // row side: partner = col[p] (cleaned against V), w, y pulled through the permutation
-    const int32_t *col;
-    const float *w, *y;
-    int32_t V;
-    int32_t *r_partner;
-    float *r_w, *r_y;
-    // col side: p is a row-sorted position
-    const int32_t *row_sorted;
-    const float *in_w, *in_y;   // r_w, r_y
-    int32_t *c_perm, *c_partner, *r_to_c;
-    float *c_w, *c_y;
+struct SortPass {
+    SortSide s[2];              // 0 row side, 1 col side (blockIdx.y)
+    const float *w, *y;         // the batch's weights and values by arrival index
+    int64_t n;
+    int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
+    int ntiles;
+    uint16_t *count;            // [2][kMaxDigits][tile_stride]: row d of a side = every tile's count of digit d (a tile holds < 65536 keys)
+    int tile_stride;            // ntiles rounded up to a multiple of 8 (16-byte rows); the padding is never written or used
+    int32_t *mapped;            // [2][ntiles]: ids this tile's workgroup mapped to 0 (first pass).  Every entry is written by
+                                // every build — no counter to zero, no atomics; side_tiles adds them up into plan counts[5]
 };
 
 // *out = sum of v over the workgroup (kSortThreads threads; called by all of them)
@@ -105,33 +104,35 @@ __device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
 }
 
 template <int E>
-__device__ inline void sort_load_keys(const SortIn &in, int64_t base, int32_t (&key)[E], int &mapped)
+__device__ inline void sort_load_keys(const SortSide &sd, int64_t n, int64_t base, int32_t (&key)[E], int &mapped)
 {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t i = base + j * 64 + lane;
         int32_t k = 0;
-        if (i < in.n) {
-            k = in.keys[i];
-            if (in.clean_below > 0 && (uint32_t)k >= (uint32_t)in.clean_below) { k = 0; ++mapped; }
+        if (i < n) {
+            k = sd.keys[i];
+            if (sd.clean_below > 0 && (uint32_t)k >= (uint32_t)sd.clean_below) { k = 0; ++mapped; }
         }
         key[j] = k;
     }
 }
 
 template <int E>
-__global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
+__global__ __launch_bounds__(kSortThreads) void radix_hist(SortPass in)
 {
     static_assert(kSortThreads == kMaxDigits, "one thread per digit zeroes and stores the histogram");
     __shared__ int hist[kMaxDigits];
+    const int side = blockIdx.y;
+    const SortSide &sd = in.s[side];
     const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
     int32_t key[E];
     int mapped = 0;
-    sort_load_keys<E>(in, base, key, mapped);
+    sort_load_keys<E>(sd, in.n, base, key, mapped);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const bool valid = base + j * 64 + lane < in.n;
@@ -140,32 +141,34 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortIn in)
         if (valid && lane == __ffsll((long long)peers) - 1) atomicAdd(&hist[digit], __popcll(peers));
     }
     __syncthreads();
-    if ((int)threadIdx.x < nd) in.count[(size_t)threadIdx.x * in.tile_stride + blockIdx.x] = (uint16_t)hist[threadIdx.x];
-    // ids the cleaning mapped to 0 are reported once, by the pass that first sees the raw ids
-    if (in.clean_below > 0) block_store_sum(mapped, in.mapped + blockIdx.x);
+    uint16_t *count = in.count + (size_t)side * kMaxDigits * in.tile_stride;
+    if ((int)threadIdx.x < nd) count[(size_t)threadIdx.x * in.tile_stride + blockIdx.x] = (uint16_t)hist[threadIdx.x];
+    // ids the cleaning mapped to 0 are reported once, by the pass that sees the raw ids
+    if (sd.clean_below > 0) block_store_sum(mapped, in.mapped + (size_t)side * in.ntiles + blockIdx.x);
 }
 
-template <int E, int LAST /* 0 no, 1 row side, 2 col side */>
-__global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut out)
+template <int E, bool LAST>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter(SortPass in)
 {
     __shared__ int wcnt[kSortWaves][kMaxDigits];          // a wave's running digit counts; then every wave's bases
     __shared__ int scan_red[kSortWaves];
+    const int side = blockIdx.y;
+    const SortSide &sd = in.s[side];
     const int nd = 1 << in.db, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // The kernel is a chain of short memory round trips on a few hundred workgroups: everything that does not depend on
     // the keys is requested up front, in the order it is needed (vector loads return in order), and consumed later.
     const int64_t base = ((int64_t)blockIdx.x * kSortWaves + wave) * (64 * E);
     int32_t key[E], rank[E], val[E];
     int mapped = 0;
-    sort_load_keys<E>(in, base, key, mapped);
-    mapped = 0;                                           // (row ids mapped to 0 are counted by radix_hist)
+    sort_load_keys<E>(sd, in.n, base, key, mapped);       // (ids mapped to 0 are counted by radix_hist)
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t i = base + j * 64 + lane;
-        val[j] = in.vals ? (i < in.n ? in.vals[i] : 0) : (int32_t)i;
+        val[j] = sd.vals ? (i < in.n ? sd.vals[i] : 0) : (int32_t)i;
     }
-    // row d of the count table (thread d; 16-bit counts, one row = the tiles' counts of digit d): the first kWalk x 8 tiles
+    // row d of the side's count table (thread d; 16-bit counts, one row = the tiles' counts of digit d): the first kWalk x 8 tiles
     const int d_mine = (int)threadIdx.x < nd ? (int)threadIdx.x : 0;
-    const uint4 *rowp = reinterpret_cast<const uint4 *>(in.count + (size_t)d_mine * in.tile_stride);
+    const uint4 *rowp = reinterpret_cast<const uint4 *>(in.count + ((size_t)side * kMaxDigits + d_mine) * in.tile_stride);
     const int nq = in.tile_stride / 8;                    // uint4 per row
     uint4 cw[kWalk];
 #pragma unroll
@@ -173,14 +176,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
     // what the last pass pulls through the permutation (depends on the values only)
     int32_t g_id[E];
     float g_w[E], g_y[E];
-    if (LAST != 0) {
+    if (LAST) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const bool valid = base + j * 64 + lane < in.n;
             const int32_t p = valid ? val[j] : 0;
-            g_id[j] = LAST == 1 ? out.col[p] : out.row_sorted[p];
-            g_w[j] = LAST == 1 ? out.w[p] : out.in_w[p];
-            g_y[j] = LAST == 1 ? out.y[p] : out.in_y[p];
+            g_id[j] = sd.other[p];
+            g_w[j] = in.w[p];
+            g_y[j] = in.y[p];
         }
     }
     // ---- stable rank of every key among the keys of its digit in this wave's range (a wave zeroes and uses its own
@@ -248,26 +251,19 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortIn in, SortOut
         const int digit = (key[j] >> in.shift) & (nd - 1);
         const int dest = wcnt[wave][digit] + rank[j];
         const int32_t p = val[j];
-        if (LAST == 0) {
-            out.keys[dest] = key[j];
-            out.vals[dest] = p;
-        } else if (LAST == 1) {
-            out.sorted_keys[dest] = key[j];
-            int32_t c = g_id[j];
-            if ((uint32_t)c >= (uint32_t)out.V) { c = 0; ++mapped; }
-            out.r_partner[dest] = c;
-            out.r_w[dest] = g_w[j];
-            out.r_y[dest] = g_y[j];
+        if (!LAST) {
+            sd.out_keys[dest] = key[j];
+            sd.out_vals[dest] = p;
         } else {
-            out.sorted_keys[dest] = key[j];
-            out.c_perm[dest] = p;
-            out.r_to_c[p] = dest;
-            out.c_partner[dest] = g_id[j];
-            out.c_w[dest] = g_w[j];
-            out.c_y[dest] = g_y[j];
+            sd.sorted_keys[dest] = key[j];
+            int32_t o = g_id[j];
+            if ((uint32_t)o >= (uint32_t)sd.other_below) o = 0;     // (counted by the other side's first radix_hist)
+            sd.partner[dest] = o;
+            sd.w_out[dest] = g_w[j];
+            sd.y_out[dest] = g_y[j];
+            if (side == 0) sd.where[p] = dest; else sd.where[dest] = p;
         }
     }
-    if (LAST == 1) block_store_sum(mapped, in.mapped + in.ntiles + blockIdx.x);     // col ids mapped to 0
 }
 
 // ---- chunk / id numbering of BOTH sides in two launches --------------------------------------------------
@@ -405,6 +401,10 @@ struct TileExtra {
     int32_t *counts;            // plan counts
     const int32_t *mapped;      // per sort tile: ids mapped to 0 (row ids, then col ids)
     int n_mapped;
+    // the join of the two sorts (col-side tiles): c_perm[q] = rpos[c_orig[q]], r_to_c its inverse
+    const int32_t *c_orig;      // [B] arrival index of the pair at col-sorted position q
+    const int32_t *rpos;        // [B] row-sorted position of the pair that arrived i-th
+    int32_t *c_perm, *r_to_c;
 };
 
 __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
@@ -416,6 +416,22 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
     const int side = blockIdx.y, t = blockIdx.x;
     const int32_t *keys = sk.keys[side];
     const int64_t begin = (int64_t)t * kTile;
+    if (side == 1) {
+        // the two sorts ran side by side: what links them is where the row side put each pair (two coalesced accesses, a
+        // gather and a scatter per position, under the wave searches below)
+        const int64_t q0 = begin + (int64_t)threadIdx.x * kTilePer;
+        int32_t o[kTilePer], rp[kTilePer];
+#pragma unroll
+        for (int i = 0; i < kTilePer; ++i) o[i] = q0 + i < B ? ex.c_orig[q0 + i] : 0;
+#pragma unroll
+        for (int i = 0; i < kTilePer; ++i) rp[i] = ex.rpos[o[i]];
+#pragma unroll
+        for (int i = 0; i < kTilePer; ++i) {
+            if (q0 + i >= B) continue;
+            ex.c_perm[q0 + i] = rp[i];
+            ex.r_to_c[rp[i]] = (int32_t)(q0 + i);
+        }
+    }
     if (threadIdx.x < 64) {                                // wave 0 searches together
         const int64_t r = begin > 0 ? run_start_of(keys, begin) : 0;
         if (threadIdx.x == 0) lds_rs[kTileThreads / 64] = r;
@@ -656,10 +672,11 @@ static int launch_fill_records(const glove_plan *plan, hipStream_t st, const int
 }
 
 struct PlanWs {
-    int32_t *keys[2], *vals[2];      // ping-pong buffers of the sort passes
+    int32_t *keys[2][2], *vals[2][2];   // [side][ping-pong] buffers of the sort passes
     int32_t *row_sorted;             // row ids in row-side order
     int32_t *col_sorted;             // col ids in col-side order
-    uint16_t *count;                 // [digits][tile_stride] of the pass in flight
+    int32_t *rpos, *c_orig;          // [B] row-sorted position by arrival index / arrival index by col-sorted position
+    uint16_t *count;                 // [2][digits][tile_stride] of the pass in flight
     int tile_stride;
     int32_t *mapped;                 // [2][sort tiles] ids mapped to 0 per tile (row ids, col ids)
     int64_t *tile_rs;                // [2][ntiles] start of the run that crosses a tile's left edge
@@ -682,17 +699,20 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     char *base = (char *)ws;
     auto take = [&](size_t bytes) { void *q = base + off; off += align_up(bytes, 256); return q; };
     const size_t n = (size_t)(B > 0 ? B : 1);
-    for (int i = 0; i < 2; ++i) {
-        p.keys[i] = (int32_t *)take(n * 4);
-        p.vals[i] = (int32_t *)take(n * 4);
-    }
+    for (int sd = 0; sd < 2; ++sd)
+        for (int i = 0; i < 2; ++i) {
+            p.keys[sd][i] = (int32_t *)take(n * 4);
+            p.vals[sd][i] = (int32_t *)take(n * 4);
+        }
     p.row_sorted = (int32_t *)take(n * 4);
     p.col_sorted = (int32_t *)take(n * 4);
+    p.rpos = (int32_t *)take(n * 4);
+    p.c_orig = (int32_t *)take(n * 4);
     p.sort_e = sort_e_for(B);
     const size_t per_tile = (size_t)kSortThreads * p.sort_e;
     p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
     p.tile_stride = (p.sort_tiles + 7) / 8 * 8;
-    p.count = (uint16_t *)take((size_t)p.tile_stride * kMaxDigits * 2);
+    p.count = (uint16_t *)take((size_t)2 * p.tile_stride * kMaxDigits * 2);
     p.mapped = (int32_t *)take((size_t)2 * p.sort_tiles * 4);
     p.ntiles = (int)((n + kTile - 1) / kTile);
     p.tile_rs = (int64_t *)take((size_t)2 * p.ntiles * 8);
@@ -710,37 +730,33 @@ static int ceil_log2(int32_t v)
     return b;
 }
 
-// One stable sort by id: P passes of (radix_hist, radix_scatter).  first_keys: the ids as they arrive (row side: raw row
-// ids, cleaned against clean_below; col side: r_partner, already clean).  `last` carries the destination arrays of the last
-// pass; side = 1 row, 2 col.
+// Both stable sorts by id, P passes of (radix_hist, radix_scatter) with grid.y = side.  `fin` carries, per side, the raw ids
+// (first pass) and the destination arrays of the last pass.
 template <int E>
-static void launch_sort(const int32_t *first_keys, int32_t clean_below, int64_t B, int bits, const PlanWs &pw, SortOut last,
-                        int side, hipStream_t st)
+static void launch_sorts(SortPass fin, int64_t B, int bits, const PlanWs &pw, hipStream_t st)
 {
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P;
     for (int p = 0; p < P; ++p) {
-        SortIn in;
-        in.keys = p == 0 ? first_keys : pw.keys[(p - 1) & 1];
-        in.vals = p == 0 ? nullptr : pw.vals[(p - 1) & 1];
+        SortPass in = fin;
+        for (int sd = 0; sd < 2; ++sd) {
+            if (p > 0) {
+                in.s[sd].keys = pw.keys[sd][(p - 1) & 1];
+                in.s[sd].vals = pw.vals[sd][(p - 1) & 1];
+                in.s[sd].clean_below = 0;
+            }
+            in.s[sd].out_keys = pw.keys[sd][p & 1];
+            in.s[sd].out_vals = pw.vals[sd][p & 1];
+        }
         in.n = B;
-        in.clean_below = p == 0 ? clean_below : 0;
         in.shift = p * db;
         in.db = db;
         in.ntiles = pw.sort_tiles;
         in.count = pw.count;
         in.tile_stride = pw.tile_stride;
         in.mapped = pw.mapped;
-        hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in);
-        if (p < P - 1) {
-            SortOut out = last;
-            out.keys = pw.keys[p & 1];
-            out.vals = pw.vals[p & 1];
-            hipLaunchKernelGGL((radix_scatter<E, 0>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, out);
-        } else if (side == 1) {
-            hipLaunchKernelGGL((radix_scatter<E, 1>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, last);
-        } else {
-            hipLaunchKernelGGL((radix_scatter<E, 2>), dim3(pw.sort_tiles), dim3(kSortThreads), 0, st, in, last);
-        }
+        hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
+        if (p < P - 1) hipLaunchKernelGGL((radix_scatter<E, false>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
+        else hipLaunchKernelGGL((radix_scatter<E, true>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
     }
 }
 
@@ -788,22 +804,19 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     const int bits = ceil_log2(V);
     const int32_t Vr = plan->V_row > 0 ? plan->V_row : V;
 
-    // ---- row side: stable sort by (row id, position); its last pass fills r_partner / r_w / r_y
-    SortOut ro = {};
-    ro.sorted_keys = pw.row_sorted;
-    ro.col = col; ro.w = w; ro.y = y; ro.V = V;
-    ro.r_partner = plan->r_partner; ro.r_w = plan->r_w; ro.r_y = plan->r_y;
-    // ---- col side: stable sort of the row-sorted pairs by col id; its last pass fills c_perm / r_to_c / c_partner / c_w / c_y
-    SortOut co = {};
-    co.sorted_keys = pw.col_sorted;
-    co.row_sorted = pw.row_sorted; co.in_w = plan->r_w; co.in_y = plan->r_y;
-    co.c_perm = plan->c_perm; co.c_partner = plan->c_partner; co.r_to_c = plan->r_to_c;
-    co.c_w = plan->c_w; co.c_y = plan->c_y;
-#define SORTS(E)                                                                                              \
-    launch_sort<E>(row, Vr, B, bits, pw, ro, 1, st);                                                          \
-    launch_sort<E>(plan->r_partner, 0, B, bits, pw, co, 2, st)
-    if (pw.sort_e == 4) { SORTS(4); } else if (pw.sort_e == 8) { SORTS(8); } else { SORTS(16); }
-#undef SORTS
+    // ---- both sides: stable sort of the batch by (id, arrival index); the last pass fills the side's pair arrays
+    SortPass fin = {};
+    fin.w = w; fin.y = y;
+    SortSide &rs = fin.s[0], &cs = fin.s[1];
+    rs.keys = row; rs.vals = nullptr; rs.clean_below = Vr;
+    rs.sorted_keys = pw.row_sorted; rs.other = col; rs.other_below = V;
+    rs.partner = plan->r_partner; rs.w_out = plan->r_w; rs.y_out = plan->r_y; rs.where = pw.rpos;
+    cs.keys = col; cs.vals = nullptr; cs.clean_below = V;
+    cs.sorted_keys = pw.col_sorted; cs.other = row; cs.other_below = Vr;
+    cs.partner = plan->c_partner; cs.w_out = plan->c_w; cs.y_out = plan->c_y; cs.where = pw.c_orig;
+    if (pw.sort_e == 4) launch_sorts<4>(fin, B, bits, pw, st);
+    else if (pw.sort_e == 8) launch_sorts<8>(fin, B, bits, pw, st);
+    else launch_sorts<16>(fin, B, bits, pw, st);
 
     // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
     const SideKeys sk = {{pw.row_sorted, pw.col_sorted}};
@@ -811,7 +824,8 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                         {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
                         (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
                         {plan->r_crec ? pw.chunk_aux[0] : nullptr, plan->r_crec ? pw.chunk_aux[1] : nullptr}};
-    const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles};
+    const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles,
+                          (const int32_t *)pw.c_orig, (const int32_t *)pw.rpos, plan->c_perm, plan->r_to_c};
     hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
                        pw.tile_rs, pw.tile_sums, ex);
     hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
     uint32_t *kbuf = reinterpret_cast<uint32_t *>(smem);                 // [np] sorted ids of the sort in flight
     int32_t *vbuf = reinterpret_cast<int32_t *>(kbuf + np);              // [np] their positions before the sort
     int32_t *srow = vbuf + np;                                           // [np] row ids, row-sorted
-    int32_t *scol = srow + np;                                           // [np] col ids, row-sorted
-    float *sw = reinterpret_cast<float *>(scol + np);                    // [np] w, row-sorted
+    int32_t *rpos = srow + np;                                           // [np] row-sorted position of the pair that arrived i-th
+    float *sw = reinterpret_cast<float *>(rpos + np);                    // [np] w, row-sorted
     float *sy = sw + np;                                                 // [np]
     SmallLds &L = *reinterpret_cast<SmallLds *>(sy + np);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
             if (k >= B) continue;
             if ((uint32_t)c[e] >= (uint32_t)V) { c[e] = 0; ++mapped; }
             srow[k] = (int32_t)kbuf[k];
-            scol[k] = c[e]; sw[k] = wv[e]; sy[k] = yv[e];
+            rpos[p[e]] = k;
+            sw[k] = wv[e]; sy[k] = yv[e];
             plan.r_partner[k] = c[e]; plan.r_w[k] = wv[e]; plan.r_y[k] = yv[e];
         }
     }
@@ -299,11 +300,14 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
                   SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts, plan.heavy);
 
     SMALL_STAMP(4);                                                      // row side numbered and stored
-    // ---- col side: stable sort of the row-sorted pairs by col id
+    // ---- col side: stable sort of the batch AS IT ARRIVED by col id (like the row side; the tiled builder runs both sorts
+    // in the same launches); a pair's row-sorted position links the sides
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int i = wave * 64 * E + j * 64 + lane;
-        key[j] = i < B ? (uint32_t)scol[i] : 0u;
+        uint32_t c = i < B ? (uint32_t)col[i] : 0u;
+        if (c >= (uint32_t)V) c = 0;                                     // (counted above, when the row side pulled it)
+        key[j] = c;
         val[j] = i;
     }
     block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
     for (int e = 0; e < E; ++e) {
         const int j = threadIdx.x * E + e;
         if (j >= B) continue;
-        const int p = vbuf[j];
+        const int p = rpos[vbuf[j]];
         plan.c_perm[j] = p;
         plan.r_to_c[p] = j;
         plan.c_partner[j] = srow[p];

@@ -274,8 +274,8 @@ def build_plan(row, col, chunk_cap, heavy_chunks=8, V=None):
     """Reference construction of the per-batch dedup index the HIP library builds on device.
 
     Row side: pairs stably sorted by row id; each run of equal ids is cut into chunks of at
-    most `chunk_cap` pairs.  Col side: the ROW-SORTED pairs stably sorted by col id, `c_perm`
-    pointing back into row-sorted positions and `r_to_c` its inverse.  See DESIGN.md "Data layout".
+    most `chunk_cap` pairs.  Col side: the pairs (in the order they arrive, like the row side) stably sorted by
+    col id, `c_perm` giving the row-sorted position of each and `r_to_c` its inverse.  See DESIGN.md "Data layout".
     With `V` given, ids outside [0, V) count as id 0 — what the reference's vocabulary lookup returns for
     an unknown token (src/models/estimator.py:26-28) — and counts[5] says how many there were.
     """
@@ -306,7 +306,11 @@ def build_plan(row, col, chunk_cap, heavy_chunks=8, V=None):
     perm_r = np.argsort(row, kind="stable")
     s_row, s_col = row[perm_r], col[perm_r]
     r_chunk_id, r_chunk_start, r_uniq_slot, r_uniq_rec = side(s_row)
-    perm_c = np.argsort(s_col, kind="stable")
+    # the col side sorts the batch as it arrives, independently of the row side (so both sorts can share their launches
+    # on the device); what links the sides is the row-sorted position of every pair
+    rpos = np.empty(B, np.int64)
+    rpos[perm_r] = np.arange(B)
+    perm_c = rpos[np.argsort(col, kind="stable")]
     c_chunk_id, c_chunk_start, c_uniq_slot, c_uniq_rec = side(s_col[perm_c])
     r_to_c = np.empty(B, np.int64)
     r_to_c[perm_c] = np.arange(B)
