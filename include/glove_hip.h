@@ -111,8 +111,8 @@ typedef struct glove_hyper {
 /*
  * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,
  * the `Unique` + `UnsortedSegmentSum` pair that Keras' OptimizerV2 runs on every sparse
- * gradient: pairs are stably sorted by row id (row side) and the sorted
- * pairs again by col id (col side); runs of equal ids are cut into chunks of at most
+ * gradient: pairs are stably sorted by row id (row side) and, independently,
+ * by col id (col side); runs of equal ids are cut into chunks of at most
  * `chunk_cap` pairs; `*_uniq_slot[q]` is the first chunk of the q-th distinct id.
  * Built on the device by glove_plan_build; the arrays are plain device buffers so a caller
  * may keep one plan per batch of a static nonzero stream resident in HBM.
@@ -143,7 +143,7 @@ typedef struct glove_plan {
     int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
     int32_t *r_uniq_rec;        /* [cap_uniq][4]  {id, first chunk, chunks, pairs} of the q-th distinct
                                  * row id: everything the apply kernels need in one 16-B load */
-    /* col side: position k = k-th row-sorted pair in (col id, row-sorted position) order */
+    /* col side: position k = k-th pair in (col id, arrival order) order — sorted like the row side, independently of it */
     int32_t *c_partner;         /* [B] row id */
     int32_t *c_perm;            /* [B] row-sorted position of the pair */
     float   *c_w;               /* [B] glove_weight, col-sorted order (the col side forms e_i by itself) */
