@@ -68,6 +68,9 @@ struct SortSide {
 struct SortPass {
     SortSide s[2];              // 0 row side, 1 col side (blockIdx.y)
     const float *w, *y;         // the batch's weights and values by arrival index
+    int4 *pairs;                // [n] {row id, col id, w, y} by arrival index: written by the first radix_hist (row-side tiles),
+                                // gathered by the last radix_scatter — one 16-byte fetch per pair and side instead of three
+                                // 4-byte ones, each of which moves a whole sector (1 M pairs: 123 -> ... us for that launch)
     int64_t n;
     int shift, db;              // digit = (key >> shift) & ((1 << db) - 1)
     int ntiles;
@@ -133,6 +136,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortPass in)
     int32_t key[E];
     int mapped = 0;
     sort_load_keys<E>(sd, in.n, base, key, mapped);
+    if (side == 0 && sd.vals == nullptr) {
+        // first pass, row-side tiles: the batch as 16-byte pairs for the last pass's gathers (coalesced in and out)
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int64_t i = base + j * 64 + lane;
+            if (i < in.n) in.pairs[i] = make_int4(key[j], sd.other[i], __float_as_int(in.w[i]), __float_as_int(in.y[i]));
+        }
+    }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const bool valid = base + j * 64 + lane < in.n;
@@ -181,9 +192,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortPass in)
         for (int j = 0; j < E; ++j) {
             const bool valid = base + j * 64 + lane < in.n;
             const int32_t p = valid ? val[j] : 0;
-            g_id[j] = sd.other[p];
-            g_w[j] = in.w[p];
-            g_y[j] = in.y[p];
+            const int4 g = in.pairs[p];
+            g_id[j] = side == 0 ? g.y : g.x;
+            g_w[j] = __int_as_float(g.z);
+            g_y[j] = __int_as_float(g.w);
         }
     }
     // ---- stable rank of every key among the keys of its digit in this wave's range (a wave zeroes and uses its own
@@ -676,6 +688,7 @@ struct PlanWs {
     int32_t *row_sorted;             // row ids in row-side order
     int32_t *col_sorted;             // col ids in col-side order
     int32_t *rpos, *c_orig;          // [B] row-sorted position by arrival index / arrival index by col-sorted position
+    int4 *pairs;                     // [B] the batch as {row, col, w, y} by arrival index
     uint16_t *count;                 // [2][digits][tile_stride] of the pass in flight
     int tile_stride;
     int32_t *mapped;                 // [2][sort tiles] ids mapped to 0 per tile (row ids, col ids)
@@ -708,6 +721,7 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     p.col_sorted = (int32_t *)take(n * 4);
     p.rpos = (int32_t *)take(n * 4);
     p.c_orig = (int32_t *)take(n * 4);
+    p.pairs = (int4 *)take(n * 16);
     p.sort_e = sort_e_for(B);
     const size_t per_tile = (size_t)kSortThreads * p.sort_e;
     p.sort_tiles = (int)((n + per_tile - 1) / per_tile);
@@ -806,7 +820,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
 
     // ---- both sides: stable sort of the batch by (id, arrival index); the last pass fills the side's pair arrays
     SortPass fin = {};
-    fin.w = w; fin.y = y;
+    fin.w = w; fin.y = y; fin.pairs = pw.pairs;
     SortSide &rs = fin.s[0], &cs = fin.s[1];
     rs.keys = row; rs.vals = nullptr; rs.clean_below = Vr;
     rs.sorted_keys = pw.row_sorted; rs.other = col; rs.other_below = V;
