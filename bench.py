@@ -363,7 +363,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 
     # refilled every step; on big tables with chunk records, so that the rebuilt index is stepped in the fused form too
     from trainer.hip_api import staging_records
-    rec_kw = dict(records=staging_records(B, tables.V_row, V, tables.d) if mode == "single" and not adam and
+    rec_kw = dict(links=False, records=staging_records(B, tables.V_row, V, tables.d) if mode == "single" and not adam and
                   (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES else None)     # (as the trainer's runner decides: from a first batch)
     staging = hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) if dynamic else None
     ahead = max(1, build_ahead) if dynamic else 1

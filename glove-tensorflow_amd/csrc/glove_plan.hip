@@ -63,6 +63,7 @@ struct SortSide {
     int32_t *partner;           // [n] partner id of the pair at each sorted position
     float *w_out, *y_out;       // [n]
     int32_t *where;             // row side: rpos[arrival index] = sorted position; col side: c_orig[sorted position] = arrival index
+                                // (nullptr: the plan does not want c_perm / r_to_c)
 };
 
 struct SortPass {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(SortPass in)
             sd.partner[dest] = o;
             sd.w_out[dest] = g_w[j];
             sd.y_out[dest] = g_y[j];
-            if (side == 0) sd.where[p] = dest; else sd.where[dest] = p;
+            if (sd.where) { if (side == 0) sd.where[p] = dest; else sd.where[dest] = p; }
         }
     }
 }
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
     const int side = blockIdx.y, t = blockIdx.x;
     const int32_t *keys = sk.keys[side];
     const int64_t begin = (int64_t)t * kTile;
-    if (side == 1) {
+    if (side == 1 && ex.c_perm) {
         // the two sorts ran side by side: what links them is where the row side put each pair (two coalesced accesses, a
         // gather and a scatter per position, under the wave searches below)
         const int64_t q0 = begin + (int64_t)threadIdx.x * kTilePer;
@@ -800,7 +801,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
-        !plan->c_w || !plan->c_y || !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->r_to_c || !plan->c_partner || !plan->c_perm || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
+        !plan->c_w || !plan->c_y || !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->c_partner || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
         return GLOVE_E_BADARG;
     if (!plan->heavy || plan->heavy_chunks < 1 ||
         plan->cap_heavy < 2 * B / ((int64_t)plan->heavy_chunks * plan->chunk_cap) + 2)
@@ -808,6 +809,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     // the chunk / uniq arrays must be able to hold the worst case (every pair its own chunk)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
+    if ((plan->r_to_c == nullptr) != (plan->c_perm == nullptr)) return GLOVE_E_BADARG;     // the links come as a pair or not at all
     if (B <= kSmallPlanMax) {                                                          // launch-bound regime
         if (int rc = plan_build_small(row, col, w, y, B, V, plan, st)) return rc;
         return plan->r_crec ? launch_fill_records(plan, st) : 0;
@@ -824,10 +826,10 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     SortSide &rs = fin.s[0], &cs = fin.s[1];
     rs.keys = row; rs.vals = nullptr; rs.clean_below = Vr;
     rs.sorted_keys = pw.row_sorted; rs.other = col; rs.other_below = V;
-    rs.partner = plan->r_partner; rs.w_out = plan->r_w; rs.y_out = plan->r_y; rs.where = pw.rpos;
+    rs.partner = plan->r_partner; rs.w_out = plan->r_w; rs.y_out = plan->r_y; rs.where = plan->c_perm ? pw.rpos : nullptr;
     cs.keys = col; cs.vals = nullptr; cs.clean_below = V;
     cs.sorted_keys = pw.col_sorted; cs.other = row; cs.other_below = Vr;
-    cs.partner = plan->c_partner; cs.w_out = plan->c_w; cs.y_out = plan->c_y; cs.where = pw.c_orig;
+    cs.partner = plan->c_partner; cs.w_out = plan->c_w; cs.y_out = plan->c_y; cs.where = plan->c_perm ? pw.c_orig : nullptr;
     if (pw.sort_e == 4) launch_sorts<4>(fin, B, bits, pw, st);
     else if (pw.sort_e == 8) launch_sorts<8>(fin, B, bits, pw, st);
     else launch_sorts<16>(fin, B, bits, pw, st);

@@ -317,8 +317,7 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
         const int j = threadIdx.x * E + e;
         if (j >= B) continue;
         const int p = rpos[vbuf[j]];
-        plan.c_perm[j] = p;
-        plan.r_to_c[p] = j;
+        if (plan.c_perm) { plan.c_perm[j] = p; plan.r_to_c[p] = j; }      // (optional links: see glove_hip.h)
         plan.c_partner[j] = srow[p];
         plan.c_w[j] = sw[p];
         plan.c_y[j] = sy[p];

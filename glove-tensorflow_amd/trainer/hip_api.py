@@ -441,7 +441,7 @@ class Plan:
                   "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
-                 cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None):
+                 cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None, links: bool = True):
         self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
         self.cap_chunks = int(B if cap_chunks is None else cap_chunks)
         self.cap_uniq = int(min(B, V) if cap_uniq is None else cap_uniq)
@@ -459,7 +459,10 @@ class Plan:
         self.r_crec = self.c_crec = None
         if self.B > 0 and (self.B <= RECORDS_AT_BUILD_MAX if records is None else records):
             self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
-        self.r_partner, self.r_to_c, self.c_partner, self.c_perm = (torch.empty(n, **i32) for _ in range(4))
+        self.r_partner, self.c_partner = torch.empty(n, **i32), torch.empty(n, **i32)
+        # c_perm / r_to_c link the two sorted orders; no kernel reads them: `links=False` (the per-step plans of a
+        # reshuffled epoch) leaves them out and the build skips the join of its two sorts
+        self.r_to_c, self.c_perm = (torch.empty(n, **i32), torch.empty(n, **i32)) if links else (None, None)
         self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.c_w, self.c_y = torch.empty(n, **f32), torch.empty(n, **f32)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
@@ -542,7 +545,7 @@ class Plan:
         return out
 
     def nbytes(self) -> int:
-        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts"))
+        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts") if getattr(self, f) is not None)
         return n + sum(t.numel() * 4 for t in (self.r_crec, self.c_crec) if t is not None)
 
 
@@ -606,7 +609,7 @@ class GloveHip:
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
                    into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None,
-                   V_row: int = 0, records: bool | None = None) -> Plan:
+                   V_row: int = 0, records: bool | None = None, links: bool = True) -> Plan:
         """Builds the dedup index of one batch on the device.  `V_row`: rows of this rank's row-table shard when the
         row ids are shard-local (ids outside it count as id 0, like col ids outside [0, V)).  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
@@ -622,7 +625,7 @@ class GloveHip:
                 raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
             plan = into
         else:
-            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row, records=records)
+            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row, records=records, links=links)
         if ws is None:      # builds that run concurrently on different streams each bring their own scratch
             ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),

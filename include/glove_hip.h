@@ -137,7 +137,9 @@ typedef struct glove_plan {
     int32_t *r_partner;         /* [B] col id of pair k */
     float   *r_w;               /* [B] glove_weight */
     float   *r_y;               /* [B] glove_value  */
-    int32_t *r_to_c;            /* [B] col-side position of pair k (inverse of c_perm) */
+    int32_t *r_to_c;            /* [B] col-side position of pair k (inverse of c_perm).  r_to_c / c_perm link the two orders for
+                                 * callers that want them (tests, diagnostics); no kernel of the library reads them: both NULL =
+                                 * not computed (the per-step plans of a reshuffled epoch) */
     int32_t *r_chunk_id;        /* [cap_chunks]   row id of the chunk */
     int32_t *r_chunk_start;     /* [cap_chunks+1] first pair of the chunk; [chunks] = B */
     int32_t *r_uniq_slot;       /* [cap_uniq+1]   first chunk of the q-th distinct row id */
@@ -145,7 +147,7 @@ typedef struct glove_plan {
                                  * row id: everything the apply kernels need in one 16-B load */
     /* col side: position k = k-th pair in (col id, arrival order) order — sorted like the row side, independently of it */
     int32_t *c_partner;         /* [B] row id */
-    int32_t *c_perm;            /* [B] row-sorted position of the pair */
+    int32_t *c_perm;            /* [B] row-sorted position of the pair (optional, see r_to_c) */
     float   *c_w;               /* [B] glove_weight, col-sorted order (the col side forms e_i by itself) */
     float   *c_y;               /* [B] glove_value,  col-sorted order */
     int32_t *c_chunk_id;

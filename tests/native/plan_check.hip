@@ -22,6 +22,7 @@ __global__ void check_pairs(glove_plan p, int32_t V, int32_t Vr, int32_t *errors
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < B; k += (int64_t)gridDim.x * blockDim.x) {
         if ((uint32_t)p.r_partner[k] >= (uint32_t)V) flag(errors, 0);
         if ((uint32_t)p.c_partner[k] >= (uint32_t)Vr) flag(errors, 1);
+        if (!p.c_perm) continue;                                        // the optional links between the two orders
         const int32_t q = p.c_perm[k], inv = p.r_to_c[k];
         if ((uint32_t)q >= (uint64_t)B) flag(errors, 2);
         else if (p.r_to_c[q] != (int32_t)k) flag(errors, 4);            // r_to_c inverts c_perm => both are bijections

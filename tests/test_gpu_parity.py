@@ -169,7 +169,8 @@ def _assert_plan_equals_oracle(plan, want, B, w, y):
                          ("r_chunk_start", want["r_chunk_start"], nc_r + 1), ("r_uniq_slot", want["r_uniq_slot"], nu_r + 1),
                          ("c_chunk_id", want["c_chunk_id"], nc_c), ("c_chunk_start", want["c_chunk_start"], nc_c + 1),
                          ("c_uniq_slot", want["c_uniq_slot"], nu_c + 1)):
-        np.testing.assert_array_equal(getattr(plan, name).cpu().numpy()[:n], exp, err_msg=name)
+        if getattr(plan, name) is not None:                     # (c_perm / r_to_c are optional: Plan(links=False))
+            np.testing.assert_array_equal(getattr(plan, name).cpu().numpy()[:n], exp, err_msg=name)
     np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
     np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
@@ -1411,7 +1412,7 @@ def test_fused_step_on_a_device_refilled_plan(hip, plan_checker, workload, B):
     V, d = wl["V"], wl["d"]
     assert staging_records(B, V, V, d) is True
     cap = 32
-    staging = Plan(B, V, cap, "cuda:0", records=True)
+    staging = Plan(B, V, cap, "cuda:0", records=True, links=False)      # as the trainer's runner allocates them
     ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
     errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     lr = 0.05

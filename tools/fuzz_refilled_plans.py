@@ -32,7 +32,7 @@ for case in range(cases):
     d = int(rng.choice([4, 20, 50, 64, 128, 300]))
     cap = int(rng.choice([1, 2, 3, 8, 16, 32]))
     zipf = bool(rng.integers(0, 2))
-    staging = Plan(B, V, cap, "cuda:0", records=True)
+    staging = Plan(B, V, cap, "cuda:0", records=True, links=bool(rng.integers(0, 2)))
     ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
     hp = ref.Hyper(learning_rate=0.05)
     t = oracle_tables(V, d, "Adagrad")
