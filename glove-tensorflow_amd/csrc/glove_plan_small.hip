@@ -1,14 +1,16 @@
 // Single-workgroup index build for small batches (B <= kSmallPlanMax).
 //
-// glove_plan_build's general path is ten dependent launches: launch-bound (~80 us) for the reference's default batch of
-// 1,024 nonzeros, where one step of the kernels takes ~10 us.  A caller that hands over a fresh batch every step (the
+// glove_plan_build's general path is a chain of dependent launches: launch-bound (~50 us) for the reference's default batch
+// of 1,024 nonzeros, where one step of the kernels takes ~10 us.  A caller that hands over a fresh batch every step (the
 // reference's input_fn does: data_utils.py:12-21) needs the index in a few microseconds, so batches up to 4,096 pairs
-// are indexed by ONE workgroup entirely in LDS: two stable radix sorts by id (hand-written, the ballot-rank scheme of
-// glove_plan.hip's tiled sort on one workgroup; passes of up to 8 bits: two for a 10^4-id vocabulary) and, per side,
-// three scans over the threads that number the chunks and ids and close the id records (the first form — rocPRIM's block
-// sort, six scans and a binary search per side — took 21 us at B = 1,024 and 60 at 4,096; a bitonic sort of 64-bit
-// (id, position) keys before it 110 us at B = 4,096; this one 17 and 43 in the stamped diagnostic build).  The result is
-// identical to the general path and to oracle/glove_ref.py:build_plan.
+// are indexed by ONE workgroup entirely in LDS.  The two sides are independent (the col side sorts the batch in arrival
+// order, like the row side): half of the workgroup's waves — a team — builds the row side while the other half builds the
+// col side, in step through the same barriers: per team one stable radix sort by id (hand-written, the ballot-rank scheme
+// of glove_plan.hip's tiled sort; passes of up to 8 bits: two for a 10^4-id vocabulary), the pair fields pulled through the
+// permutation, and three scans over the team's threads that number the chunks and ids and close the id records.  (Earlier
+// forms: rocPRIM's block sort, six scans and a binary search per side 21 us at B = 1,024 and 60 at 4,096; a bitonic sort
+// of 64-bit (id, position) keys before it 110 us at B = 4,096; one side after the other on all 16 waves 17 and 43.)  The
+// result is identical to the general path and to oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
 
 namespace glove {
@@ -25,10 +27,9 @@ __device__ unsigned long long *g_small_stamps = nullptr;     // [waves][16], set
 #define SMALL_STAMP(slot) ((void)0)
 #endif
 
-// Workgroup size: 16 waves.  A sort pass costs ~2 us whatever the number of ranking rounds per wave (its barriers and the
-// column walk of the wave counters are the fixed part), so the rounds are spread over as many waves as a workgroup has:
-// measured per step with the index rebuilt (text8 d = 64): B = 1,024: 16 waves x 1 pair per thread 31.0 us, 4 x 4 33.7;
-// B = 4,096: 16 x 4 56.7 us, 4 x 16 85 (rocPRIM's block sort with six scans per side: 36 / 73).
+// Workgroup size: 16 waves, 8 per side.  A sort pass costs ~2 us whatever the number of ranking rounds per wave (its
+// barriers and the column walk of the wave counters are the fixed part), so the rounds are spread over as many waves as
+// the workgroup has.
 constexpr int kSmallMaxWaves = 16;
 constexpr int kSmallDigits = 256;
 
@@ -48,12 +49,16 @@ struct SmallLds {
 // counters into the waves' starting offsets, a scan over the digits gives where each digit starts, every pair moves to
 // its place in kbuf / vbuf, the next pass reads its positions from there.  Four barriers per pass.  On return kbuf / vbuf
 // hold the pairs in sorted order (positions behind n: untouched).
+// A team = the T threads (T / 64 waves) that build one side; `tid` / `wave` count inside the team.  Both teams run the same
+// code in step: the workgroup barriers below are met by everybody.
+struct Team { int tid, wave; };
+
 template <int T, int E>
-__device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], int n, int bits, uint32_t *kbuf, int32_t *vbuf,
-                                        SmallLds &L)
+__device__ inline void block_sort_pairs(const Team &tm, uint32_t (&key)[E], int32_t (&val)[E], int n, int bits, uint32_t *kbuf,
+                                        int32_t *vbuf, SmallLds &L)
 {
     constexpr int NW = T / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = tm.wave, tid = tm.tid;
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P, nd = 1 << db;
     for (int p = 0; p < P; ++p) {
         const int shift = p * db;
@@ -85,11 +90,11 @@ __device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], i
         }
         __syncthreads();                                                    // (also: every read of kbuf / vbuf has happened)
         int total = 0;
-        if ((int)threadIdx.x < nd) {
+        if (tid < nd) {
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) {
-                const int c = L.wcnt[wv][threadIdx.x];
-                L.wcnt[wv][threadIdx.x] = total;
+                const int c = L.wcnt[wv][tid];
+                L.wcnt[wv][tid] = total;
                 total += c;
             }
         }
@@ -103,7 +108,7 @@ __device__ inline void block_sort_pairs(uint32_t (&key)[E], int32_t (&val)[E], i
         __syncthreads();
         int start = incl - total;
         for (int wv = 0; wv < wave; ++wv) start += L.red[wv];
-        if ((int)threadIdx.x < nd) L.dig[threadIdx.x] = start;
+        if (tid < nd) L.dig[tid] = start;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -127,12 +132,12 @@ struct SmallSideOut {
 // and chunk (sum of both counts, packed), the next id opening behind its last position (min: where its last id's pairs
 // end).
 template <int T, int E>
-__device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_chunks, int cap_heavy, int side,
+__device__ inline void small_side(const Team &tm, const int32_t *ids, int B, int cap, int heavy_chunks, int cap_heavy, int side,
                                   SmallLds &L, const SmallSideOut &o, int32_t *counts, int32_t *heavy)
 {
     constexpr int NW = T / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = threadIdx.x * E;
+    const int lane = threadIdx.x & 63, wave = tm.wave;
+    const int k0 = tm.tid * E;
     int32_t id[E + 1];
     id[0] = (k0 > 0 && k0 <= B) ? ids[k0 - 1] : -1;
 #pragma unroll
@@ -229,130 +234,143 @@ __device__ inline void small_side(const int32_t *ids, int B, int cap, int heavy_
     __syncthreads();                                                        // the scan slots are free again
 }
 
-template <int T, int E>
-constexpr size_t small_lds_bytes() { return (size_t)6 * T * E * 4 + sizeof(SmallLds); }
-
-template <int T, int E>
-__global__ __launch_bounds__(T) void plan_small_kernel(
-    const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
-    const float *__restrict__ y, int B, int V, int bits, glove_plan plan)
+// One side of the index, by the TT threads of `tm`'s team (team 0: row side, 1: col side).  kbuf / vbuf / L: the team's LDS;
+// rpos: shared, written by the row side for plans that want the links, read by the col side behind a barrier.
+template <int TT, int E>
+__device__ inline void build_side(int team, const Team &tm, uint32_t *kbuf, int32_t *vbuf, int32_t *rpos, SmallLds &L,
+                                  const int32_t *own, const int32_t *other, const float *sw, const float *sy,
+                                  int B, int bits, const glove_plan &plan)
 {
-    constexpr int np = T * E, NW = T / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *kbuf = reinterpret_cast<uint32_t *>(smem);                 // [np] sorted ids of the sort in flight
-    int32_t *vbuf = reinterpret_cast<int32_t *>(kbuf + np);              // [np] their positions before the sort
-    int32_t *srow = vbuf + np;                                           // [np] row ids, row-sorted
-    int32_t *rpos = srow + np;                                           // [np] row-sorted position of the pair that arrived i-th
-    float *sw = reinterpret_cast<float *>(rpos + np);                    // [np] w, row-sorted
-    float *sy = sw + np;                                                 // [np]
-    SmallLds &L = *reinterpret_cast<SmallLds *>(sy + np);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // every word of `counts` is written by this kernel: [4] (heavy ids) before anybody appends behind it, the rest at the end
-    if (threadIdx.x == 0) plan.counts[4] = 0;
-    const uint32_t Vr = (uint32_t)(plan.V_row > 0 ? plan.V_row : V);
-    int mapped = 0;
-    SMALL_STAMP(0);
-
-    // ---- row side: stable sort by row id; ids outside [0, V_row) count as id 0 (the reference's unknown-token id,
-    // estimator.py:26-28; see glove_plan.hip)
+    const int lane = threadIdx.x & 63;
+    // ---- stable sort of the batch by this side's id (own / other / sw / sy: the batch in LDS, ids already mapped into the tables)
     uint32_t key[E];
     int32_t val[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const int i = wave * 64 * E + j * 64 + lane;
-        uint32_t r = 0;
-        if (i < B) {
-            r = (uint32_t)row[i];
-            if (r >= Vr) { r = 0; ++mapped; }
-        }
-        key[j] = r;
+        const int i = tm.wave * 64 * E + j * 64 + lane;
+        key[j] = i < B ? (uint32_t)own[i] : 0u;
         val[j] = i;
     }
-    SMALL_STAMP(1);                                                      // row ids arrived
-    block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
-    SMALL_STAMP(2);                                                      // row sort done
-    // col / w / y pulled through the permutation: the row side's pair fields, kept in LDS for the col side
+    SMALL_STAMP(1);                                                      // ids arrived
+    block_sort_pairs<TT, E>(tm, key, val, B, bits, kbuf, vbuf, L);
+    SMALL_STAMP(2);                                                      // sort done
+    // partner id / w / y pulled through the permutation: the side's pair fields
     {
+        int32_t *partner_out = team == 0 ? plan.r_partner : plan.c_partner;
+        float *w_out = team == 0 ? plan.r_w : plan.c_w, *y_out = team == 0 ? plan.r_y : plan.c_y;
         int32_t p[E], c[E];
         float wv[E], yv[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int k = threadIdx.x * E + e;
+            const int k = tm.tid * E + e;
             p[e] = k < B ? vbuf[k] : 0;
-            c[e] = col[p[e]];
-            wv[e] = w[p[e]];
-            yv[e] = y[p[e]];
+            c[e] = other[p[e]];
+            wv[e] = sw[p[e]];
+            yv[e] = sy[p[e]];
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int k = threadIdx.x * E + e;
+            const int k = tm.tid * E + e;
             if (k >= B) continue;
-            if ((uint32_t)c[e] >= (uint32_t)V) { c[e] = 0; ++mapped; }
-            srow[k] = (int32_t)kbuf[k];
-            rpos[p[e]] = k;
-            sw[k] = wv[e]; sy[k] = yv[e];
-            plan.r_partner[k] = c[e]; plan.r_w[k] = wv[e]; plan.r_y[k] = yv[e];
+            partner_out[k] = c[e]; w_out[k] = wv[e]; y_out[k] = yv[e];
+            if (team == 0 && plan.c_perm) rpos[p[e]] = k;
         }
     }
     __syncthreads();                                                     // (counts[4] = 0 is also ordered before the appends)
-    SMALL_STAMP(3);                                                      // pair fields gathered, row arrays stored
-    small_side<T, E>(srow, B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 0, L,
-                  SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}, plan.counts, plan.heavy);
-
-    SMALL_STAMP(4);                                                      // row side numbered and stored
-    // ---- col side: stable sort of the batch AS IT ARRIVED by col id (like the row side; the tiled builder runs both sorts
-    // in the same launches); a pair's row-sorted position links the sides
+    SMALL_STAMP(3);                                                      // pair fields gathered and stored
+    if (team == 1 && plan.c_perm) {                                      // the optional links between the two orders (glove_hip.h)
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int i = wave * 64 * E + j * 64 + lane;
-        uint32_t c = i < B ? (uint32_t)col[i] : 0u;
-        if (c >= (uint32_t)V) c = 0;                                     // (counted above, when the row side pulled it)
-        key[j] = c;
-        val[j] = i;
+        for (int e = 0; e < E; ++e) {
+            const int q = tm.tid * E + e;
+            if (q >= B) continue;
+            const int rp = rpos[vbuf[q]];
+            plan.c_perm[q] = rp;
+            plan.r_to_c[rp] = q;
+        }
     }
-    block_sort_pairs<T, E>(key, val, B, bits, kbuf, vbuf, L);
-    SMALL_STAMP(5);                                                      // col sort done
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int j = threadIdx.x * E + e;
-        if (j >= B) continue;
-        const int p = rpos[vbuf[j]];
-        if (plan.c_perm) { plan.c_perm[j] = p; plan.r_to_c[p] = j; }      // (optional links: see glove_hip.h)
-        plan.c_partner[j] = srow[p];
-        plan.c_w[j] = sw[p];
-        plan.c_y[j] = sy[p];
-    }
-    SMALL_STAMP(6);                                                      // col arrays stored
-    small_side<T, E>(reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, 1, L,
-                  SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec}, plan.counts, plan.heavy);
+    const SmallSideOut so = team == 0 ? SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec}
+                                      : SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec};
+    small_side<TT, E>(tm, reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, team, L,
+                      so, plan.counts, plan.heavy);
+    SMALL_STAMP(4);                                                      // side numbered and stored
+}
 
-    SMALL_STAMP(7);                                                      // col side numbered and stored
+template <int T, int E, bool TEAMS>
+constexpr size_t small_lds_bytes()
+{
+    return TEAMS ? (size_t)9 * (T / 2) * E * 4 + 2 * sizeof(SmallLds) : (size_t)7 * T * E * 4 + sizeof(SmallLds);
+}
+
+// T threads.  TEAMS: two teams of T / 2 build the two sides at the same time, E pairs per thread of a team (B <= (T / 2) E:
+// up to 2,048 pairs — beyond, twice the ranking rounds per wave cost more than the second sort's fixed part saves: 4,096
+// pairs 57 against 52 us); otherwise all T threads build one side after the other (B <= T E).
+template <int T, int E, bool TEAMS>
+__global__ __launch_bounds__(T) void plan_small_kernel(
+    const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
+    const float *__restrict__ y, int B, int V, int bits, glove_plan plan)
+{
+    constexpr int TT = TEAMS ? T / 2 : T, np = TT * E, NT = TEAMS ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *kbuf = reinterpret_cast<uint32_t *>(smem);                 // [NT][np] sorted ids of a team's sort
+    int32_t *vbuf = reinterpret_cast<int32_t *>(kbuf + NT * np);         // [NT][np] their arrival indices
+    int32_t *rpos = vbuf + NT * np;                                      // [np] row-sorted position by arrival index (plans with links)
+    int32_t *srow = rpos + np, *scol = srow + np;                        // [np] the batch: ids mapped into the tables,
+    float *sw = reinterpret_cast<float *>(scol + np), *sy = sw + np;     // [np] weights and values, by arrival index
+    SmallLds *L = reinterpret_cast<SmallLds *>(sy + np);                 // [NT]
+    // every word of `counts` is written by this kernel: [4] (heavy ids) before anybody appends behind it, the rest at the end
+    if (threadIdx.x == 0) plan.counts[4] = 0;
+    SMALL_STAMP(0);
+    // ---- the batch into LDS (coalesced; both sides sort and gather from there); ids outside their table count as id 0 (the
+    // reference's unknown-token id, estimator.py:26-28; see glove_plan.hip)
+    int mapped = 0;
+    {
+        const uint32_t Vr = (uint32_t)(plan.V_row > 0 ? plan.V_row : V);
+        for (int i = threadIdx.x; i < B; i += T) {
+            uint32_t r = (uint32_t)row[i], c = (uint32_t)col[i];
+            if (r >= Vr) { r = 0; ++mapped; }
+            if (c >= (uint32_t)V) { c = 0; ++mapped; }
+            srow[i] = (int32_t)r; scol[i] = (int32_t)c; sw[i] = w[i]; sy[i] = y[i];
+        }
+    }
+    __syncthreads();
+    if (TEAMS) {
+        const int team = threadIdx.x / TT;                               // 0: row side, 1: col side (wave-uniform)
+        const Team tm = {(int)threadIdx.x % TT, ((int)threadIdx.x % TT) >> 6};
+        build_side<TT, E>(team, tm, kbuf + team * np, vbuf + team * np, rpos, L[team], team == 0 ? srow : scol,
+                          team == 0 ? scol : srow, sw, sy, B, bits, plan);
+    } else {
+        const Team tm = {(int)threadIdx.x, (int)threadIdx.x >> 6};
+        for (int side = 0; side < 2; ++side)
+            build_side<TT, E>(side, tm, kbuf, vbuf, rpos, L[0], side == 0 ? srow : scol, side == 0 ? scol : srow, sw, sy, B, bits, plan);
+    }
     // ---- ids mapped to 0, and the spare words
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) mapped += __shfl_xor(mapped, dlt, 64);
-    if (lane == 0) L.s_mapped[wave] = mapped;
+    __shared__ int s_mapped[kSmallMaxWaves];
+    if (lane == 0) s_mapped[wave] = mapped;
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = 0;
-        for (int wv = 0; wv < NW; ++wv) total += L.s_mapped[wv];
+        for (int wv = 0; wv < T / 64; ++wv) total += s_mapped[wv];
         plan.counts[5] = total;
         plan.counts[6] = plan.counts[7] = 0;
     }
-    SMALL_STAMP(8);
+    SMALL_STAMP(5);
 }
 
-template <int T, int E>
+template <int T, int E, bool TEAMS>
 static int launch_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                         const glove_plan *plan, hipStream_t st)
 {
-    const size_t smem = small_lds_bytes<T, E>();
+    const size_t smem = small_lds_bytes<T, E, TEAMS>();
     int bits = 1;                                                        // ids < 2^bits
     while (bits < 31 && (1u << bits) < (uint32_t)V) ++bits;
     // above the 64 KiB default of dynamic LDS: the limit is raised explicitly
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E, TEAMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((plan_small_kernel<T, E>), dim3(1), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
+    hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS>), dim3(1), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
                        bits, *plan);
     return (int)hipGetLastError();
 }
@@ -365,9 +383,10 @@ extern "C" int glove_debug_set_small_stamps(void *p) { return (int)hipMemcpyToSy
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const glove_plan *plan, hipStream_t st)
 {
-    if (B <= 1024) return launch_small<1024, 1>(row, col, w, y, B, V, plan, st);
-    if (B <= 2048) return launch_small<1024, 2>(row, col, w, y, B, V, plan, st);
-    return launch_small<1024, 4>(row, col, w, y, B, V, plan, st);
+    // 16 waves: 8 per side up to 2,048 pairs, all of them on one side after the other beyond
+    if (B <= 1024) return launch_small<1024, 2, true>(row, col, w, y, B, V, plan, st);
+    if (B <= 2048) return launch_small<1024, 4, true>(row, col, w, y, B, V, plan, st);
+    return launch_small<1024, 4, false>(row, col, w, y, B, V, plan, st);
 }
 
 }  // namespace glove
