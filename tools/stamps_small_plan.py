@@ -25,15 +25,16 @@ for bt in batches:
 torch.cuda.synchronize()
 stamps = torch.zeros(16 * 16, dtype=torch.int64, device="cuda:0")
 assert hip.lib.glove_debug_set_small_stamps(stamps.data_ptr()) == 0
-names = ["start", "row ids loaded", "row sort", "gather col/w/y + store", "row side numbered", "col sort", "col arrays stored",
-         "col side numbered", "end"]
+# (up to 2,048 pairs waves 0-7 build the row side while waves 8-15 build the col side: the phases are those of either team;
+#  beyond, the second side's stamps overwrite the first's)
+names = ["start", "batch staged in LDS + ids read back", "sort", "gather partner/w/y + store", "side numbered", "end"]
 acc = []
 for rep in range(8):
     stamps.zero_()
     torch.cuda.synchronize()
     hip.build_plan(*batches[rep % 4], V, chunk_cap=cap, into=staging)
     torch.cuda.synchronize()
-    st = stamps.cpu().numpy().reshape(16, 16)[:, :9].astype(np.float64)
+    st = stamps.cpu().numpy().reshape(16, 16)[:, :6].astype(np.float64)
     st = st[st[:, 0] > 0]                                          # the waves of this workgroup size
     acc.append((st[:, 1:] - st[:, :-1]).max(axis=0) / 100.0)       # 100 MHz -> us; the slowest wave of each phase
 acc = np.median(np.array(acc), axis=0)
