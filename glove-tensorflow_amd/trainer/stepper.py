@@ -644,15 +644,18 @@ class ReshufflingRunner:
 
     def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True, streamed=None):
         """`streamed` (one GPU): the loop of builds and steps runs in C on real streams (glove_steps_rebuilt_f32) instead of
-        being replayed from hipGraphs.  Not the default: at the reference's batch size it is bound by the host's launch
-        calls (Adagrad 40 k steps/s, Adam 27 k) where the replayed graphs, whose branches mostly run one after the other,
-        reach 40-47 k and 31 k."""
+        being replayed from hipGraphs.  None = by batch size: small batches are bound by the host's launch calls on real
+        streams (B = 1,024: 32 k steps/s against 45 k from replayed graphs; 16,384: 21 k against 29 k), big ones gain from
+        builds that really run beside the steps (the branches of a replayed graph mostly run one after the other:
+        131,072: 13.4 k against 11.5 k steps/s; tools/exp_runner_modes.py)."""
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
         self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
         self.graphs_on = bool(graphs) and hip is not None and (
             stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
+        if streamed is None:
+            streamed = bool(graphs) and stream.B >= 65536
         self.streamed = bool(streamed) and stepper is None and hip is not None
         if self.streamed:
             self.graphs_on = False
