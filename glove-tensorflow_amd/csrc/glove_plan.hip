@@ -5,8 +5,9 @@
 // of every step (reached from reference src/models/train_utils.py:13-16).  The
 // sums themselves happen in glove_step.hip; this file only orders the pairs.
 //
-// Integer work: two stable sorts (a hand-written tiled LSD radix sort, below) + two tile kernels that number the
-// chunks and ids of both sides.  The result is bit-exact against oracle/glove_ref.py:build_plan.
+// Integer work: two stable sorts in the same launches (a hand-written tiled LSD radix sort, below) + two tile kernels that
+// number the chunks and ids of both sides (+ one that fills the optional chunk records).  The result is bit-exact against
+// oracle/glove_ref.py:build_plan.
 #include "glove_common.h"
 
 #include <cstring>
