@@ -46,6 +46,10 @@ inline hipError_t zero_words(void *p, int n_words, hipStream_t st)
     return hipGetLastError();
 }
 
+// Up to kPlanSetMax plans handed to one launch by value (the one-workgroup index build of consecutive small batches)
+constexpr int kPlanSetMax = 8;
+struct PlanSet { glove_plan p[kPlanSetMax]; };
+
 // ---- per-chunk records (glove_plan.r_crec / c_crec) --------------------------------------------------
 // A record holds 4 + 3 * capP dwords, capP = rec_cap(chunk_cap): the header, then capP / kRecPad blocks of kRecPad pairs,
 // each block {partner[8] | w[8] | y[8]} — so that what a chunk of n pairs needs is the PREFIX of 4 + 24 ceil(n / 8)

@@ -17,7 +17,7 @@ namespace glove {
 // glove_plan_small.hip: one-workgroup build for batches of at most kSmallPlanMax pairs
 constexpr int kSmallPlanMax = 4096;
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
-                     const glove_plan *plan, hipStream_t st);
+                     const PlanSet &set, int n, hipStream_t st);
 
 __device__ inline int wave_sum_int(int v)
 {
@@ -594,8 +594,12 @@ struct RecordArgs {
     int32_t *crec[2];
     const int2 *chunk_aux[2];     // side_emit's {id position, chunks-behind word} per chunk, or nullptr: bisect uniq_slot
 };
-__global__ __launch_bounds__(kBlock) void fill_records(const int32_t *__restrict__ counts, RecordArgs a, int capP)
+struct RecordSet { RecordArgs a[kPlanSetMax]; const int32_t *counts[kPlanSetMax]; };
+
+__global__ __launch_bounds__(kBlock) void fill_records(RecordSet set, int capP)
 {
+    const RecordArgs &a = set.a[blockIdx.z];               // blockIdx.z: which plan of the set
+    const int32_t *__restrict__ counts = set.counts[blockIdx.z];
     // A wave takes 32 consecutive chunks: their bounds, ids and header words arrive in three coalesced loads, then eight
     // lanes per chunk write line 0 of its record — header | block 0 | 16 B of padding: lane g of the octet stores float4 g,
     // the wave stores eight whole 128-byte lines per instruction — four chunks per lane, the loads of all four in flight
@@ -670,19 +674,38 @@ __global__ __launch_bounds__(kBlock) void fill_records(const int32_t *__restrict
     }
 }
 
+static RecordArgs record_args(const glove_plan *plan, const int2 *aux_r, const int2 *aux_c)
+{
+    return RecordArgs{{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+                      {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
+                      {plan->r_crec, plan->c_crec}, {aux_r, aux_c}};
+}
+
+// records of n plans of the same shape (same B, chunk_cap, capacities) in one launch
+static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStream_t st, const int2 *aux_r = nullptr,
+                                   const int2 *aux_c = nullptr)
+{
+    const glove_plan *plan = plans[0];
+    const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
+    RecordSet set = {};
+    int64_t most = 1;
+    for (int j = 0; j < n; ++j) {
+        set.a[j] = record_args(plans[j], aux_r, aux_c);
+        set.counts[j] = plans[j]->counts;
+        const int64_t nr = most_chunks(plans[j], true), nc = most_chunks(plans[j], false);
+        most = nr > most ? nr : most;
+        most = nc > most ? nc : most;
+    }
+    // 32 chunks per wave, four waves per workgroup
+    const int64_t per_block = (kBlock / 64) * 32;
+    const int64_t nb = (most + per_block - 1) / per_block;
+    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb), 2, n), dim3(kBlock), 0, st, set, capP);
+    return (int)hipGetLastError();
+}
+
 static int launch_fill_records(const glove_plan *plan, hipStream_t st, const int2 *aux_r = nullptr, const int2 *aux_c = nullptr)
 {
-    const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
-    const int64_t nr = most_chunks(plan, true), nc = most_chunks(plan, false);
-    const RecordArgs a = {{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
-                          {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
-                          {plan->r_crec, plan->c_crec}, {aux_r, aux_c}};
-    // 32 chunks per wave, four waves per workgroup
-    const int64_t most = nr > nc ? nr : nc, per_block = (kBlock / 64) * 32;
-    const int64_t nb = (most + per_block - 1) / per_block;
-    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb), 2), dim3(kBlock), 0, st,
-                       (const int32_t *)plan->counts, a, capP);
-    return (int)hipGetLastError();
+    return launch_fill_records_set(&plan, 1, st, aux_r, aux_c);
 }
 
 struct PlanWs {
@@ -791,16 +814,9 @@ size_t glove_plan_workspace_bytes(int64_t B, int32_t V)
     return carve_plan_ws(nullptr, B).bytes;
 }
 
-int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
-                     const glove_plan *plan, void *ws, size_t ws_bytes, void *stream)
+// the argument checks of an index build into `plan` (B > 0)
+static int check_plan_for_build(const glove_plan *plan, int64_t B, int32_t V)
 {
-    if (!plan || !ws || B < 0 || V <= 0 || plan->chunk_cap <= 0 || plan->B != B || !plan->counts) return GLOVE_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (B == 0) {
-        HIP_TRY(zero_words(plan->counts, 8, st));
-        return 0;
-    }
-    if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     if (!plan->r_partner || !plan->r_w || !plan->r_y || !plan->r_chunk_id || !plan->r_chunk_start || !plan->r_uniq_slot ||
         !plan->c_w || !plan->c_y || !plan->r_uniq_rec || !plan->c_uniq_rec || !plan->c_partner || !plan->c_chunk_id || !plan->c_chunk_start || !plan->c_uniq_slot)
         return GLOVE_E_BADARG;
@@ -811,8 +827,24 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
     if ((plan->r_to_c == nullptr) != (plan->c_perm == nullptr)) return GLOVE_E_BADARG;     // the links come as a pair or not at all
+    return 0;
+}
+
+int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
+                     const glove_plan *plan, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!plan || !ws || B < 0 || V <= 0 || plan->chunk_cap <= 0 || plan->B != B || !plan->counts) return GLOVE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        HIP_TRY(zero_words(plan->counts, 8, st));
+        return 0;
+    }
+    if (!row || !col || !w || !y) return GLOVE_E_BADARG;
+    if (int rc = check_plan_for_build(plan, B, V)) return rc;
     if (B <= kSmallPlanMax) {                                                          // launch-bound regime
-        if (int rc = plan_build_small(row, col, w, y, B, V, plan, st)) return rc;
+        PlanSet set;
+        set.p[0] = *plan;
+        if (int rc = plan_build_small(row, col, w, y, B, V, set, 1, st)) return rc;
         return plan->r_crec ? launch_fill_records(plan, st) : 0;
     }
     const PlanWs pw = carve_plan_ws(ws, B);
@@ -849,6 +881,39 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                        (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
     if (plan->r_crec) return launch_fill_records(plan, st, pw.chunk_aux[0], pw.chunk_aux[1]);
     return (int)hipGetLastError();
+}
+
+int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t n,
+                          int32_t V, const glove_plan *const *plans, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!plans || n < 1 || B < 0 || V <= 0) return GLOVE_E_BADARG;
+    for (int j = 0; j < n; ++j)
+        if (!plans[j] || plans[j]->B != B || plans[j]->chunk_cap <= 0 || plans[j]->chunk_cap != plans[0]->chunk_cap || !plans[j]->counts ||
+            (plans[j]->r_crec == nullptr) != (plans[0]->r_crec == nullptr))
+            return GLOVE_E_BADARG;
+    if (B == 0 || B > kSmallPlanMax) {
+        // nothing to share between the builds of big batches: one after the other through the one workspace
+        for (int j = 0; j < n; ++j)
+            if (int rc = glove_plan_build(row + (size_t)j * B, col + (size_t)j * B, w + (size_t)j * B, y + (size_t)j * B, B, V, plans[j],
+                                          ws, ws_bytes, stream))
+                return rc;
+        return 0;
+    }
+    if (!row || !col || !w || !y) return GLOVE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += kPlanSetMax) {
+        const int m = n - j0 < kPlanSetMax ? n - j0 : kPlanSetMax;
+        PlanSet set;
+        for (int j = 0; j < m; ++j) {
+            if (int rc = check_plan_for_build(plans[j0 + j], B, V)) return rc;
+            set.p[j] = *plans[j0 + j];
+        }
+        const size_t off = (size_t)j0 * B;
+        if (int rc = plan_build_small(row + off, col + off, w + off, y + off, B, V, set, m, st)) return rc;
+        if (plans[0]->r_crec)
+            if (int rc = launch_fill_records_set(plans + j0, m, st)) return rc;
+    }
+    return 0;
 }
 
 int glove_plan_fill_records(const glove_plan *plan, void *stream)

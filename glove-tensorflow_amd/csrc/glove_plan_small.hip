@@ -307,8 +307,11 @@ constexpr size_t small_lds_bytes()
 template <int T, int E, bool TEAMS>
 __global__ __launch_bounds__(T) void plan_small_kernel(
     const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
-    const float *__restrict__ y, int B, int V, int bits, glove_plan plan)
+    const float *__restrict__ y, int B, int V, int bits, PlanSet set)
 {
+    // workgroup j indexes batch j of the stream into plan j (glove_plan_build_many; one plan: glove_plan_build)
+    const glove_plan &plan = set.p[blockIdx.x];
+    row += (size_t)blockIdx.x * B; col += (size_t)blockIdx.x * B; w += (size_t)blockIdx.x * B; y += (size_t)blockIdx.x * B;
     constexpr int TT = TEAMS ? T / 2 : T, np = TT * E, NT = TEAMS ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *kbuf = reinterpret_cast<uint32_t *>(smem);                 // [NT][np] sorted ids of a team's sort
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
 
 template <int T, int E, bool TEAMS>
 static int launch_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
-                        const glove_plan *plan, hipStream_t st)
+                        const PlanSet &set, int n, hipStream_t st)
 {
     const size_t smem = small_lds_bytes<T, E, TEAMS>();
     int bits = 1;                                                        // ids < 2^bits
@@ -370,8 +373,8 @@ static int launch_small(const int32_t *row, const int32_t *col, const float *w, 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E, TEAMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS>), dim3(1), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
-                       bits, *plan);
+    hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS>), dim3(n), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
+                       bits, set);
     return (int)hipGetLastError();
 }
 
@@ -381,12 +384,12 @@ extern "C" int glove_debug_set_small_stamps(void *p) { return (int)hipMemcpyToSy
 
 // host side: called from glove_plan_build for B <= kSmallPlanMax (4,096)
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
-                     const glove_plan *plan, hipStream_t st)
+                     const PlanSet &set, int n, hipStream_t st)
 {
     // 16 waves: 8 per side up to 2,048 pairs, all of them on one side after the other beyond
-    if (B <= 1024) return launch_small<1024, 2, true>(row, col, w, y, B, V, plan, st);
-    if (B <= 2048) return launch_small<1024, 4, true>(row, col, w, y, B, V, plan, st);
-    return launch_small<1024, 4, false>(row, col, w, y, B, V, plan, st);
+    if (B <= 1024) return launch_small<1024, 2, true>(row, col, w, y, B, V, set, n, st);
+    if (B <= 2048) return launch_small<1024, 4, true>(row, col, w, y, B, V, set, n, st);
+    return launch_small<1024, 4, false>(row, col, w, y, B, V, set, n, st);
 }
 
 }  // namespace glove

@@ -42,7 +42,7 @@ def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
 
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
-    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_fill_records", "glove_step_workspace_bytes",
+    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_build_many", "glove_plan_fill_records", "glove_step_workspace_bytes",
     "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
@@ -117,6 +117,7 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_abi_version": (C.c_int, []),
         "glove_plan_workspace_bytes": (sz, [i64, i32]),
         "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
+        "glove_plan_build_many": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(P(GlovePlan)), vp, sz, vp]),
         "glove_plan_fill_records": (C.c_int, [P(GlovePlan), vp]),
         "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
         "glove_passes_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
@@ -631,6 +632,20 @@ class GloveHip:
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
         return plan.compact(self.lib, d) if compact else plan
+
+    def build_plans(self, row, col, w, y, V: int, plans: list, ws: torch.Tensor | None = None) -> None:
+        """The indexes of len(plans) consecutive batches of a stream (plan j: pairs [j B, (j + 1) B) of the arrays) refilled
+        in as few launches as they allow: small batches — the reference's 1,024 — go eight to a launch (glove_plan_build_many)."""
+        B, n = plans[0].B, len(plans)
+        for t, dt in ((row, torch.int32), (col, torch.int32), (w, torch.float32), (y, torch.float32)):
+            _require(t, dt)
+            if t.numel() < n * B:
+                raise ValueError("the arrays hold fewer than %d batches of %d pairs" % (n, B))
+        if ws is None:
+            ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
+        ptrs = (C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans])
+        _check(self.lib.glove_plan_build_many(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n, V, ptrs, _ptr(ws), ws.numel(),
+                                              _stream()), "glove_plan_build_many")
 
     # ---- passes
     def passes(self, plan, tables, hyper, ws=None):

@@ -273,6 +273,13 @@ class GraphedSteps:
             torch.cuda.synchronize()
             self._graphs, self._seen = {}, {}
 
+    def __del__(self):           # graphs before the streams they were captured on (see ReshufflingRunner.__del__)
+        try:
+            if getattr(self, "_graphs", None):
+                self.release_graphs()
+        except Exception:
+            pass
+
 
 class Stepper(GraphedSteps):
     """`exchange`: "dense" = all-reduce of the flat dense gradient buffer; "rows" = all-gather of packed touched-row
@@ -662,6 +669,7 @@ class ReshufflingRunner:
         self.sharded = isinstance(stepper, ShardedStepper)
         self.loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, dtype=torch.float32, device=tables.device)
         self.graphs = {}
+        self.grouped = False
         self.position = 0                      # next batch of the current epoch
         self.handles = None                    # both tables sharded: the epoch's prepared batches
         # batches per epoch: the ranks' shards differ in length (by one pair data parallel, by the ownership of the rows
@@ -695,8 +703,11 @@ class ReshufflingRunner:
             del probe
         if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
+        # small batches: their indexes are built a group of `ahead` at a time by one launch; the ring holds two groups
+        from trainer.hip_api import RECORDS_AT_BUILD_MAX
+        self.grouped = stepper is None and not self.streamed and B <= RECORDS_AT_BUILD_MAX and 2 <= self.ahead <= 8
         self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows, records=records, links=False)
-                     for _ in range(self.ahead)]
+                     for _ in range(2 * self.ahead if self.grouped else self.ahead)]
         self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
                         for _ in range(self.ahead)]
         self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
@@ -740,9 +751,44 @@ class ReshufflingRunner:
         else:
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
+    def _issue_grouped(self, first, count, window):
+        """Small batches (the one-workgroup index builder): the indexes of `ahead` consecutive batches come from ONE launch
+        (glove_plan_build_many: a workgroup per batch) — the graph's branches mostly run one after the other, so what counts is
+        the number of launches on the chain: bs = 1,024 Adagrad 22 -> ... us per step.  The ring holds two such groups: group
+        g + 1 is built (on its side stream) while group g steps."""
+        B, G = self.stream.B, self.ahead
+        src = self.window if window else tuple(t[first * B:] for t in (self.stream.row, self.stream.col, self.stream.w, self.stream.y))
+        main = torch.cuda.current_stream()
+        n_groups = (count + G - 1) // G
+        built, stepped = [None] * n_groups, [None] * n_groups
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def launch_build(g):
+            st = self.ring_streams[g % 2]
+            st.wait_event(stepped[g - 2] if g >= 2 else start)
+            n = min(G, count - g * G)
+            with torch.cuda.stream(st):
+                self.hip.build_plans(*(t[g * G * B:] for t in src), self.stream.V,
+                                     self.ring[(g % 2) * G:(g % 2) * G + n], ws=self.ring_ws[g % 2])
+                built[g] = torch.cuda.Event()
+                built[g].record(st)
+        for g in range(min(2, n_groups)):
+            launch_build(g)
+        for g in range(n_groups):
+            main.wait_event(built[g])
+            for j in range(min(G, count - g * G)):
+                self._step(self.ring[(g % 2) * G + j])
+            stepped[g] = torch.cuda.Event()
+            stepped[g].record(main)
+            if g + 2 < n_groups:
+                launch_build(g + 2)
+
     def _issue(self, first, count, window=False):
         """`count` steps over batches first..first+count-1 of the stream (window: over the first `count` batches of the
         window) with `ahead` index builds in flight."""
+        if self.grouped:
+            return self._issue_grouped(first, count, window)
         B = self.stream.B
         batch = (lambda i: tuple(t[i * B:(i + 1) * B] for t in self.window)) if window else (lambda i: self.stream.batch(first + i))
         main = torch.cuda.current_stream()
@@ -816,6 +862,15 @@ class ReshufflingRunner:
         if self.graphs:
             torch.cuda.synchronize()
             self.graphs = {}
+
+    def __del__(self):
+        # the captured bursts go before the side streams they were captured on: a runner dropped with its graphs alive
+        # (attributes torn down in arbitrary order, nothing synchronised) made the replay of ANOTHER object's graph
+        # segfault later in the same process (tests/rccl_graph_case.py, the grouped small-batch bursts)
+        try:
+            self.release_graphs()
+        except Exception:
+            pass
 
     def read_loss(self) -> dict:
         """Host read of the last step's scalars (synchronises; call at the logging cadence only)."""

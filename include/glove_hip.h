@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed); 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -182,6 +182,15 @@ size_t glove_plan_workspace_bytes(int64_t B, int32_t V);
 int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, const float *y,
                      int64_t B, int32_t V, const glove_plan *plan,
                      void *ws, size_t ws_bytes, void *stream);
+
+/* The indexes of n consecutive batches of a stream in as few launches as they allow: plan j (plans[j], a host array of n
+ * pointers) indexes pairs [j B, (j + 1) B) of row / col / w / y.  All plans have the same B, chunk_cap and kind (records or
+ * not).  Batches of up to 4,096 pairs — the one-workgroup builder — go eight to a launch, a workgroup each (the per-step
+ * plans of a reshuffled epoch at the reference's batch size: one launch instead of one per step); bigger ones are built one
+ * after the other, exactly as n calls of glove_plan_build would.  The results are those of n calls of glove_plan_build. */
+int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y,
+                          int64_t B, int32_t n, int32_t V, const glove_plan *const *plans,
+                          void *ws, size_t ws_bytes, void *stream);
 
 /* (Re)builds r_crec / c_crec of a plan whose other arrays are complete (both must be non-NULL). */
 int glove_plan_fill_records(const glove_plan *plan, void *stream);

@@ -1521,3 +1521,27 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
             gb = e.sum() + kappa_b * n * ownb0[u].double()
             want_b = ownb0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
             np.testing.assert_allclose(gotb[u].item(), want_b.item(), rtol=2e-5, atol=1e-6, err_msg="%s bias %d" % (side, u))
+
+
+@pytest.mark.parametrize("B,V,cap,n", [(300, 40, 8, 3), (1024, 10000, 16, 8), (2048, 500, 32, 4), (3000, 97, 3, 5), (4096, 12000, 16, 11),
+                                       (5000, 300, 8, 3)])
+def test_many_small_plans_from_one_launch(hip, plan_checker, B, V, cap, n):
+    """glove_plan_build_many: the indexes of n consecutive batches of a stream — a workgroup per batch, eight batches per
+    launch while they fit the one-workgroup builder, one after the other beyond — are the indexes n calls of
+    glove_plan_build give, array for array and record for record, into poisoned plans."""
+    from trainer.hip_api import Plan
+    batches = [make_batch(900 + 7 * j, B, V, zipf=(j % 2 == 0)) for j in range(n)]
+    batches[1][0][::5] = V + 3                                  # ids outside the vocabulary in one of them
+    row, col, w, y = (torch.from_numpy(np.concatenate([b[k] for b in batches])).cuda() for k in range(4))
+    plans = [Plan(B, V, cap, "cuda:0", records=True, links=(j % 2 == 0)) for j in range(n)]
+    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
+    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    for p_ in plans:
+        _poison(p_, ws)
+    hip.build_plans(row, col, w, y, V, plans, ws=ws)
+    for j, p_ in enumerate(plans):
+        plan_checker(p_, V, errors)
+        _assert_plan_equals_oracle(p_, ref.build_plan(batches[j][0], batches[j][1], cap, V=V), B, batches[j][2], batches[j][3])
+        single = hip.build_plan(*to_dev(*batches[j]), V, chunk_cap=cap, records=True)
+        assert torch.equal(p_.counts, single.counts)
+    assert errors.tolist() == [0] * 8, errors.tolist()
