@@ -374,8 +374,43 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev) for _ in range(ahead)]
         ring_streams = [torch.cuda.Stream() for _ in range(ahead)]
 
+    # small batches (the one-workgroup index builder): the indexes of a group of steps come from ONE launch
+    # (glove_plan_build_many), as the trainer's reshuffling runner builds them; two groups of staging plans
+    grouped = dynamic and 2 <= ahead <= 8 and B <= 4096 and nb >= ahead
+    if grouped:
+        ring = ring + [hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) for _ in range(ahead)]
+        whole = tuple(coo[k][:(nb // ahead) * ahead * B].contiguous() for k in ("row", "col", "w", "y"))
+
+    def sweep_grouped(n_steps):
+        main, G = torch.cuda.current_stream(), ahead
+        n_groups = (n_steps + G - 1) // G
+        built, stepped = [None] * n_groups, [None] * n_groups
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def launch_build(g):
+            st = ring_streams[g % 2]
+            st.wait_event(stepped[g - 2] if g >= 2 else start)
+            n, b0 = min(G, n_steps - g * G), (g % (nb // G)) * G
+            with torch.cuda.stream(st):
+                hip.build_plans(*(t[b0 * B:] for t in whole), V, ring[(g % 2) * G:(g % 2) * G + n], ws=ring_ws[g % 2])
+                built[g] = torch.cuda.Event()
+                built[g].record(st)
+        for g in range(min(2, n_groups)):
+            launch_build(g)
+        for g in range(n_groups):
+            main.wait_event(built[g])
+            for j in range(min(G, n_steps - g * G)):
+                hip.step_adagrad(ring[(g % 2) * G + j], tables, hyper, loss_out, ws)
+            stepped[g] = torch.cuda.Event()
+            stepped[g].record(main)
+            if g + 2 < n_groups:
+                launch_build(g + 2)
+
     def sweep_pipelined(n_steps):
         """n_steps dynamic steps with `ahead` index builds in flight (call inside a graph capture or eagerly)."""
+        if grouped:
+            return sweep_grouped(n_steps)
         main = torch.cuda.current_stream()
         built, stepped = [None] * n_steps, [None] * n_steps
         start = torch.cuda.Event()
@@ -686,6 +721,10 @@ def main(argv=None):
         specs = ([("c1_shape_adam_bs1024", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
                   # BASELINE configs[1] at the reference's batch size and at (nearly) the whole stream per step
                   ("text8_d64_bs1024", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
+                  # ... and with the index of every batch rebuilt inside the timed step (a reshuffled epoch at the reference's
+                  # default shape: the indexes of eight steps from one launch)
+                  ("text8_d64_bs1024_index_rebuilt_every_step", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200,
+                                                                        dynamic=True, build_ahead=8)),
                   ("text8_d64_bs1048576", 4, dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
                   # the dedup index (the reference's per-step Unique + segment-sum) rebuilt INSIDE every timed step instead
                   # of once at load — what a reshuffled epoch costs: one build at a time, and six in flight on their own streams
