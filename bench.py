@@ -374,11 +374,12 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev) for _ in range(ahead)]
         ring_streams = [torch.cuda.Stream() for _ in range(ahead)]
 
-    # small batches (the one-workgroup index builder): the indexes of a group of steps come from ONE launch
-    # (glove_plan_build_many), as the trainer's reshuffling runner builds them; two groups of staging plans
-    grouped = dynamic and 2 <= ahead <= 8 and B <= 4096 and nb >= ahead
+    # the indexes of a group of steps come from the launches of ONE build (glove_plan_build_many), as the trainer's
+    # reshuffling runner builds them; two groups of staging plans
+    grouped = dynamic and 2 <= ahead <= 8 and nb >= ahead and B < 65536     # (C4, B = 1 M: 847 us grouped against 783)
     if grouped:
         ring = ring + [hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) for _ in range(ahead)]
+        ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * ahead, dtype=torch.uint8, device=dev) for _ in range(2)]
         whole = tuple(coo[k][:(nb // ahead) * ahead * B].contiguous() for k in ("row", "col", "w", "y"))
 
     def sweep_grouped(n_steps):

@@ -124,9 +124,17 @@ __device__ inline void sort_load_keys(const SortSide &sd, int64_t n, int64_t bas
     }
 }
 
-template <int E>
-__global__ __launch_bounds__(kSortThreads) void radix_hist(SortPass in)
+// The passes of up to kPlanSetMax batches of the same size share their launches as well (blockIdx.z = batch): the
+// indexes of consecutive batches of a stream in the launches of one (glove_plan_build_many).
+struct SortPassSet { SortPass b[kPlanSetMax]; };
+// (a single batch takes its arguments bare: a 2-KB argument block costs every launch of a lone build ~1.5 us)
+__device__ inline const SortPass &pick(const SortPass &a) { return a; }
+__device__ inline const SortPass &pick(const SortPassSet &a) { return a.b[blockIdx.z]; }
+
+template <int E, class Args>
+__global__ __launch_bounds__(kSortThreads) void radix_hist(Args args)
 {
+    const SortPass &in = pick(args);
     static_assert(kSortThreads == kMaxDigits, "one thread per digit zeroes and stores the histogram");
     __shared__ int hist[kMaxDigits];
     const int side = blockIdx.y;
@@ -160,9 +168,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(SortPass in)
     if (sd.clean_below > 0) block_store_sum(mapped, in.mapped + (size_t)side * in.ntiles + blockIdx.x);
 }
 
-template <int E, bool LAST>
-__global__ __launch_bounds__(kSortThreads) void radix_scatter(SortPass in)
+template <int E, bool LAST, class Args>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter(Args args)
 {
+    const SortPass &in = pick(args);
     __shared__ int wcnt[kSortWaves][kMaxDigits];          // a wave's running digit counts; then every wave's bases
     __shared__ int scan_red[kSortWaves];
     const int side = blockIdx.y;
@@ -421,10 +430,25 @@ struct TileExtra {
     int32_t *c_perm, *r_to_c;
 };
 
-__global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
-                                                           int64_t *__restrict__ tile_rs, int2 *__restrict__ tile_sums,
-                                                           TileExtra ex)
+struct SideOne {                                           // the numbering kernels' arguments for one batch
+    SideKeys sk;
+    int64_t *tile_rs;
+    int2 *tile_sums;
+    TileExtra ex;
+    SideOut out;
+};
+struct SideSet { SideOne b[kPlanSetMax]; };                // per batch of a set (blockIdx.z)
+__device__ inline const SideOne &pick(const SideOne &a) { return a; }
+__device__ inline const SideOne &pick(const SideSet &a) { return a.b[blockIdx.z]; }
+
+template <class Args>
+__global__ __launch_bounds__(kTileThreads) void side_tiles(Args args, int64_t B, int32_t chunk_cap, int ntiles)
 {
+    const SideOne &one = pick(args);
+    const SideKeys &sk = one.sk;
+    int64_t *__restrict__ tile_rs = one.tile_rs;
+    int2 *__restrict__ tile_sums = one.tile_sums;
+    const TileExtra &ex = one.ex;
     __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
     __shared__ int red[2][kTileThreads / 64];
     const int side = blockIdx.y, t = blockIdx.x;
@@ -488,10 +512,14 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(SideKeys sk, int64_t 
     }
 }
 
-__global__ __launch_bounds__(kTileThreads) void side_emit(SideKeys sk, int64_t B, int32_t chunk_cap, int ntiles,
-                                                          const int64_t *__restrict__ tile_rs,
-                                                          const int2 *__restrict__ tile_sums, SideOut out)
+template <class Args>
+__global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, int32_t chunk_cap, int ntiles)
 {
+    const SideOne &one = pick(args);
+    const SideKeys &sk = one.sk;
+    const int64_t *__restrict__ tile_rs = one.tile_rs;
+    const int2 *__restrict__ tile_sums = one.tile_sums;
+    const SideOut &out = one.out;
     __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
     __shared__ int64_t lds_open[kTileThreads / 64];
     __shared__ int red[2][kTileThreads / 64];
@@ -594,12 +622,16 @@ struct RecordArgs {
     int32_t *crec[2];
     const int2 *chunk_aux[2];     // side_emit's {id position, chunks-behind word} per chunk, or nullptr: bisect uniq_slot
 };
-struct RecordSet { RecordArgs a[kPlanSetMax]; const int32_t *counts[kPlanSetMax]; };
+struct RecordOne { RecordArgs a; const int32_t *counts; };
+struct RecordSet { RecordOne b[kPlanSetMax]; };            // blockIdx.z: which plan of the set
+__device__ inline const RecordOne &pick(const RecordOne &a) { return a; }
+__device__ inline const RecordOne &pick(const RecordSet &a) { return a.b[blockIdx.z]; }
 
-__global__ __launch_bounds__(kBlock) void fill_records(RecordSet set, int capP)
+template <class Args>
+__global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
 {
-    const RecordArgs &a = set.a[blockIdx.z];               // blockIdx.z: which plan of the set
-    const int32_t *__restrict__ counts = set.counts[blockIdx.z];
+    const RecordArgs &a = pick(args).a;
+    const int32_t *__restrict__ counts = pick(args).counts;
     // A wave takes 32 consecutive chunks: their bounds, ids and header words arrive in three coalesced loads, then eight
     // lanes per chunk write line 0 of its record — header | block 0 | 16 B of padding: lane g of the octet stores float4 g,
     // the wave stores eight whole 128-byte lines per instruction — four chunks per lane, the loads of all four in flight
@@ -682,16 +714,16 @@ static RecordArgs record_args(const glove_plan *plan, const int2 *aux_r, const i
 }
 
 // records of n plans of the same shape (same B, chunk_cap, capacities) in one launch
-static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStream_t st, const int2 *aux_r = nullptr,
-                                   const int2 *aux_c = nullptr)
+static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStream_t st, const int2 *const *aux_r = nullptr,
+                                   const int2 *const *aux_c = nullptr)
 {
     const glove_plan *plan = plans[0];
     const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
     RecordSet set = {};
     int64_t most = 1;
     for (int j = 0; j < n; ++j) {
-        set.a[j] = record_args(plans[j], aux_r, aux_c);
-        set.counts[j] = plans[j]->counts;
+        set.b[j].a = record_args(plans[j], aux_r ? aux_r[j] : nullptr, aux_c ? aux_c[j] : nullptr);
+        set.b[j].counts = plans[j]->counts;
         const int64_t nr = most_chunks(plans[j], true), nc = most_chunks(plans[j], false);
         most = nr > most ? nr : most;
         most = nc > most ? nc : most;
@@ -699,13 +731,15 @@ static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStr
     // 32 chunks per wave, four waves per workgroup
     const int64_t per_block = (kBlock / 64) * 32;
     const int64_t nb = (most + per_block - 1) / per_block;
-    hipLaunchKernelGGL(fill_records, dim3((unsigned)(nb < 1 ? 1 : nb), 2, n), dim3(kBlock), 0, st, set, capP);
+    const dim3 grid((unsigned)(nb < 1 ? 1 : nb), 2, n);
+    if (n == 1) hipLaunchKernelGGL(fill_records<RecordOne>, grid, dim3(kBlock), 0, st, set.b[0], capP);
+    else hipLaunchKernelGGL(fill_records<RecordSet>, grid, dim3(kBlock), 0, st, set, capP);
     return (int)hipGetLastError();
 }
 
-static int launch_fill_records(const glove_plan *plan, hipStream_t st, const int2 *aux_r = nullptr, const int2 *aux_c = nullptr)
+static int launch_fill_records(const glove_plan *plan, hipStream_t st)
 {
-    return launch_fill_records_set(&plan, 1, st, aux_r, aux_c);
+    return launch_fill_records_set(&plan, 1, st);
 }
 
 struct PlanWs {
@@ -769,37 +803,109 @@ static int ceil_log2(int32_t v)
     return b;
 }
 
-// Both stable sorts by id, P passes of (radix_hist, radix_scatter) with grid.y = side.  `fin` carries, per side, the raw ids
-// (first pass) and the destination arrays of the last pass.
+// Both stable sorts by id of the nb batches of a set, P passes of (radix_hist, radix_scatter) with grid.y = side and
+// grid.z = batch.  fin[j] carries, per side, the raw ids (first pass) and the destination arrays of the last pass; pw[j]
+// is batch j's workspace.
 template <int E>
-static void launch_sorts(SortPass fin, int64_t B, int bits, const PlanWs &pw, hipStream_t st)
+static void launch_sorts(const SortPass *fin, const PlanWs *pw, int nb, int64_t B, int bits, hipStream_t st)
 {
     const int P = (bits + 7) / 8, db = (bits + P - 1) / P;
     for (int p = 0; p < P; ++p) {
-        SortPass in = fin;
-        for (int sd = 0; sd < 2; ++sd) {
-            if (p > 0) {
-                in.s[sd].keys = pw.keys[sd][(p - 1) & 1];
-                in.s[sd].vals = pw.vals[sd][(p - 1) & 1];
-                in.s[sd].clean_below = 0;
+        SortPassSet set;
+        for (int j = 0; j < nb; ++j) {
+            SortPass &in = set.b[j];
+            in = fin[j];
+            for (int sd = 0; sd < 2; ++sd) {
+                if (p > 0) {
+                    in.s[sd].keys = pw[j].keys[sd][(p - 1) & 1];
+                    in.s[sd].vals = pw[j].vals[sd][(p - 1) & 1];
+                    in.s[sd].clean_below = 0;
+                }
+                in.s[sd].out_keys = pw[j].keys[sd][p & 1];
+                in.s[sd].out_vals = pw[j].vals[sd][p & 1];
             }
-            in.s[sd].out_keys = pw.keys[sd][p & 1];
-            in.s[sd].out_vals = pw.vals[sd][p & 1];
+            in.n = B;
+            in.shift = p * db;
+            in.db = db;
+            in.ntiles = pw[j].sort_tiles;
+            in.count = pw[j].count;
+            in.tile_stride = pw[j].tile_stride;
+            in.mapped = pw[j].mapped;
         }
-        in.n = B;
-        in.shift = p * db;
-        in.db = db;
-        in.ntiles = pw.sort_tiles;
-        in.count = pw.count;
-        in.tile_stride = pw.tile_stride;
-        in.mapped = pw.mapped;
-        hipLaunchKernelGGL((radix_hist<E>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
-        if (p < P - 1) hipLaunchKernelGGL((radix_scatter<E, false>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
-        else hipLaunchKernelGGL((radix_scatter<E, true>), dim3(pw.sort_tiles, 2), dim3(kSortThreads), 0, st, in);
+        const dim3 grid(pw[0].sort_tiles, 2, nb);
+        if (nb == 1) {
+            hipLaunchKernelGGL((radix_hist<E, SortPass>), grid, dim3(kSortThreads), 0, st, set.b[0]);
+            if (p < P - 1) hipLaunchKernelGGL((radix_scatter<E, false, SortPass>), grid, dim3(kSortThreads), 0, st, set.b[0]);
+            else hipLaunchKernelGGL((radix_scatter<E, true, SortPass>), grid, dim3(kSortThreads), 0, st, set.b[0]);
+        } else {
+            hipLaunchKernelGGL((radix_hist<E, SortPassSet>), grid, dim3(kSortThreads), 0, st, set);
+            if (p < P - 1) hipLaunchKernelGGL((radix_scatter<E, false, SortPassSet>), grid, dim3(kSortThreads), 0, st, set);
+            else hipLaunchKernelGGL((radix_scatter<E, true, SortPassSet>), grid, dim3(kSortThreads), 0, st, set);
+        }
     }
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// The tiled builder over nb <= kPlanSetMax batches of B pairs each (batch j: pairs [j B, (j + 1) B) of the arrays, plan
+// plans[j], workspace slice j): every launch covers all of them.
+static int build_tiled_set(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
+                           const glove_plan *const *plans, int nb, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    const size_t per = carve_plan_ws(nullptr, B).bytes;
+    if (per * (size_t)nb > ws_bytes) return GLOVE_E_WORKSPACE;
+    PlanWs pw[kPlanSetMax];
+    SortPass fin[kPlanSetMax];
+    const int bits = ceil_log2(V);
+    for (int j = 0; j < nb; ++j) {
+        const glove_plan *plan = plans[j];
+        pw[j] = carve_plan_ws((char *)ws + per * j, B);
+        const int32_t Vr = plan->V_row > 0 ? plan->V_row : V;
+        const size_t off = (size_t)j * B;
+        // ---- both sides: stable sort of the batch by (id, arrival index); the last pass fills the side's pair arrays
+        SortPass &f = fin[j];
+        f = SortPass{};
+        f.w = w + off; f.y = y + off; f.pairs = pw[j].pairs;
+        SortSide &rs = f.s[0], &cs = f.s[1];
+        rs.keys = row + off; rs.vals = nullptr; rs.clean_below = Vr;
+        rs.sorted_keys = pw[j].row_sorted; rs.other = col + off; rs.other_below = V;
+        rs.partner = plan->r_partner; rs.w_out = plan->r_w; rs.y_out = plan->r_y; rs.where = plan->c_perm ? pw[j].rpos : nullptr;
+        cs.keys = col + off; cs.vals = nullptr; cs.clean_below = V;
+        cs.sorted_keys = pw[j].col_sorted; cs.other = row + off; cs.other_below = Vr;
+        cs.partner = plan->c_partner; cs.w_out = plan->c_w; cs.y_out = plan->c_y; cs.where = plan->c_perm ? pw[j].c_orig : nullptr;
+    }
+    if (pw[0].sort_e == 4) launch_sorts<4>(fin, pw, nb, B, bits, st);
+    else if (pw[0].sort_e == 8) launch_sorts<8>(fin, pw, nb, B, bits, st);
+    else launch_sorts<16>(fin, pw, nb, B, bits, st);
+
+    // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
+    SideSet ss;
+    const int2 *aux_r[kPlanSetMax], *aux_c[kPlanSetMax];
+    for (int j = 0; j < nb; ++j) {
+        const glove_plan *plan = plans[j];
+        ss.b[j].sk = SideKeys{{pw[j].row_sorted, pw[j].col_sorted}};
+        ss.b[j].tile_rs = pw[j].tile_rs;
+        ss.b[j].tile_sums = pw[j].tile_sums;
+        ss.b[j].out = SideOut{{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
+                            {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
+                            (const int64_t *)pw[j].tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
+                            {plan->r_crec ? pw[j].chunk_aux[0] : nullptr, plan->r_crec ? pw[j].chunk_aux[1] : nullptr}};
+        ss.b[j].ex = TileExtra{pw[j].tile_re, plan->counts, (const int32_t *)pw[j].mapped, 2 * pw[j].sort_tiles,
+                             (const int32_t *)pw[j].c_orig, (const int32_t *)pw[j].rpos, plan->c_perm, plan->r_to_c};
+        aux_r[j] = pw[j].chunk_aux[0];
+        aux_c[j] = pw[j].chunk_aux[1];
+    }
+    const dim3 grid(pw[0].ntiles, 2, nb);
+    if (nb == 1) {
+        hipLaunchKernelGGL(side_tiles<SideOne>, grid, dim3(kTileThreads), 0, st, ss.b[0], B, plans[0]->chunk_cap, pw[0].ntiles);
+        hipLaunchKernelGGL(side_emit<SideOne>, grid, dim3(kTileThreads), 0, st, ss.b[0], B, plans[0]->chunk_cap, pw[0].ntiles);
+    } else {
+        hipLaunchKernelGGL(side_tiles<SideSet>, grid, dim3(kTileThreads), 0, st, ss, B, plans[0]->chunk_cap, pw[0].ntiles);
+        hipLaunchKernelGGL(side_emit<SideSet>, grid, dim3(kTileThreads), 0, st, ss, B, plans[0]->chunk_cap, pw[0].ntiles);
+    }
+    if (plans[0]->r_crec) return launch_fill_records_set(plans, nb, st, aux_r, aux_c);
+    return (int)hipGetLastError();
+}
 
 }  // namespace glove
 
@@ -847,40 +953,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
         if (int rc = plan_build_small(row, col, w, y, B, V, set, 1, st)) return rc;
         return plan->r_crec ? launch_fill_records(plan, st) : 0;
     }
-    const PlanWs pw = carve_plan_ws(ws, B);
-    if (pw.bytes > ws_bytes) return GLOVE_E_WORKSPACE;
-
-    const int bits = ceil_log2(V);
-    const int32_t Vr = plan->V_row > 0 ? plan->V_row : V;
-
-    // ---- both sides: stable sort of the batch by (id, arrival index); the last pass fills the side's pair arrays
-    SortPass fin = {};
-    fin.w = w; fin.y = y; fin.pairs = pw.pairs;
-    SortSide &rs = fin.s[0], &cs = fin.s[1];
-    rs.keys = row; rs.vals = nullptr; rs.clean_below = Vr;
-    rs.sorted_keys = pw.row_sorted; rs.other = col; rs.other_below = V;
-    rs.partner = plan->r_partner; rs.w_out = plan->r_w; rs.y_out = plan->r_y; rs.where = plan->c_perm ? pw.rpos : nullptr;
-    cs.keys = col; cs.vals = nullptr; cs.clean_below = V;
-    cs.sorted_keys = pw.col_sorted; cs.other = row; cs.other_below = Vr;
-    cs.partner = plan->c_partner; cs.w_out = plan->c_w; cs.y_out = plan->c_y; cs.where = plan->c_perm ? pw.c_orig : nullptr;
-    if (pw.sort_e == 4) launch_sorts<4>(fin, B, bits, pw, st);
-    else if (pw.sort_e == 8) launch_sorts<8>(fin, B, bits, pw, st);
-    else launch_sorts<16>(fin, B, bits, pw, st);
-
-    // ---- chunks and ids of both sides: two launches over tiles of the sorted keys, then the id records
-    const SideKeys sk = {{pw.row_sorted, pw.col_sorted}};
-    const SideOut so = {{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
-                        {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
-                        (const int64_t *)pw.tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
-                        {plan->r_crec ? pw.chunk_aux[0] : nullptr, plan->r_crec ? pw.chunk_aux[1] : nullptr}};
-    const TileExtra ex = {pw.tile_re, plan->counts, (const int32_t *)pw.mapped, 2 * pw.sort_tiles,
-                          (const int32_t *)pw.c_orig, (const int32_t *)pw.rpos, plan->c_perm, plan->r_to_c};
-    hipLaunchKernelGGL(side_tiles, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
-                       pw.tile_rs, pw.tile_sums, ex);
-    hipLaunchKernelGGL(side_emit, dim3(pw.ntiles, 2), dim3(kTileThreads), 0, st, sk, B, plan->chunk_cap, pw.ntiles,
-                       (const int64_t *)pw.tile_rs, (const int2 *)pw.tile_sums, so);
-    if (plan->r_crec) return launch_fill_records(plan, st, pw.chunk_aux[0], pw.chunk_aux[1]);
-    return (int)hipGetLastError();
+    return build_tiled_set(row, col, w, y, B, V, &plan, 1, ws, ws_bytes, st);
 }
 
 int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t n,
@@ -891,16 +964,30 @@ int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w
         if (!plans[j] || plans[j]->B != B || plans[j]->chunk_cap <= 0 || plans[j]->chunk_cap != plans[0]->chunk_cap || !plans[j]->counts ||
             (plans[j]->r_crec == nullptr) != (plans[0]->r_crec == nullptr))
             return GLOVE_E_BADARG;
-    if (B == 0 || B > kSmallPlanMax) {
-        // nothing to share between the builds of big batches: one after the other through the one workspace
+    if (B == 0) {
         for (int j = 0; j < n; ++j)
-            if (int rc = glove_plan_build(row + (size_t)j * B, col + (size_t)j * B, w + (size_t)j * B, y + (size_t)j * B, B, V, plans[j],
-                                          ws, ws_bytes, stream))
-                return rc;
+            if (int rc = glove_plan_build(row, col, w, y, 0, V, plans[j], ws, ws_bytes, stream)) return rc;
         return 0;
     }
     if (!row || !col || !w || !y) return GLOVE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (B > kSmallPlanMax) {
+        // the tiled builder: as many batches per set of launches as the workspace holds (a slice of
+        // glove_plan_workspace_bytes(B, V) each), up to kPlanSetMax
+        if (!ws) return GLOVE_E_BADARG;
+        const size_t per = carve_plan_ws(nullptr, B).bytes;
+        int fit = (int)(ws_bytes / per);
+        if (fit < 1) return GLOVE_E_WORKSPACE;
+        fit = fit > kPlanSetMax ? kPlanSetMax : fit;
+        for (int j0 = 0; j0 < n; j0 += fit) {
+            const int m = n - j0 < fit ? n - j0 : fit;
+            for (int j = 0; j < m; ++j)
+                if (int rc = check_plan_for_build(plans[j0 + j], B, V)) return rc;
+            const size_t off = (size_t)j0 * B;
+            if (int rc = build_tiled_set(row + off, col + off, w + off, y + off, B, V, plans + j0, m, ws, ws_bytes, st)) return rc;
+        }
+        return 0;
+    }
     for (int j0 = 0; j0 < n; j0 += kPlanSetMax) {
         const int m = n - j0 < kPlanSetMax ? n - j0 : kPlanSetMax;
         PlanSet set;

@@ -304,13 +304,16 @@ constexpr size_t small_lds_bytes()
 // T threads.  TEAMS: two teams of T / 2 build the two sides at the same time, E pairs per thread of a team (B <= (T / 2) E:
 // up to 2,048 pairs — beyond, twice the ranking rounds per wave cost more than the second sort's fixed part saves: 4,096
 // pairs 57 against 52 us); otherwise all T threads build one side after the other (B <= T E).
-template <int T, int E, bool TEAMS>
+__device__ inline const glove_plan &pick_plan(const glove_plan &a) { return a; }
+__device__ inline const glove_plan &pick_plan(const PlanSet &a) { return a.p[blockIdx.x]; }
+
+template <int T, int E, bool TEAMS, class Plans>
 __global__ __launch_bounds__(T) void plan_small_kernel(
     const int32_t *__restrict__ row, const int32_t *__restrict__ col, const float *__restrict__ w,
-    const float *__restrict__ y, int B, int V, int bits, PlanSet set)
+    const float *__restrict__ y, int B, int V, int bits, Plans set)
 {
-    // workgroup j indexes batch j of the stream into plan j (glove_plan_build_many; one plan: glove_plan_build)
-    const glove_plan &plan = set.p[blockIdx.x];
+    // workgroup j indexes batch j of the stream into plan j (glove_plan_build_many; one plan — the bare struct: glove_plan_build)
+    const glove_plan &plan = pick_plan(set);
     row += (size_t)blockIdx.x * B; col += (size_t)blockIdx.x * B; w += (size_t)blockIdx.x * B; y += (size_t)blockIdx.x * B;
     constexpr int TT = TEAMS ? T / 2 : T, np = TT * E, NT = TEAMS ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -370,10 +373,18 @@ static int launch_small(const int32_t *row, const int32_t *col, const float *w, 
     int bits = 1;                                                        // ids < 2^bits
     while (bits < 31 && (1u << bits) < (uint32_t)V) ++bits;
     // above the 64 KiB default of dynamic LDS: the limit is raised explicitly
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E, TEAMS>),
+    if (n == 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E, TEAMS, glove_plan>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS, glove_plan>), dim3(1), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
+                           bits, set.p[0]);
+        return (int)hipGetLastError();
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_small_kernel<T, E, TEAMS, PlanSet>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS>), dim3(n), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
+    hipLaunchKernelGGL((plan_small_kernel<T, E, TEAMS, PlanSet>), dim3(n), dim3(T), smem, st, row, col, w, y, (int)B, (int)V,
                        bits, set);
     return (int)hipGetLastError();
 }

@@ -641,8 +641,8 @@ class GloveHip:
             _require(t, dt)
             if t.numel() < n * B:
                 raise ValueError("the arrays hold fewer than %d batches of %d pairs" % (n, B))
-        if ws is None:
-            ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
+        if ws is None:      # (the tiled builder takes as many batches per set of launches as the workspace holds slices)
+            ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V) * min(n, 8))
         ptrs = (C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans])
         _check(self.lib.glove_plan_build_many(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n, V, ptrs, _ptr(ws), ws.numel(),
                                               _stream()), "glove_plan_build_many")

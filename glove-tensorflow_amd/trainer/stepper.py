@@ -704,13 +704,14 @@ class ReshufflingRunner:
         if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
         # small batches: their indexes are built a group of `ahead` at a time by one launch; the ring holds two groups
-        from trainer.hip_api import RECORDS_AT_BUILD_MAX
-        self.grouped = stepper is None and not self.streamed and B <= RECORDS_AT_BUILD_MAX and 2 <= self.ahead <= 8
-        self.group = 8 if self.ahead >= 4 else self.ahead       # what one launch takes (bs = 1,024: 4 -> 68.8 k steps/s, 8 -> 74.0 k)
+        self.grouped = stepper is None and not self.streamed and 2 <= self.ahead <= 8
+        # what one set of launches takes (bs = 1,024: 4 -> 68.8 k steps/s, 8 -> 74.0 k; big batches: four, for the memory
+        # of their staging plans)
+        self.group = (8 if B <= 65536 else 4) if self.ahead >= 4 else self.ahead
         self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows, records=records, links=False)
                      for _ in range(2 * self.group if self.grouped else self.ahead)]
-        self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
-                        for _ in range(self.ahead)]
+        self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * (self.group if self.grouped else 1), dtype=torch.uint8,
+                                    device=dev) for _ in range(2 if self.grouped else self.ahead)]
         self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
         self.window = None
@@ -753,10 +754,10 @@ class ReshufflingRunner:
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
     def _issue_grouped(self, first, count, window):
-        """Small batches (the one-workgroup index builder): the indexes of `group` consecutive batches come from ONE launch
-        (glove_plan_build_many: a workgroup per batch) — the graph's branches mostly run one after the other, so what counts is
-        the number of launches on the chain: bs = 1,024 Adagrad 22.0 -> 13.5 us per step.  The ring holds two such groups: group
-        g + 1 is built (on its side stream) while group g steps."""
+        """The indexes of `group` consecutive batches come from the launches of ONE build (glove_plan_build_many: a workgroup
+        per batch in the one-workgroup builder, grid.z = batch in the tiled one) — the graph's branches mostly run one after
+        the other, so what counts is the number of launches on the chain: bs = 1,024 Adagrad 22.0 -> 13.5 us per step.  The
+        ring holds two such groups: group g + 1 is built (on its side stream) while group g steps."""
         B, G = self.stream.B, self.group
         src = self.window if window else tuple(t[first * B:] for t in (self.stream.row, self.stream.col, self.stream.w, self.stream.y))
         main = torch.cuda.current_stream()

@@ -183,11 +183,12 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                      int64_t B, int32_t V, const glove_plan *plan,
                      void *ws, size_t ws_bytes, void *stream);
 
-/* The indexes of n consecutive batches of a stream in as few launches as they allow: plan j (plans[j], a host array of n
- * pointers) indexes pairs [j B, (j + 1) B) of row / col / w / y.  All plans have the same B, chunk_cap and kind (records or
- * not).  Batches of up to 4,096 pairs — the one-workgroup builder — go eight to a launch, a workgroup each (the per-step
- * plans of a reshuffled epoch at the reference's batch size: one launch instead of one per step); bigger ones are built one
- * after the other, exactly as n calls of glove_plan_build would.  The results are those of n calls of glove_plan_build. */
+/* The indexes of n consecutive batches of a stream in the launches of one: plan j (plans[j], a host array of n pointers)
+ * indexes pairs [j B, (j + 1) B) of row / col / w / y.  All plans have the same B, chunk_cap and kind (records or not).  Up
+ * to eight batches share every launch (a workgroup per batch in the one-workgroup builder of small batches, grid.z = batch
+ * in the tiled builder): what a reshuffled epoch pays per step for its index is a fraction of the build's launch chain.  The
+ * tiled builder (B > 4,096) needs a slice of glove_plan_workspace_bytes(B, V) per batch of a set: it takes as many batches
+ * per set as `ws_bytes` holds.  The results are those of n calls of glove_plan_build. */
 int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y,
                           int64_t B, int32_t n, int32_t V, const glove_plan *const *plans,
                           void *ws, size_t ws_bytes, void *stream);

@@ -1524,17 +1524,18 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
 
 
 @pytest.mark.parametrize("B,V,cap,n", [(300, 40, 8, 3), (1024, 10000, 16, 8), (2048, 500, 32, 4), (3000, 97, 3, 5), (4096, 12000, 16, 11),
-                                       (5000, 300, 8, 3)])
+                                       (5000, 300, 8, 3), (9000, 40000, 16, 9), (70000, 300000, 32, 4)])
 def test_many_small_plans_from_one_launch(hip, plan_checker, B, V, cap, n):
-    """glove_plan_build_many: the indexes of n consecutive batches of a stream — a workgroup per batch, eight batches per
-    launch while they fit the one-workgroup builder, one after the other beyond — are the indexes n calls of
-    glove_plan_build give, array for array and record for record, into poisoned plans."""
+    """glove_plan_build_many: the indexes of n consecutive batches of a stream from the launches of one — a workgroup per
+    batch in the one-workgroup builder, grid.z = batch in the tiled one, as many batches per set as the workspace has slices —
+    are the indexes n calls of glove_plan_build give, array for array and record for record, into poisoned plans."""
     from trainer.hip_api import Plan
     batches = [make_batch(900 + 7 * j, B, V, zipf=(j % 2 == 0)) for j in range(n)]
     batches[1][0][::5] = V + 3                                  # ids outside the vocabulary in one of them
     row, col, w, y = (torch.from_numpy(np.concatenate([b[k] for b in batches])).cuda() for k in range(4))
     plans = [Plan(B, V, cap, "cuda:0", records=True, links=(j % 2 == 0)) for j in range(n)]
-    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
+    # (9 batches through a workspace of 4 slices: sets of 4, 4 and 1)
+    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * min(n, 4), dtype=torch.uint8, device="cuda:0")
     errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     for p_ in plans:
         _poison(p_, ws)

@@ -23,7 +23,9 @@ backend = HipBackend("cuda:0")
 hip = GloveHip("cuda:0")
 hyper = make_hyper(learning_rate=0.05 if opt == "Adagrad" else 0.001, batch_size=B)
 steps = max(200, min(20000, 40_000_000 // B))
-for name, kw in (("graphs", dict(graphs=True, streamed=False)), ("streamed C loop", dict(streamed=True)), ("eager", dict(graphs=False, streamed=False))):
+modes = (("graphs", dict(graphs=True, streamed=False)), ("streamed C loop", dict(streamed=True)), ("eager", dict(graphs=False, streamed=False)))
+only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
+for name, kw in [m for m in modes if only is None or m[0].split()[0] in only]:
     stream = NonzeroStream(coo, B, V, backend, "cuda:0", seed=11, static_plans=False)
     tables = DeviceTables(V, d, opt, seed=4)
     runner = ReshufflingRunner(hip, stream, tables, hyper, ahead=ahead, burst=64, **kw)
