@@ -704,7 +704,7 @@ class ReshufflingRunner:
         if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
         # small batches: their indexes are built a group of `ahead` at a time by one launch; the ring holds two groups
-        self.grouped = stepper is None and not self.streamed and 2 <= self.ahead <= 8
+        self.grouped = not self.streamed and 2 <= self.ahead <= 8           # (also under a data-parallel / row-sharded stepper)
         # what one set of launches takes (bs = 1,024: 4 -> 68.8 k steps/s, 8 -> 74.0 k; big batches: four, for the memory
         # of their staging plans)
         self.group = (8 if B <= 65536 else 4) if self.ahead >= 4 else self.ahead
