@@ -620,7 +620,9 @@ struct RecordArgs {
     const int32_t *chunk_id[2], *chunk_start[2], *partner[2];
     const float *w[2], *y[2];
     int32_t *crec[2];
-    const int2 *chunk_aux[2];     // side_emit's {id position, chunks-behind word} per chunk, or nullptr: bisect uniq_slot
+    const int2 *chunk_aux[2];     // side_emit's {id position, chunks-behind word} per chunk, or nullptr
+    int header_in_record;         // no chunk_aux: 1 = the builder left words 2, 3 of every header in the record itself
+                                  // (the one-workgroup builder), 0 = bisect uniq_slot (records of a finished plan)
 };
 struct RecordOne { RecordArgs a; const int32_t *counts; };
 struct RecordSet { RecordOne b[kPlanSetMax]; };            // blockIdx.z: which plan of the set
@@ -657,6 +659,8 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
         cid = chunk_id[j0 + lane];
         if (aux) {
             ax = aux[j0 + lane];
+        } else if (a.header_in_record) {
+            ax = *reinterpret_cast<const int2 *>(a.crec[side] + (size_t)(j0 + lane) * sq * 4 + 2);
         } else {
             // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
             // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
@@ -706,23 +710,23 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
     }
 }
 
-static RecordArgs record_args(const glove_plan *plan, const int2 *aux_r, const int2 *aux_c)
+static RecordArgs record_args(const glove_plan *plan, const int2 *aux_r, const int2 *aux_c, bool header_in_record)
 {
     return RecordArgs{{plan->r_uniq_slot, plan->c_uniq_slot}, {plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                       {plan->r_partner, plan->c_partner}, {plan->r_w, plan->c_w}, {plan->r_y, plan->c_y},
-                      {plan->r_crec, plan->c_crec}, {aux_r, aux_c}};
+                      {plan->r_crec, plan->c_crec}, {aux_r, aux_c}, header_in_record ? 1 : 0};
 }
 
 // records of n plans of the same shape (same B, chunk_cap, capacities) in one launch
 static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStream_t st, const int2 *const *aux_r = nullptr,
-                                   const int2 *const *aux_c = nullptr)
+                                   const int2 *const *aux_c = nullptr, bool header_in_record = false)
 {
     const glove_plan *plan = plans[0];
     const int capP = rec_cap(plan->chunk_cap);        // glove_common.h: a trip of the pass kernel reads up to kRecPad slots from q0
     RecordSet set = {};
     int64_t most = 1;
     for (int j = 0; j < n; ++j) {
-        set.b[j].a = record_args(plans[j], aux_r ? aux_r[j] : nullptr, aux_c ? aux_c[j] : nullptr);
+        set.b[j].a = record_args(plans[j], aux_r ? aux_r[j] : nullptr, aux_c ? aux_c[j] : nullptr, header_in_record);
         set.b[j].counts = plans[j]->counts;
         const int64_t nr = most_chunks(plans[j], true), nc = most_chunks(plans[j], false);
         most = nr > most ? nr : most;
@@ -737,9 +741,9 @@ static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStr
     return (int)hipGetLastError();
 }
 
-static int launch_fill_records(const glove_plan *plan, hipStream_t st)
+static int launch_fill_records(const glove_plan *plan, hipStream_t st, bool header_in_record = false)
 {
-    return launch_fill_records_set(&plan, 1, st);
+    return launch_fill_records_set(&plan, 1, st, nullptr, nullptr, header_in_record);
 }
 
 struct PlanWs {
@@ -951,7 +955,7 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
         PlanSet set;
         set.p[0] = *plan;
         if (int rc = plan_build_small(row, col, w, y, B, V, set, 1, st)) return rc;
-        return plan->r_crec ? launch_fill_records(plan, st) : 0;
+        return plan->r_crec ? launch_fill_records(plan, st, true) : 0;
     }
     return build_tiled_set(row, col, w, y, B, V, &plan, 1, ws, ws_bytes, st);
 }
@@ -998,7 +1002,7 @@ int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w
         const size_t off = (size_t)j0 * B;
         if (int rc = plan_build_small(row + off, col + off, w + off, y + off, B, V, set, m, st)) return rc;
         if (plans[0]->r_crec)
-            if (int rc = launch_fill_records_set(plans + j0, m, st)) return rc;
+            if (int rc = launch_fill_records_set(plans + j0, m, st, nullptr, nullptr, true)) return rc;
     }
     return 0;
 }
