@@ -78,3 +78,13 @@ def assert_tables_close(dt, t, rtol=1e-5, atol=1e-6):
             assert float(getattr(dt, n)[:, dm:].abs().max()) == 0.0, n + " padding moved"
     np.testing.assert_allclose(dt.scalars[0].item(), t.g, rtol=rtol, atol=atol, err_msg="global_bias")
     assert dt.global_step == t.step
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (for a torch.distributed rendezvous on 127.0.0.1): fixed numbers derived from the
+    pid fell into the ephemeral range and collided, once in a while, with a connection of an earlier test."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+

@@ -14,6 +14,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent / "oracle"))
+from helpers import free_port  # noqa: E402
+
 WORLD = 2
 B, V, D, STEPS = 96, 40, 8, 5
 
@@ -53,7 +57,7 @@ def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer, exchan
     """Dense all-reduce and touched-rows all-gather: either way two ranks == one rank on the joint batch."""
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 29500 + os.getpid() % 2000 + ["dense", "rows", "auto"].index(exchange) * 2 + (0 if optimizer == "Adagrad" else 1)
+    port = free_port()
     mp.spawn(_worker, args=(port, optimizer, str(tmp_path), exchange), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, optimizer, dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
@@ -106,7 +110,7 @@ def _sharded_worker(rank, port, out_dir, exchange="dense"):
 def test_row_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path, exchange):
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 31500 + os.getpid() % 2000 + (exchange == "rows")
+    port = free_port()
     mp.spawn(_sharded_worker, args=(port, str(tmp_path), exchange), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
@@ -170,7 +174,7 @@ def _fully_sharded_worker(rank, port, out_dir):
 def test_fully_sharded_step_equals_single_rank_on_the_joint_batch(tmp_path):
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_fully_sharded_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
     hp = ref.Hyper(learning_rate=0.05)
@@ -208,7 +212,7 @@ def _stream_worker(rank, port, out_dir, routed):
 def test_every_nonzero_lands_on_exactly_one_rank(tmp_path, routed):
     """Data-parallel shards (a contiguous slice of one permutation each, the remainder spread over the first ranks) and
     row-owner routing (nothing truncated to the lightest rank's count): the ranks' streams partition the file."""
-    port = 35500 + os.getpid() % 2000 + int(routed)
+    port = free_port()
     mp.spawn(_stream_worker, args=(port, str(tmp_path), routed), nprocs=WORLD, join=True)
     parts = [np.load(tmp_path / ("stream%d.npz" % r)) for r in range(WORLD)]
     w = np.sort(np.concatenate([p["w"] for p in parts]))       # the weights are the nonzeros' serial numbers
@@ -289,7 +293,7 @@ def test_reshuffled_epochs_on_two_ranks_equal_one_rank_on_the_joint_stream(tmp_p
     and the batches of two epochs differ."""
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
-    port = 37500 + os.getpid() % 2000 + ["dp_dense", "dp_rows", "rowsharded"].index(form)
+    port = free_port()
     mp.spawn(_reshuffle_worker, args=(port, str(tmp_path), form), nprocs=WORLD, join=True)
     ranks = [np.load(tmp_path / ("re%d.npz" % r)) for r in range(WORLD)]
     t = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
@@ -324,7 +328,7 @@ def test_reshuffled_epochs_with_both_tables_sharded(tmp_path):
     """ShardedStepper under the reshuffling runner: the epoch's batches (fetch lists, renumbered col ids) are prepared
     collectively when the epoch starts.  The model after 24 steps over four epoch boundaries is finite, every rank made
     the same number of steps, and re-running gives the same bits (the permutations are seeded)."""
-    port = 39500 + os.getpid() % 2000
+    port = free_port()
     outs = []
     for attempt in range(2):
         d = tmp_path / ("run%d" % attempt)

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import glove_ref as ref
+from helpers import free_port
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -298,7 +299,7 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
             "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
             "--train-steps", "60", "--log-every", "10"]                # unseeded: rank 0 draws the seed for both
-    mp.spawn(_two_rank_trainer, args=(29700 + os.getpid() % 200, argv, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(tmp_path)), nprocs=2, join=True)
     a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(a[n], b[n]), n
@@ -325,7 +326,7 @@ def test_two_rank_trainer_with_touched_rows_exchange_on_one_gpu(hip, tmp_path):
         argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(out / "job"), "--disable-datetime-path",
                 "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
                 "--train-steps", "40", "--log-every", "20", "--seed", "5", "--exchange", exchange, "--skip-eval"]
-        mp.spawn(_two_rank_trainer, args=(29950 + os.getpid() % 200 + k, argv, str(out)), nprocs=2, join=True)
+        mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(out)), nprocs=2, join=True)
         res[exchange] = [torch.load(out / ("rank%d.pt" % r)) for r in range(2)]
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(res["rows"][0][n], res["rows"][1][n]), n            # replicas identical
@@ -564,7 +565,7 @@ def test_two_rank_row_sharded_trainer_on_one_gpu(hip, tmp_path):
     argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
             "--embedding-size", "24", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "48",
             "--train-steps", "60", "--log-every", "20", "--seed", "9", "--row-sharded"]
-    mp.spawn(_two_rank_trainer, args=(29900 + os.getpid() % 90, argv, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(tmp_path)), nprocs=2, join=True)
     a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
     V = len(vocab.read_text().split("\n"))
     assert a["R"].shape[0] + b["R"].shape[0] == V and a["R"].shape[0] == (V + 1) // 2      # disjoint row shards
