@@ -158,10 +158,10 @@ class NonzeroStream:
 
     def reshuffle_in_place(self):
         """A fresh permutation of this rank's pairs becomes the stream (`row`, `col`, `w`, `y`).  The permutation of the NEXT
-        epoch is drawn and applied on a side stream, into a second set of buffers, while the current epoch trains (on a
-        device it costs a sort of nnz random keys and four gathers: at 131,072-pair batches of a 1.2 M-pair stream a
-        quarter of the epoch's time when it sat between two epochs); an epoch boundary then is a wait on an event that has
-        usually fired, and a swap of the two sets.  The sequence of permutations is the same as drawing them one by one."""
+        epoch is drawn and applied on a side stream, into a second set of buffers, while the current epoch trains (as a
+        device randperm plus four gathers it cost a quarter of the epoch's time at 131,072-pair batches of a 1.2 M-pair
+        stream when it sat between two epochs; on the HIP backend it is one gather launch under a keyed bijection); an epoch boundary then is a wait on an event that has
+        usually fired, and a swap of the two sets."""
         if self.device.type != "cuda":
             if self._dev_gen is None:
                 self._dev_gen = torch.Generator(device=self.device)
@@ -187,10 +187,17 @@ class NonzeroStream:
 
     def _permute_into_spare(self, main):
         self._side.wait_stream(main)                       # the spare set's last readers (the epoch before) are on `main`
+        hip = getattr(self.backend, "hip", None)
         with torch.cuda.stream(self._side):
-            p = torch.randperm(self.nnz, generator=self._dev_gen, device=self.device)
-            for dst, src in zip(self._spare, (self.row, self.col, self.w, self.y)):
-                torch.index_select(src, 0, p, out=dst)
+            if hip is not None:
+                # one gather launch under a keyed bijection of the positions (glove_shuffle_stream: no sort of nnz random
+                # keys, no index array); the key comes from the stream's seeded host generator
+                key = int.from_bytes(torch.randint(0, 256, (16,), generator=self.gen, dtype=torch.uint8).numpy().tobytes(), "little")
+                hip.shuffle_stream((self.row, self.col, self.w, self.y), self._spare, key)
+            else:
+                p = torch.randperm(self.nnz, generator=self._dev_gen, device=self.device)
+                for dst, src in zip(self._spare, (self.row, self.col, self.w, self.y)):
+                    torch.index_select(src, 0, p, out=dst)
             self._ready = torch.cuda.Event()
             self._ready.record(self._side)
 

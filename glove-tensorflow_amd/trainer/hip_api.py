@@ -42,7 +42,7 @@ def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
 
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
-    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_build_many", "glove_plan_fill_records", "glove_step_workspace_bytes",
+    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_build_many", "glove_plan_fill_records", "glove_shuffle_stream", "glove_step_workspace_bytes",
     "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
@@ -118,6 +118,7 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_plan_workspace_bytes": (sz, [i64, i32]),
         "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
         "glove_plan_build_many": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(P(GlovePlan)), vp, sz, vp]),
+        "glove_shuffle_stream": (C.c_int, [vp, vp, vp, vp, i64, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
         "glove_plan_fill_records": (C.c_int, [P(GlovePlan), vp]),
         "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
         "glove_passes_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
@@ -646,6 +647,14 @@ class GloveHip:
         ptrs = (C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans])
         _check(self.lib.glove_plan_build_many(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n, V, ptrs, _ptr(ws), ws.numel(),
                                               _stream()), "glove_plan_build_many")
+
+    def shuffle_stream(self, src, dst, key: int) -> None:
+        """dst = the four arrays of `src` (row, col, w, y) under the bijection of positions the 128-bit `key` determines."""
+        n = src[0].numel()
+        for t, dt in zip(tuple(src) + tuple(dst), (torch.int32, torch.int32, torch.float32, torch.float32) * 2):
+            _require(t, dt, n)
+        _check(self.lib.glove_shuffle_stream(*(_ptr(t) for t in src), n, key & (2 ** 64 - 1), (key >> 64) & (2 ** 64 - 1),
+                                             *(_ptr(t) for t in dst), _stream()), "glove_shuffle_stream")
 
     # ---- passes
     def passes(self, plan, tables, hyper, ws=None):

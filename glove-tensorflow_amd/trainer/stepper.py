@@ -651,10 +651,9 @@ class ReshufflingRunner:
 
     def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True, streamed=None):
         """`streamed` (one GPU): the loop of builds and steps runs in C on real streams (glove_steps_rebuilt_f32) instead of
-        being replayed from hipGraphs.  None = by batch size: small batches are bound by the host's launch calls on real
-        streams (B = 1,024: 32 k steps/s against 45 k from replayed graphs; 16,384: 21 k against 29 k), big ones gain from
-        builds that really run beside the steps (the branches of a replayed graph mostly run one after the other:
-        131,072: 13.4 k against 11.5 k steps/s; tools/exp_runner_modes.py)."""
+        being replayed from hipGraphs.  Not the default at any batch size (tools/exp_runner_modes.py, Adagrad, text8 scale):
+        B = 1,024: 28 k steps/s against 72 k from the replayed bursts with grouped index builds; 16,384: 21 k against 43 k;
+        131,072: 13.7 k against 17.4 k; V = 400 k, d = 300 at B = 1 M: 1,063 against 1,064."""
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
@@ -662,7 +661,7 @@ class ReshufflingRunner:
         self.graphs_on = bool(graphs) and hip is not None and (
             stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
         if streamed is None:
-            streamed = bool(graphs) and stream.B >= 65536
+            streamed = False
         self.streamed = bool(streamed) and stepper is None and hip is not None
         if self.streamed:
             self.graphs_on = False

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -192,6 +192,13 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
 int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y,
                           int64_t B, int32_t n, int32_t V, const glove_plan *const *plans,
                           void *ws, size_t ws_bytes, void *stream);
+
+/* The epoch's reshuffle of a resident nonzero stream (the reference's input_fn reshuffles every epoch: data_utils.py:12-21):
+ * out[i] = in[pi(i)] for a bijection pi of [0, n) determined by the 128-bit key (a Feistel network with cycle walking: no
+ * sort, no index array) — one gather launch.  Out of place: the four outputs are other buffers than the inputs. */
+int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n,
+                         uint64_t key_lo, uint64_t key_hi,
+                         int32_t *row_out, int32_t *col_out, float *w_out, float *y_out, void *stream);
 
 /* (Re)builds r_crec / c_crec of a plan whose other arrays are complete (both must be non-NULL). */
 int glove_plan_fill_records(const glove_plan *plan, void *stream);

@@ -1546,3 +1546,30 @@ def test_many_small_plans_from_one_launch(hip, plan_checker, B, V, cap, n):
         single = hip.build_plan(*to_dev(*batches[j]), V, chunk_cap=cap, records=True)
         assert torch.equal(p_.counts, single.counts)
     assert errors.tolist() == [0] * 8, errors.tolist()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 65536, 1_190_011])
+def test_stream_shuffle_is_a_keyed_bijection(hip, n):
+    """glove_shuffle_stream: the four arrays come out under ONE bijection of the positions (every pair stays a pair, nothing is
+    lost or doubled), determined by the key: the same key gives the same order, another key another one, and positions really
+    move (the reference reshuffles its input every epoch: data_utils.py:12-21)."""
+    g = torch.Generator(device="cpu").manual_seed(n)
+    row = torch.arange(n, dtype=torch.int32, device="cuda:0")                  # row = the position itself: reads the bijection off
+    col = torch.randint(0, 1000, (n,), generator=g, dtype=torch.int32).cuda()
+    w, y = torch.rand(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    outs = []
+    for key in (0x0123456789abcdef0011223344556677, 0x0123456789abcdef0011223344556677, 5):
+        dst = tuple(torch.full_like(t, -1) for t in (row, col, w, y))
+        hip.shuffle_stream((row, col, w, y), dst, key)
+        pi = dst[0].long()
+        assert torch.equal(torch.sort(pi).values, torch.arange(n, device="cuda:0"))               # a bijection
+        assert torch.equal(dst[1], col[pi]) and torch.equal(dst[2], w[pi]) and torch.equal(dst[3], y[pi])  # pairs stay pairs
+        outs.append(pi)
+    assert torch.equal(outs[0], outs[1])
+    if n >= 1000:
+        assert not torch.equal(outs[0], outs[2])
+        moved = (outs[0] != torch.arange(n, device="cuda:0")).float().mean().item()
+        assert moved > 0.99                                                                        # (a random permutation fixes ~1 position)
+        # neighbours part: the mean distance of the images of adjacent positions is about n / 3 for a random permutation
+        gap = (outs[0][1:] - outs[0][:-1]).abs().float().mean().item()
+        assert 0.25 * n < gap < 0.42 * n, gap

@@ -16,13 +16,20 @@ from trainer.stepper import HipBackend, ReshufflingRunner  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 opt = sys.argv[2] if len(sys.argv) > 2 else "Adagrad"
 ahead = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-V, d = 10000, 64
-row, col, w, y = synthetic.text8_shaped(V=V, seed=0)
-coo = dict(row=row.numpy(), col=col.numpy(), w=w.numpy(), y=y.numpy())
+wl_name = sys.argv[5] if len(sys.argv) > 5 else ""
+if wl_name:                                  # a bench workload (e.g. zipf_v400k_d300: the C4 shard)
+    wl = synthetic.make_workload(wl_name, device="cuda:0", work_device="cuda:0")
+    V, d = wl["V"], wl["d"]
+    coo = {k: wl[k].cpu().numpy() for k in ("row", "col", "w", "y")}
+    del wl
+else:
+    V, d = 10000, 64
+    row, col, w, y = synthetic.text8_shaped(V=V, seed=0)
+    coo = dict(row=row.numpy(), col=col.numpy(), w=w.numpy(), y=y.numpy())
 backend = HipBackend("cuda:0")
 hip = GloveHip("cuda:0")
 hyper = make_hyper(learning_rate=0.05 if opt == "Adagrad" else 0.001, batch_size=B)
-steps = max(200, min(20000, 40_000_000 // B))
+steps = max(200, min(20000, 40_000_000 // B)) if not wl_name else 96
 modes = (("graphs", dict(graphs=True, streamed=False)), ("streamed C loop", dict(streamed=True)), ("eager", dict(graphs=False, streamed=False)))
 only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
 for name, kw in [m for m in modes if only is None or m[0].split()[0] in only]:
