@@ -3,9 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload text8_d64] [--batch-size B]
 
-A "step" is one optimizer step over one batch of B synthetic co-occurrence nonzeros that are already resident in HBM
-together with their dedup index (DESIGN.md "Data layout"; the index of a static stream is built once at load time,
-`--dynamic` puts the index build of every batch inside the timed region instead).
+A "step" is one optimizer step over one batch of B synthetic co-occurrence nonzeros that are already resident in HBM.
+On one GPU the stream is stepped the way the trainer steps it by default (`--epoch-shuffle full`, what the reference's
+make_csv_dataset(shuffle=True, num_epochs=None) does): every epoch is dealt anew from the sorted master orders and the
+dedup index of every batch is numbered inside the timed region (trainer.stepper.ReshufflingRunner: epoch deals and index
+builds on a side stream, steps replayed from hipGraphs).  `--static-index` times the other product mode instead
+(`--epoch-shuffle static`: one permutation, the index of every batch built once at load, outside the clock).
 
 N = 1: the sparse Adagrad step (fused forward+gradient pass kernel(s) + apply kernel; glove_step_adagrad_f32 picks the
 form).  The headline is the workload BASELINE.json's metric is quoted on at 1, 2, 4 and 8 GPUs — config 4, synthetic
@@ -13,7 +16,8 @@ Zipf V = 400 k, d = 300 — as the one-GPU shard of its 200 M nonzeros (25 M, ba
 "achieved HBM GB/s vs peak" is about HBM (text8's tables live in the caches).  Unless `--single` is given the same JSON
 line also carries `configs`: text8 d = 64 (BASELINE configs[1]: static index, index rebuilt every step, the
 reference's batch size, Keras-legacy Adam), V = 50 k at d = 300 and V = 2 M at d = 128, each with its own roofline —
-as far as the wall-clock budget (`--budget-seconds`) goes; what did not fit is named in `configs_skipped`.
+as far as the wall-clock budget (`--budget-seconds`) goes; what did not fit is named in `configs_skipped`.  `roofline.frac`
+of every entry = algorithmic bytes per step / ms_per_step / 8 TB/s (the whole step as timed, index work included).
 
 N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child process; under a launcher it
 is a rank).  Every rank owns its own shard of nonzeros (global batch = N * B, weak scaling).  The headline is config 4
@@ -82,10 +86,11 @@ def parse(argv=None):
     ap.add_argument("--collectives", action="store_true",
                     help="with --row-sharded / --force-dense on one GPU: issue every collective through RCCL although there is one rank")
     ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table")
-    ap.add_argument("--dynamic", action="store_true", help="rebuild the dedup index of every batch inside the timed region")
-    ap.add_argument("--build-ahead", type=int, default=1,
-                    help="with --dynamic: index builds in flight (each on its own stream and staging plan), the way an "
-                         "input pipeline prefetches batches; 1 = build and step strictly alternate on one stream")
+    ap.add_argument("--static-index", action="store_true",
+                    help="one GPU: the trainer's --epoch-shuffle static (the index of every resident batch built at load, "
+                         "outside the clock) instead of its default, epochs dealt and indexed inside the timed region")
+    ap.add_argument("--index-segment", type=int, default=0,
+                    help="dealt epochs: consecutive batches whose index one set of launches builds (0 = the runner's choice)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of all CPU legs together")
@@ -147,7 +152,7 @@ def algorithmic_bytes(B, d, u_row, u_col):
     return 16 * B + 16 * (d + 1) * (u_row + u_col)
 
 
-def measured_traffic(workload, B, cap, fused):
+def measured_traffic(workload, B, cap, fused, index="static"):
     """HBM-side bytes per step from the committed PMC summary of this exact configuration
     (profiles/*_traffic.json, produced by tools/pmc_traffic.py from separate `rocprofv3 --pmc`
     passes of this bench); None when no summary matches.  `fused`: the step ran in a fused form — a summary counts
@@ -159,7 +164,7 @@ def measured_traffic(workload, B, cap, fused):
             m = j.get("meta", {})
             prof_fused = any(k.startswith("sidepass_kernel") and k.rstrip().endswith(("true>", ", 1>", ", 2>")) for k in j.get("kernels", {}))
             if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap \
-                    and prof_fused == bool(fused):
+                    and prof_fused == bool(fused) and m.get("index", "static") == index:
                 return float(j["traffic_bytes_per_step"]), os.path.basename(f)
         except (OSError, ValueError, KeyError):
             continue
@@ -278,9 +283,167 @@ def steps_per_graph(steps: int) -> int:
     return 1
 
 
+def timed_region(ctx, run, steps, warmup, min_timed_ms):
+    """The contract's timed region around run(n_steps): warm-up, then exactly `steps` steps between barrier + synchronize on
+    both sides, MAX over ranks; repeated at least three times and until at least min_timed_ms have been measured (a single
+    transient cannot swing the figure), median reported.  Returns (median seconds, all)."""
+    dev, world, dist = ctx.dev, ctx.world, ctx.dist
+    torch.cuda.synchronize()
+    log("  warm-up steps")
+    run(warmup)
+    # the first tens of milliseconds after the load phase run slow whatever the kernels are (B = 1 M at text8 scale:
+    # 158 us/step in a first region of 200 steps, 47 in every later one; a graph's first replay also carries its
+    # upload): the warm-up goes on, untimed, until the loop has run for 50 ms
+    ctx.barrier()
+    t_warm = time.perf_counter()
+    while True:
+        run(steps)
+        ctx.barrier()
+        warm = torch.tensor([time.perf_counter() - t_warm], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)     # every rank takes the same number of rounds
+        if float(warm.item()) >= 0.05:
+            break
+    log("  timed region")
+    elapsed_all, total = [], 0.0
+    while True:
+        ctx.barrier()
+        t0 = time.perf_counter()
+        run(steps)
+        ctx.barrier()
+        el = time.perf_counter() - t0
+        stop = torch.tensor([el, 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            el = float(stop[0].item())
+        elapsed_all.append(el)
+        total += el
+        if (total * 1e3 >= min_timed_ms and len(elapsed_all) >= 3) or len(elapsed_all) >= 50:   # every rank sees the same MAX: same decision
+            break
+    return statistics.median(elapsed_all), elapsed_all
+
+
+def event_us(fn, reps=3, stream=None):
+    """Median GPU time of fn() in microseconds, HIP events on the stream the work is launched on."""
+    st = stream or torch.cuda.current_stream()
+    spans = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            a.record(st)
+            fn()
+            b.record(st)
+        torch.cuda.synchronize()
+        spans.append(a.elapsed_time(b) * 1e3)
+    return sorted(spans)[len(spans) // 2]
+
+
+def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.05, chunk_cap=0, step_form=0,
+              no_graph=False, min_timed_ms=20.0, segment=0):
+    """One GPU, the trainer's default mode (--epoch-shuffle full): the stream object and the runner are the trainer's own
+    (trainer.data_utils.NonzeroStream, trainer.stepper.ReshufflingRunner), timed from outside — epoch deals, index builds
+    and steps all inside the timed region."""
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ReshufflingRunner
+    hip, dev = ctx.hip, ctx.dev
+    adam = optimizer == "Adam"
+    log("%s B=%d %s, epochs dealt and indexed inside the timed region: generating the workload" % (workload, B, optimizer))
+    wl = ctx.workload(workload)
+    V, d = wl["V"], wl["d"]
+    nnz = wl["row"].numel()
+    if nnz < B:
+        raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))
+    backend = HipBackend(dev)
+    backend.hip = hip
+    tables = DeviceTables(V, d, optimizer, device=dev, seed=1)
+    backend.row_floats = tables.d
+    if step_form == 4:
+        tables.enable_twin()
+    t0 = time.perf_counter()
+    stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False)
+    torch.cuda.synchronize()
+    masters_ms = (time.perf_counter() - t0) * 1e3
+    hyper = make_hyper(batch_size=B, learning_rate=lr, step_form=step_form)
+    runner = ReshufflingRunner(hip, stream, tables, hyper, chunk_cap=chunk_cap, burst=64, graphs=not no_graph, segment=segment)
+    cap, S, nb = runner.cap, runner.S, runner.nb
+    log("  masters in %.1f ms (once, at load); %d batches per epoch, index built %d batches at a time, chunk records: %s" % (
+        masters_ms, nb, S, runner.records))
+
+    def run(n_steps):
+        done = 0
+        while done < n_steps:
+            done += runner.run(n_steps - done)
+    elapsed, elapsed_all = timed_region(ctx, run, steps, warmup, min_timed_ms)
+    final_loss = float(runner.loss_out[0].item())
+    log("  %.4f ms per step (%d repeats); per-kernel pass" % (elapsed / steps * 1e3, len(elapsed_all)))
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+    # ---- what the batches touched (the staging plans of both slots, as the last builds left them)
+    torch.cuda.synchronize()
+    plans = [p for blk in runner.slots for p in blk.plans]
+    counts = torch.stack([p.counts for p in plans]).double()
+    counts = counts[counts[:, 0] > 0].mean(0).tolist()          # (a slot's tail plans are never built when the epoch's last segment is short)
+    chunks, u_row, u_col, n_heavy = counts[0] + counts[2], counts[1], counts[3], counts[4]
+    # ---- the pieces apart, each on its own with HIP events on its launch stream (the timed region overlaps them)
+    n0 = min(S, nb)
+    slot = runner.slots[0]
+
+    def steps_once():
+        for j in range(n0):
+            runner._step(slot.plans[j])
+    steps_once()
+    torch.cuda.synchronize()
+    kg = torch.cuda.CUDAGraph()               # replayed, so that kernels shorter than a host call are timed on the GPU's clock
+    with torch.cuda.graph(kg):
+        steps_once()
+    kern = {"step": event_us(kg.replay) / n0}
+    rs, cs = stream.epoch_sides()
+    kern["index_build"] = event_us(lambda: hip.build_plans_sorted(rs, cs, 0, slot, n0, V, runner.sorted_ws), stream=stream.side) / n0
+    spare = stream._sets[(stream.epoch + 1) % 2]
+    kern["epoch_deal"] = event_us(lambda: hip.deal_epoch(stream.masters, B, 12345, spare[0], spare[1], stream._deal_ws),
+                                  stream=stream.side) / nb
+    alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
+    achieved = alg / (elapsed / steps) / 1e9
+    fused = runner.records and getattr(tables, "_twin_dirty", False)
+    traffic, traffic_src = measured_traffic(workload, B, cap, fused, "dealt") if not adam else (None, None)
+    out = {
+        "metric": "co-occurrence nonzeros/sec", "value": steps * B / elapsed, "unit": "nonzeros/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "repeats": len(elapsed_all), "ms_per_step_min_max": [min(elapsed_all) / steps * 1e3, max(elapsed_all) / steps * 1e3],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": DATA_NOTE.get(workload, "synthetic"),
+        "config": {"workload": workload, "V": V, "d": d, "optimizer": optimizer,
+                   "batch_size_per_gpu": B, "global_batch": B, "nnz_per_gpu": nnz, "batches_per_epoch": nb, "chunk_cap": cap,
+                   "index": "rebuilt every step: epochs dealt from the sorted master orders (one partition pass per epoch), the "
+                            "index of %d consecutive batches numbered by 3 launches on a side stream, inside the timed region" % S,
+                   "launch": "the trainer's runner: steps replayed from hipGraphs of 2^k steps" if runner.graphs_on else
+                             "the trainer's runner: eager launches",
+                   "parallelism": "single GPU", "chunk_records": bool(runner.records)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
+                     "stream_ceiling": HBM_STREAM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+                     "kernel": "one step as timed = step kernels, beside them on a side stream index_build and epoch_deal",
+                     "algorithmic_bytes_per_step": alg, "kernel_us": kern,
+                     "kernel_us_note": "per step, each piece alone on an idle GPU (HIP events on its launch stream); in the timed "
+                                       "region index_build and epoch_deal overlap the steps",
+                     "step_kernels_alone_frac": alg / (kern["step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
+        "masters_build_ms_at_load": masters_ms, "final_loss": final_loss,
+    }
+    runner.release_graphs()
+    del kg, runner, stream, tables, plans
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    log("  done: %.3g nonzeros/s, %.4f ms per step, roofline %.3f (step kernels alone %.1f us, index %.1f us, deal %.1f us per step)" % (
+        out["value"], out["ms_per_step"], out["roofline"]["frac"], kern["step"], kern["index_build"], kern["epoch_deal"]))
+    return out
+
+
 def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, warmup=20, lr=0.05, chunk_cap=0,
-               step_form=0, exchange="auto", dynamic=False, build_ahead=1, no_graph=False, max_batches=64,
-               min_timed_ms=20.0):
+               step_form=0, exchange="auto", dynamic=False, no_graph=False, max_batches=64,
+               min_timed_ms=20.0, segment=0):
     """mode: "auto" (single-GPU sparse step on one rank, data parallel on several), "dp" (data-parallel form also on
     one rank), "sharded" (both tables sharded), "rowsharded" (row table sharded, col side data parallel)."""
     from trainer.hip_api import FUSED_STEP_BYTES, DeviceTables, auto_chunk_cap, make_hyper
@@ -291,7 +454,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         mode = "dp" if world > 1 else "single"
     if adam and mode != "single":
         raise SystemExit("--optimizer Adam is benchmarked on one GPU")
-    log("%s B=%d %s mode=%s%s: generating the workload" % (workload, B, optimizer, mode, " dynamic" if dynamic else ""))
+    if dynamic and mode == "single":
+        return run_dealt(ctx, workload, B, optimizer, steps, warmup, lr, chunk_cap, step_form, no_graph, min_timed_ms, segment)
+    log("%s B=%d %s mode=%s: generating the workload" % (workload, B, optimizer, mode))
     wl = ctx.workload(workload)
     V, d = wl["V"], wl["d"]
     coo = {k: wl[k] for k in ("row", "col", "w", "y")}
@@ -358,87 +523,13 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     ws = None
     G = hip.dense_grad_buffer(tables) if adam else None
     if mode == "single":
-        ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, tables.d) for p in plans) if not dynamic
-                         else hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
-
-    # refilled every step; on big tables with chunk records, so that the rebuilt index is stepped in the fused form too
-    from trainer.hip_api import staging_records
-    rec_kw = dict(links=False, records=staging_records(B, tables.V_row, V, tables.d) if mode == "single" and not adam and
-                  (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES else None)     # (as the trainer's runner decides: from a first batch)
-    staging = hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) if dynamic else None
-    ahead = max(1, build_ahead) if dynamic else 1
-    if ahead > 1:
-        # a ring of staging plans, scratch buffers and streams: the index of batch i is built on stream i % ahead
-        # while earlier steps run; it may start once step i - ahead, the previous reader of its staging plan, is done
-        ring = [staging] + [hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) for _ in range(ahead - 1)]
-        ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device=dev) for _ in range(ahead)]
-        ring_streams = [torch.cuda.Stream() for _ in range(ahead)]
-
-    # the indexes of a group of steps come from the launches of ONE build (glove_plan_build_many), as the trainer's
-    # reshuffling runner builds them; two groups of staging plans
-    grouped = dynamic and 2 <= ahead <= 8 and nb >= ahead and B < 65536     # (C4, B = 1 M: 847 us grouped against 783)
-    if grouped:
-        ring = ring + [hip.build_plan(*batches[0], V, chunk_cap=cap, **rec_kw) for _ in range(ahead)]
-        ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * ahead, dtype=torch.uint8, device=dev) for _ in range(2)]
-        whole = tuple(coo[k][:(nb // ahead) * ahead * B].contiguous() for k in ("row", "col", "w", "y"))
-
-    def sweep_grouped(n_steps):
-        main, G = torch.cuda.current_stream(), ahead
-        n_groups = (n_steps + G - 1) // G
-        built, stepped = [None] * n_groups, [None] * n_groups
-        start = torch.cuda.Event()
-        start.record(main)
-
-        def launch_build(g):
-            st = ring_streams[g % 2]
-            st.wait_event(stepped[g - 2] if g >= 2 else start)
-            n, b0 = min(G, n_steps - g * G), (g % (nb // G)) * G
-            with torch.cuda.stream(st):
-                hip.build_plans(*(t[b0 * B:] for t in whole), V, ring[(g % 2) * G:(g % 2) * G + n], ws=ring_ws[g % 2])
-                built[g] = torch.cuda.Event()
-                built[g].record(st)
-        for g in range(min(2, n_groups)):
-            launch_build(g)
-        for g in range(n_groups):
-            main.wait_event(built[g])
-            for j in range(min(G, n_steps - g * G)):
-                hip.step_adagrad(ring[(g % 2) * G + j], tables, hyper, loss_out, ws)
-            stepped[g] = torch.cuda.Event()
-            stepped[g].record(main)
-            if g + 2 < n_groups:
-                launch_build(g + 2)
-
-    def sweep_pipelined(n_steps):
-        """n_steps dynamic steps with `ahead` index builds in flight (call inside a graph capture or eagerly)."""
-        if grouped:
-            return sweep_grouped(n_steps)
-        main = torch.cuda.current_stream()
-        built, stepped = [None] * n_steps, [None] * n_steps
-        start = torch.cuda.Event()
-        start.record(main)
-
-        def launch_build(i):
-            st = ring_streams[i % ahead]
-            st.wait_event(stepped[i - ahead] if i >= ahead else start)
-            with torch.cuda.stream(st):
-                hip.build_plan(*batches[i % nb], V, chunk_cap=cap, into=ring[i % ahead], ws=ring_ws[i % ahead])
-                built[i] = torch.cuda.Event()
-                built[i].record(st)
-        for i in range(min(ahead, n_steps)):
-            launch_build(i)
-        for i in range(n_steps):
-            main.wait_event(built[i])
-            hip.step_adagrad(ring[i % ahead], tables, hyper, loss_out, ws)
-            stepped[i] = torch.cuda.Event()
-            stepped[i].record(main)
-            if i + ahead < n_steps:
-                launch_build(i + ahead)
+        ws = torch.empty(max(hip.lib.glove_step_workspace_bytes(B, p.cap_chunks, tables.d) for p in plans), dtype=torch.uint8, device=dev)
 
     def step(i):
         if stepper is not None:
             stepper.step(handles[i % nb])
             return
-        plan = hip.build_plan(*batches[i % nb], V, chunk_cap=cap, into=staging) if dynamic else plans[i % nb]
+        plan = plans[i % nb]
         if adam:
             hip.step_adam(plan, tables, hyper, G, loss_out, ws)
         else:
@@ -465,11 +556,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                if ahead > 1:
-                    sweep_pipelined(spg)
-                else:
-                    for i in range(spg):
-                        step(i)
+                for i in range(spg):
+                    step(i)
         except Exception as exc:             # a transport that refuses capture: the same steps, launched eagerly
             if mode == "single":
                 raise
@@ -486,42 +574,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         for i in range(done, n_steps):
             step(first + i)
 
-    torch.cuda.synchronize()
-    log("  warm-up steps")
-    run(warmup, 0)
-    # the first tens of milliseconds after the load phase run slow whatever the kernels are (B = 1 M at text8 scale:
-    # 158 us/step in a first region of 200 steps, 47 in every later one; the graph's first replay also carries its
-    # upload): the warm-up goes on, untimed, until the loop has run for 50 ms
-    ctx.barrier()
-    t_warm = time.perf_counter()
-    while True:
-        run(steps, warmup)
-        ctx.barrier()
-        warm = torch.tensor([time.perf_counter() - t_warm], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(warm, op=dist.ReduceOp.MAX)     # every rank takes the same number of rounds
-        if float(warm.item()) >= 0.05:
-            break
-    log("  timed region")
-    # the timed region: exactly `steps` steps between barrier + synchronize on both sides, MAX over ranks; repeated
-    # at least three times and until at least min_timed_ms have been measured (a single transient cannot swing the
-    # figure), median reported
-    elapsed_all, total = [], 0.0
-    while True:
-        ctx.barrier()
-        t0 = time.perf_counter()
-        run(steps, warmup)
-        ctx.barrier()
-        el = time.perf_counter() - t0
-        stop = torch.tensor([el, 0.0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(stop, op=dist.ReduceOp.MAX)
-            el = float(stop[0].item())
-        elapsed_all.append(el)
-        total += el
-        if (total * 1e3 >= min_timed_ms and len(elapsed_all) >= 3) or len(elapsed_all) >= 50:   # every rank sees the same MAX: same decision
-            break
-    elapsed = statistics.median(elapsed_all)
+    elapsed, elapsed_all = timed_region(ctx, lambda n: run(n, 0), steps, warmup, min_timed_ms)
     final_loss = float(loss_out[0].item())
     log("  %.4f ms per step (%d repeats); per-kernel pass" % (elapsed / steps * 1e3, len(elapsed_all)))
     if not (final_loss == final_loss):
@@ -600,7 +653,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                           "frac": attributed[k] / (kern[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in attributed}
     step_us = sum(kern.values())
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
-    achieved = alg / (step_us * 1e-6) / 1e9
+    # the whole step as timed (contract: bytes / ms_per_step); the kernels alone, back to back, are reported beside it
+    achieved = alg / (elapsed / steps) / 1e9
     traffic, traffic_src = measured_traffic(workload, B, cap, any(k.startswith("step_fused") for k in kern)) \
         if mode == "single" and not adam else (None, None)
     rows = getattr(stepper, "rows", False)
@@ -620,8 +674,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                    "resident_batches": nb, "chunk_cap": cap,
                    **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
                       if ctx.args.rehearse_on_one_gpu else {}),
-                   "index": ("rebuilt every step, %d builds in flight" % ahead if ahead > 1 else
-                             "rebuilt every step") if dynamic else "static, built at load",
+                   "index": "static, built at load (the trainer's --epoch-shuffle static)",
                    "launch": "hipGraph replay, %d steps per graph" % spg if graph is not None else "eager",
                    "parallelism": parallelism,
                    **({"exchange_floats_per_rank_per_step": getattr(stepper, "payload_floats", None)} if stepper is not None else {})},
@@ -631,6 +684,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                      "traffic_over_algorithmic": (traffic / alg) if traffic else None,
                      "kernel": "one step = " + " + ".join(kern),
                      "algorithmic_bytes_per_step": alg, "kernel_us": kern, "per_kernel": per_kernel,
+                     "step_kernels_alone_frac": alg / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
         "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
     }
@@ -708,8 +762,8 @@ def main(argv=None):
     if mode == "auto" and world > 1 and big and args.exchange == "auto":
         mode = "sharded"        # the form whose exchange follows the batch, not the vocabulary (DESIGN.md "Multi-GPU")
     out = run_config(ctx, args.workload, B_head, args.optimizer, mode, args.steps, args.warmup,
-                     dynamic=args.dynamic, build_ahead=args.build_ahead, **common)
-    plain = not (args.single or args.dynamic or args.optimizer != "Adagrad" or args.row_sharded or args.force_dense or
+                     dynamic=not args.static_index, segment=args.index_segment, **common)
+    plain = not (args.single or args.static_index or args.index_segment or args.optimizer != "Adagrad" or args.row_sharded or args.force_dense or
                  args.step_form or args.chunk_cap or args.batch_size or args.workload != "zipf_v400k_d300" or
                  (args.rehearse_on_one_gpu and not args.with_configs))
     if rank == 0 and not args.no_cpu_baseline and world == 1 and mode == "auto":
@@ -719,26 +773,21 @@ def main(argv=None):
         # the other configurations of BASELINE.json / BASELINE.md §3 in the same line, the HBM-bound ones last (the tail of
         # a long line is what a log keeps).  (name, estimated seconds incl. load, run_config arguments)
         extra = dict(lr=args.learning_rate, max_batches=8, min_timed_ms=args.min_timed_ms, exchange=args.exchange)
-        specs = ([("c1_shape_adam_bs1024", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
-                  # BASELINE configs[1] at the reference's batch size and at (nearly) the whole stream per step
-                  ("text8_d64_bs1024", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
-                  # ... and with the index of every batch rebuilt inside the timed step (a reshuffled epoch at the reference's
-                  # default shape: the indexes of eight steps from one launch)
-                  ("text8_d64_bs1024_index_rebuilt_every_step", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200,
-                                                                        dynamic=True, build_ahead=8)),
-                  ("text8_d64_bs1048576", 4, dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
-                  # the dedup index (the reference's per-step Unique + segment-sum) rebuilt INSIDE every timed step instead
-                  # of once at load — what a reshuffled epoch costs: one build at a time, and six in flight on their own streams
-                  ("text8_d64_index_rebuilt_every_step", 5, dict(workload="text8_d64", B=131072, steps=100, warmup=10, dynamic=True)),
-                  ("text8_d64_index_rebuilt_every_step_6_in_flight", 5, dict(workload="text8_d64", B=131072, steps=100, warmup=10,
-                                                                             dynamic=True, build_ahead=6)),
-                  ("c2_text8_d64", 4, dict(workload="text8_d64", B=131072, steps=200, warmup=20, max_batches=64)),
-                  # the headline workload with the index rebuilt every step (four builds in flight, as the trainer's default
-                  # --epoch-shuffle full runs it)
-                  ("c4_zipf_v400k_d300_index_rebuilt_every_step_4_in_flight", 12,
-                   dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4, dynamic=True, build_ahead=4)),
-                  ("c3_text8_v50k_d300", 6, dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
-                  ("c5_zipf_v2m_d128_one_gpu_shard", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4))]
+        specs = ([  # the headline workload in the trainer's other mode (--epoch-shuffle static: index built once at load)
+                  ("c4_zipf_v400k_d300_static_index", 12, dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4, max_batches=16)),
+                  # BASELINE configs[0]'s shape (Keras-legacy Adam, the reference's default batch) as the trainer runs it, and static
+                  ("c1_shape_adam_bs1024", 5, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001, dynamic=True)),
+                  ("c1_shape_adam_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
+                  # BASELINE configs[1] at the reference's batch size, at 131,072 pairs and at (nearly) the whole stream per step
+                  ("text8_d64_bs1024", 5, dict(workload="text8_d64", B=1024, steps=2000, warmup=200, dynamic=True)),
+                  ("text8_d64_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
+                  ("c2_text8_d64", 5, dict(workload="text8_d64", B=131072, steps=200, warmup=20, dynamic=True)),
+                  ("c2_text8_d64_static_index", 4, dict(workload="text8_d64", B=131072, steps=200, warmup=20, max_batches=64)),
+                  ("text8_d64_bs1048576_static_index", 4, dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),
+                  ("c3_text8_v50k_d300", 7, dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10, dynamic=True)),
+                  ("c3_text8_v50k_d300_static_index", 6, dict(workload="text8_v50k_d300", B=131072, steps=100, warmup=10)),
+                  ("c5_zipf_v2m_d128_one_gpu_shard", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4, dynamic=True)),
+                  ("c5_zipf_v2m_d128_one_gpu_shard_static_index", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4))]
                  if world == 1 else
                  # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), and config 5
                  [("c4_zipf_v400k_d300_data_parallel", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="dp")),
@@ -759,10 +808,10 @@ def main(argv=None):
             configs.append(r)
         out["configs_skipped"] = skipped
         out["configs"] = configs
-        # the headline workload as a freshly reshuffled epoch runs it (the trainer's default), beside the static figure
+        # the headline workload in the trainer's static mode, beside the headline
         for r in configs:
-            if r["name"].startswith("c4_zipf_v400k_d300_index_rebuilt_every_step"):
-                out["config"]["same_workload_index_rebuilt_every_step"] = {
+            if r["name"] == "c4_zipf_v400k_d300_static_index":
+                out["config"]["same_workload_static_index"] = {
                     "nonzeros_per_s": r["value"], "ms_per_step": r["ms_per_step"], "index": r["config"]["index"]}
     out["wall_seconds"] = time.perf_counter() - T_START
     if rank == 0:

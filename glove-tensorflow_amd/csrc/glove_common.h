@@ -99,6 +99,65 @@ __device__ inline float group_sum(float v)
 
 __device__ inline float wave_sum(float v) { return group_sum<64>(v); }
 
+// ---- keyed bijection of [0, n): a Feistel network over the b = ceil(log2 n) bits of the position — halves of floor(b / 2)
+// (high) and ceil(b / 2) (low) bits, four rounds of a multiply-xorshift mix that alternately rewrite the high half from the low
+// one and the low half from the high one, one 32-bit round key each — with cycle walking: positions that land outside [0, n)
+// go round again (2^b < 2 n: fewer than two rounds of it on average; a balanced network over an even number of bits would
+// waste up to four).  What an epoch's reshuffle of a resident nonzero stream is drawn from (glove_shuffle_stream,
+// glove_epoch_deal): no sort of n random keys, no index array.  oracle/glove_ref.py:feistel_walk restates it.
+__host__ __device__ inline uint32_t feistel_mix(uint32_t x, uint32_t k)
+{
+    // one multiply per round: the deal's histogram pass is bound by this arithmetic (25 M pairs x 2 orders x 4 rounds x ~1.3
+    // walks: 290 us per epoch with a two-multiply finaliser per round)
+    // (mixing checked on the CPU restatement: |corr(position, seat)| < 0.01, neighbours share a batch as often as chance)
+    x += k;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15;
+    return x;
+}
+
+__host__ __device__ inline uint64_t feistel_walk(uint64_t x, uint64_t n, int bits, uint4 key)
+{
+    const int hb = bits / 2, lb = bits - hb;
+    const uint32_t hmask = (uint32_t)((1ull << hb) - 1ull), lmask = (uint32_t)((1ull << lb) - 1ull);
+    do {
+        uint32_t H = (uint32_t)(x >> lb), L = (uint32_t)(x & lmask);
+        H ^= feistel_mix(L, key.x) & hmask;
+        L ^= feistel_mix(H, key.y) & lmask;
+        H ^= feistel_mix(L, key.z) & hmask;
+        L ^= feistel_mix(H, key.w) & lmask;
+        x = ((uint64_t)H << lb) | L;
+    } while (x >= n);
+    return x;
+}
+
+// b with 2^b >= n (b >= 2), or -1 when n is beyond 2^62
+inline int feistel_bits(int64_t n)
+{
+    int b = 2;
+    while (b < 62 && (1ull << b) < (uint64_t)n) ++b;
+    return (1ull << b) < (uint64_t)n ? -1 : b;
+}
+
+__device__ inline int wave_sum_int(int v)
+{
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
+    return v;
+}
+
+// lanes of the wave that hold the same digit as this one (valid lanes only); db ballots
+__device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < db; ++b) {
+        const bool bit = (digit >> b) & 1;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
 __device__ inline float dot4(const f4 a, const f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // Per-workgroup reduction of kPartials running sums into out[blockIdx.x][kPartials].

@@ -19,13 +19,6 @@ constexpr int kSmallPlanMax = 4096;
 int plan_build_small(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t V,
                      const PlanSet &set, int n, hipStream_t st);
 
-__device__ inline int wave_sum_int(int v)
-{
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) v += __shfl_xor(v, dlt, 64);
-    return v;
-}
-
 // ---- stable LSD radix sort of (id, position), B > kSmallPlanMax ------------------------------------------------
 // Both sides need the batch's pairs in (id, arrival order) order: the row side sorted by row id, the col side by col id.
 // The two sorts are independent, so they share their launches: grid.y = 2 picks the side, every launch has twice the
@@ -94,18 +87,6 @@ __device__ inline void block_store_sum(int v, int32_t *out)
         for (int wv = 0; wv < kSortWaves; ++wv) s += part[wv];
         *out = s;
     }
-}
-
-// lanes of the wave that hold the same digit as this one (valid lanes only); db ballots
-__device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
-{
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < db; ++b) {
-        const bool bit = (digit >> b) & 1;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-    }
-    return peers;
 }
 
 template <int E>
@@ -301,6 +282,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(Args args)
 //               uniq_slot; the last tile also writes the totals and the closing entries.
 // blockIdx.y selects the side.  Bit-exact against oracle/glove_ref.py:build_plan like the scans it replaces.
 
+// x[side] of a two-entry member of an argument struct, as a select: indexing by a run-time value would put a struct that was
+// composed in registers (pick(SideDev)) into scratch memory (312 bytes per lane, the numbering kernels 20 -> 14 us per batch)
+#define SIDE(x) (side ? x[1] : x[0])
+
 constexpr int kTileThreads = 256;
 constexpr int kTilePer = 8;                               // consecutive positions per thread
 constexpr int kTile = kTileThreads * kTilePer;
@@ -430,16 +415,55 @@ struct TileExtra {
     int32_t *c_perm, *r_to_c;
 };
 
+// a batch that arrives sorted (glove_plan_build_sorted) and whose plan keeps pair arrays of its own: copied by side_tiles
+struct SideCopy {
+    const int32_t *p_src[2]; const float *w_src[2], *y_src[2];
+    int32_t *p_dst[2]; float *w_dst[2], *y_dst[2];         // p_dst[side] == nullptr: nothing to copy
+};
+
 struct SideOne {                                           // the numbering kernels' arguments for one batch
     SideKeys sk;
     int64_t *tile_rs;
     int2 *tile_sums;
     TileExtra ex;
     SideOut out;
+    SideCopy cp;
 };
 struct SideSet { SideOne b[kPlanSetMax]; };                // per batch of a set (blockIdx.z)
 __device__ inline const SideOne &pick(const SideOne &a) { return a; }
 __device__ inline const SideOne &pick(const SideSet &a) { return a.b[blockIdx.z]; }
+
+// Any number of consecutive batches that arrive SORTED on both sides (an epoch dealt by glove_epoch_deal: batch z of a run
+// occupies positions [z B, (z + 1) B) of the two orders): the plans are read from a device array, so one launch covers the
+// whole run whatever its length (grid.z = batch) and its argument block stays small.
+struct SortedSrc { const int32_t *id[2], *partner[2]; const float *w[2], *y[2]; };    // the first batch of the run, both orders
+struct SortedWs { char *base; size_t per_batch, tile_rs, tile_re, tile_sums, aux0, aux1; };
+struct SideDev {
+    const glove_plan *plans;                               // device array, entry z = the plan of batch z of the run
+    SortedSrc src;
+    SortedWs ws;
+    int64_t B;
+    int ntiles;
+};
+__device__ inline SideOne pick(const SideDev &a)
+{
+    const glove_plan &pl = a.plans[blockIdx.z];
+    const size_t at = (size_t)blockIdx.z * (size_t)a.B;
+    char *w = a.ws.base + (size_t)blockIdx.z * a.ws.per_batch;
+    SideOne o;
+    o.sk = SideKeys{{a.src.id[0] + at, a.src.id[1] + at}};
+    o.tile_rs = reinterpret_cast<int64_t *>(w + a.ws.tile_rs);
+    o.tile_sums = reinterpret_cast<int2 *>(w + a.ws.tile_sums);
+    int64_t *tile_re = reinterpret_cast<int64_t *>(w + a.ws.tile_re);
+    int2 *aux0 = reinterpret_cast<int2 *>(w + a.ws.aux0), *aux1 = reinterpret_cast<int2 *>(w + a.ws.aux1);
+    o.ex = TileExtra{tile_re, pl.counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    o.out = SideOut{{pl.r_chunk_id, pl.c_chunk_id}, {pl.r_chunk_start, pl.c_chunk_start}, {pl.r_uniq_slot, pl.c_uniq_slot},
+                    pl.counts, {pl.r_uniq_rec, pl.c_uniq_rec}, tile_re, pl.heavy, pl.heavy_chunks, pl.cap_heavy,
+                    {pl.r_crec ? aux0 : nullptr, pl.r_crec ? aux1 : nullptr}};
+    o.cp = SideCopy{{a.src.partner[0] + at, a.src.partner[1] + at}, {a.src.w[0] + at, a.src.w[1] + at}, {a.src.y[0] + at, a.src.y[1] + at},
+                    {pl.r_partner, pl.c_partner}, {pl.r_w, pl.c_w}, {pl.r_y, pl.c_y}};
+    return o;
+}
 
 template <class Args>
 __global__ __launch_bounds__(kTileThreads) void side_tiles(Args args, int64_t B, int32_t chunk_cap, int ntiles)
@@ -452,8 +476,18 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(Args args, int64_t B,
     __shared__ int64_t lds_rs[kTileThreads / 64 + 1];
     __shared__ int red[2][kTileThreads / 64];
     const int side = blockIdx.y, t = blockIdx.x;
-    const int32_t *keys = sk.keys[side];
+    const int32_t *keys = SIDE(sk.keys);
     const int64_t begin = (int64_t)t * kTile;
+    if (SIDE(one.cp.p_dst)) {
+        // the batch arrived sorted and its plan keeps the pair fields itself (no chunk records): coalesced copy, a wave's
+        // lanes on consecutive positions
+        const SideCopy &cp = one.cp;
+        for (int64_t k = begin + threadIdx.x; k < begin + kTile && k < B; k += kTileThreads) {
+            SIDE(cp.p_dst)[k] = SIDE(cp.p_src)[k];
+            SIDE(cp.w_dst)[k] = SIDE(cp.w_src)[k];
+            SIDE(cp.y_dst)[k] = SIDE(cp.y_src)[k];
+        }
+    }
     if (side == 1 && ex.c_perm) {
         // the two sorts ran side by side: what links them is where the row side put each pair (two coalesced accesses, a
         // gather and a scatter per position, under the wave searches below)
@@ -525,7 +559,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
     __shared__ int red[2][kTileThreads / 64];
     __shared__ int wave_tot[2][kTileThreads / 64];
     const int side = blockIdx.y, t = blockIdx.x;
-    const int32_t *keys = sk.keys[side];
+    const int32_t *keys = SIDE(sk.keys);
     const int64_t begin = (int64_t)t * kTile;
     // ids / chunks opened by the tiles to my left
     int pu = 0, pc = 0;
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
     int ui = base_u + iu - nu, ci = base_c + ic - nc;      // numbers of my first id / chunk opening
     for (int wv = 0; wv < wave; ++wv) { ui += wave_tot[0][wv]; ci += wave_tot[1][wv]; }
     const int64_t k0 = begin + (int64_t)threadIdx.x * kTilePer;
-    int32_t *chunk_id = out.chunk_id[side], *chunk_start = out.chunk_start[side], *uniq_slot = out.uniq_slot[side];
+    int32_t *chunk_id = SIDE(out.chunk_id), *chunk_start = SIDE(out.chunk_start), *uniq_slot = SIDE(out.uniq_slot);
     int open_ui[kTilePer], open_ci[kTilePer];              // number and first chunk of the id a position opens
     int64_t my_first_open = INT64_MAX;                     // first position of mine that opens an id
 #pragma unroll
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
     int64_t right = __shfl_down(sfx, 1, 64);               // min over the lanes to my right in this wave
     if (lane == 63) right = INT64_MAX;
     next_open = right < next_open ? right : next_open;
-    int2 *aux = out.chunk_aux[side];
+    int2 *aux = SIDE(out.chunk_aux);
 #pragma unroll
     for (int i = kTilePer - 1; i >= 0; --i) {
         if (!(flag[i] & 1u)) continue;                     // (a position that opens an id opens a chunk)
@@ -605,7 +639,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
             aux[open_ci[i]] = make_int2(opens ? open_ui[i] : open_ui[i] - 1, (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
         }
         if (!(flag[i] & 2u)) continue;
-        reinterpret_cast<int4 *>(out.uniq_rec[side])[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
+        reinterpret_cast<int4 *>(SIDE(out.uniq_rec))[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
         if (chunks > out.heavy_chunks) {
             const int slot = atomicAdd(out.counts + 4, 1);  // zeroed by side_tiles, the launch before this one
             if (slot < out.cap_heavy) out.heavy[slot] = (side << 30) | open_ui[i];
@@ -628,12 +662,28 @@ struct RecordOne { RecordArgs a; const int32_t *counts; };
 struct RecordSet { RecordOne b[kPlanSetMax]; };            // blockIdx.z: which plan of the set
 __device__ inline const RecordOne &pick(const RecordOne &a) { return a; }
 __device__ inline const RecordOne &pick(const RecordSet &a) { return a.b[blockIdx.z]; }
+struct RecordDev { SideDev d; };                           // batches that arrived sorted: the pair fields are the epoch's
+__device__ inline RecordOne pick(const RecordDev &r)
+{
+    const SideDev &a = r.d;
+    const glove_plan &pl = a.plans[blockIdx.z];
+    const size_t at = (size_t)blockIdx.z * (size_t)a.B;
+    char *w = a.ws.base + (size_t)blockIdx.z * a.ws.per_batch;
+    RecordOne o;
+    o.a = RecordArgs{{pl.r_uniq_slot, pl.c_uniq_slot}, {pl.r_chunk_id, pl.c_chunk_id}, {pl.r_chunk_start, pl.c_chunk_start},
+                     {a.src.partner[0] + at, a.src.partner[1] + at}, {a.src.w[0] + at, a.src.w[1] + at}, {a.src.y[0] + at, a.src.y[1] + at},
+                     {pl.r_crec, pl.c_crec},
+                     {reinterpret_cast<const int2 *>(w + a.ws.aux0), reinterpret_cast<const int2 *>(w + a.ws.aux1)}, 0};
+    o.counts = pl.counts;
+    return o;
+}
 
 template <class Args>
 __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
 {
-    const RecordArgs &a = pick(args).a;
-    const int32_t *__restrict__ counts = pick(args).counts;
+    const RecordOne &rone = pick(args);
+    const RecordArgs &a = rone.a;
+    const int32_t *__restrict__ counts = rone.counts;
     // A wave takes 32 consecutive chunks: their bounds, ids and header words arrive in three coalesced loads, then eight
     // lanes per chunk write line 0 of its record — header | block 0 | 16 B of padding: lane g of the octet stores float4 g,
     // the wave stores eight whole 128-byte lines per instruction — four chunks per lane, the loads of all four in flight
@@ -643,9 +693,9 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
     // blocks 1 .. of the few longer chunks follow in a loop of the same eight lanes.
     const int side = blockIdx.y;
     const int n_chunks = counts[2 * side];
-    const int32_t *chunk_id = a.chunk_id[side], *chunk_start = a.chunk_start[side], *partner = a.partner[side];
-    const float *w = a.w[side], *y = a.y[side];
-    const int2 *aux = a.chunk_aux[side];
+    const int32_t *chunk_id = SIDE(a.chunk_id), *chunk_start = SIDE(a.chunk_start), *partner = SIDE(a.partner);
+    const float *w = SIDE(a.w), *y = SIDE(a.y);
+    const int2 *aux = SIDE(a.chunk_aux);
     const int sq = rec_stride_q(capP);                     // float4 per record in memory
     const int lane = threadIdx.x & 63, g = lane & 7, oct = lane >> 3;
     const int j0 = (int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 32);
@@ -660,12 +710,12 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
         if (aux) {
             ax = aux[j0 + lane];
         } else if (a.header_in_record) {
-            ax = *reinterpret_cast<const int2 *>(a.crec[side] + (size_t)(j0 + lane) * sq * 4 + 2);
+            ax = *reinterpret_cast<const int2 *>(SIDE(a.crec) + (size_t)(j0 + lane) * sq * 4 + 2);
         } else {
             // word 3: (first chunk of its id) << 31 | chunks of the same id behind this one.  The id's chunks are
             // [uniq_slot[q], uniq_slot[q + 1]) for the q found by bisection (the slots are ascending)
             const int j = j0 + lane;
-            const int32_t *slot = a.uniq_slot[side];
+            const int32_t *slot = SIDE(a.uniq_slot);
             int lo = 0, hi = counts[2 * side + 1];             // slot[lo] <= j < slot[hi]
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -682,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
         const int32_t id = __shfl(cid, c, 64);
         const int x2 = __shfl(ax.x, c, 64), x3 = __shfl(ax.y, c, 64);
         if (j >= n_chunks) continue;
-        int4 *dst = reinterpret_cast<int4 *>(a.crec[side]) + (size_t)j * sq;
+        int4 *dst = reinterpret_cast<int4 *>(SIDE(a.crec)) + (size_t)j * sq;
         const int nq = 1 + 6 * ((n + kRecPad - 1) / kRecPad);   // logical float4 the chunk needs
         // gq: float4 of the record in memory; 7 is line 0's padding; logical f = gq below 7, gq - 1 above
         for (int gq = g; gq < (nq > 7 ? nq + 1 : 8); gq += 8) {
@@ -894,6 +944,7 @@ static int build_tiled_set(const int32_t *row, const int32_t *col, const float *
                             {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
                             (const int64_t *)pw[j].tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
                             {plan->r_crec ? pw[j].chunk_aux[0] : nullptr, plan->r_crec ? pw[j].chunk_aux[1] : nullptr}};
+        ss.b[j].cp = SideCopy{};
         ss.b[j].ex = TileExtra{pw[j].tile_re, plan->counts, (const int32_t *)pw[j].mapped, 2 * pw[j].sort_tiles,
                              (const int32_t *)pw[j].c_orig, (const int32_t *)pw[j].rpos, plan->c_perm, plan->r_to_c};
         aux_r[j] = pw[j].chunk_aux[0];
@@ -918,35 +969,14 @@ static int build_tiled_set(const int32_t *row, const int32_t *col, const float *
 // instead of a sort of n random keys and four gathers (torch.randperm + index_select: 2.7 ms for the 25 M pairs of the C4
 // shard, an eighth of its epoch; 0.25 ms of 0.75 at 131,072-pair batches of a 1.2 M-pair stream).  The reference shuffles
 // through a 10,000-element buffer (data_utils.py:12-21): any bijection mixes harder.
-__device__ inline uint32_t feistel_mix(uint32_t x, uint32_t k)
-{
-    x += k;
-    x ^= x >> 16; x *= 0x7feb352du;
-    x ^= x >> 15; x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
-}
-
 __global__ __launch_bounds__(kBlock) void shuffle_stream_kernel(const int32_t *__restrict__ row, const int32_t *__restrict__ col,
                                                                 const float *__restrict__ w, const float *__restrict__ y, int64_t n,
                                                                 int h, uint4 key, int32_t *__restrict__ row_out,
                                                                 int32_t *__restrict__ col_out, float *__restrict__ w_out,
                                                                 float *__restrict__ y_out)
 {
-    const uint64_t mask = (1ull << h) - 1ull;
-    const uint32_t k[4] = {key.x, key.y, key.z, key.w};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        uint64_t x = (uint64_t)i;
-        do {
-            uint32_t L = (uint32_t)(x >> h), R = (uint32_t)(x & mask);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t t = L ^ (feistel_mix(R, k[r]) & (uint32_t)mask);
-                L = R;
-                R = t;
-            }
-            x = ((uint64_t)L << h) | R;
-        } while (x >= (uint64_t)n);
+        const uint64_t x = feistel_walk((uint64_t)i, (uint64_t)n, h, key);
         row_out[i] = row[x]; col_out[i] = col[x]; w_out[i] = w[x]; y_out[i] = y[x];
     }
 }
@@ -1047,6 +1077,97 @@ int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w
     return 0;
 }
 
+// ---- the index of batches that arrive sorted on both sides (an epoch dealt by glove_epoch_deal) ---------------------------
+static SortedWs carve_sorted_ws(void *ws, int64_t B, int *ntiles_out)
+{
+    SortedWs s;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t q = off; off += align_up(bytes, 256); return q; };
+    const size_t n = (size_t)(B > 0 ? B : 1);
+    const int ntiles = (int)((n + kTile - 1) / kTile);
+    s.base = (char *)ws;
+    s.tile_rs = take((size_t)2 * ntiles * 8);
+    s.tile_re = take((size_t)2 * ntiles * 8);
+    s.tile_sums = take((size_t)2 * ntiles * 8);
+    s.aux0 = take(n * 8);
+    s.aux1 = take(n * 8);
+    s.per_batch = off;
+    if (ntiles_out) *ntiles_out = ntiles;
+    return s;
+}
+
+size_t glove_plan_sorted_workspace_bytes(int64_t B, int32_t n_batches)
+{
+    if (B < 0 || n_batches < 0) return 0;
+    return carve_sorted_ws(nullptr, B, nullptr).per_batch * (size_t)n_batches;
+}
+
+int32_t glove_plan_chunk_bound(int64_t B, int32_t cap_uniq, int32_t chunk_cap)
+{
+    if (B < 0 || cap_uniq < 0 || chunk_cap <= 0) return 0;
+    const int64_t bound = (int64_t)cap_uniq + B / chunk_cap + 1;
+    return (int32_t)(bound < B ? bound : B);
+}
+
+int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_side, int64_t first_pair, int64_t B,
+                            int32_t n_batches, int32_t V, const glove_plan *plans, const glove_plan *plans_dev, void *ws,
+                            size_t ws_bytes, void *stream)
+{
+    if (!row_side || !col_side || !plans || !plans_dev || first_pair < 0 || B <= 0 || n_batches < 0 || V <= 0) return GLOVE_E_BADARG;
+    if (n_batches == 0) return 0;
+    if (!row_side->id || !row_side->partner || !row_side->w || !row_side->y || !col_side->id || !col_side->partner || !col_side->w ||
+        !col_side->y || !ws)
+        return GLOVE_E_BADARG;
+    int64_t most = 1;
+    for (int j = 0; j < n_batches; ++j) {
+        const glove_plan *p = plans + j;
+        if (p->B != B || p->chunk_cap <= 0 || p->chunk_cap != plans[0].chunk_cap || !p->counts) return GLOVE_E_BADARG;
+        if ((p->r_crec == nullptr) != (plans[0].r_crec == nullptr) || (p->r_crec == nullptr) != (p->c_crec == nullptr)) return GLOVE_E_BADARG;
+        if (!p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot || !p->r_uniq_rec || !p->c_chunk_id || !p->c_chunk_start ||
+            !p->c_uniq_slot || !p->c_uniq_rec)
+            return GLOVE_E_BADARG;
+        // a plan without chunk records keeps the pair fields itself (the step kernels read them): all six or none
+        const bool own = p->r_partner || p->r_w || p->r_y || p->c_partner || p->c_w || p->c_y;
+        if (own && (!p->r_partner || !p->r_w || !p->r_y || !p->c_partner || !p->c_w || !p->c_y)) return GLOVE_E_BADARG;
+        if (!own && !p->r_crec) return GLOVE_E_BADARG;
+        if (p->c_perm || p->r_to_c) return GLOVE_E_BADARG;              // the links between the orders are not computed here
+        if (!p->heavy || p->heavy_chunks < 1 || p->cap_heavy < 2 * B / ((int64_t)p->heavy_chunks * p->chunk_cap) + 2) return GLOVE_E_WORKSPACE;
+        if (p->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
+        if (p->cap_chunks < glove_plan_chunk_bound(B, p->cap_uniq, p->chunk_cap)) return GLOVE_E_WORKSPACE;
+        const int64_t mr = most_chunks(p, true), mc = most_chunks(p, false);
+        most = mr > most ? mr : most;
+        most = mc > most ? mc : most;
+    }
+    SideDev sd;
+    sd.plans = plans_dev;
+    sd.src = SortedSrc{{row_side->id + first_pair, col_side->id + first_pair}, {row_side->partner + first_pair, col_side->partner + first_pair},
+                       {row_side->w + first_pair, col_side->w + first_pair}, {row_side->y + first_pair, col_side->y + first_pair}};
+    sd.ws = carve_sorted_ws(ws, B, &sd.ntiles);
+    sd.B = B;
+    if (sd.ws.per_batch * (size_t)n_batches > ws_bytes) return GLOVE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t cap = plans[0].chunk_cap;
+    for (int z0 = 0; z0 < n_batches; z0 += 65535) {                      // (grid.z is 16 bits)
+        const int nz = n_batches - z0 < 65535 ? n_batches - z0 : 65535;
+        SideDev part = sd;
+        part.plans = plans_dev + z0;
+        part.ws.base = sd.ws.base + (size_t)z0 * sd.ws.per_batch;
+        for (int x = 0; x < 2; ++x) {
+            part.src.id[x] += (size_t)z0 * B; part.src.partner[x] += (size_t)z0 * B;
+            part.src.w[x] += (size_t)z0 * B; part.src.y[x] += (size_t)z0 * B;
+        }
+        const dim3 grid(sd.ntiles, 2, nz);
+        hipLaunchKernelGGL(side_tiles<SideDev>, grid, dim3(kTileThreads), 0, st, part, B, cap, sd.ntiles);
+        hipLaunchKernelGGL(side_emit<SideDev>, grid, dim3(kTileThreads), 0, st, part, B, cap, sd.ntiles);
+        if (plans[0].r_crec) {
+            const int64_t per_block = (kBlock / 64) * 32;
+            const int64_t nb = (most + per_block - 1) / per_block;
+            hipLaunchKernelGGL(fill_records<RecordDev>, dim3((unsigned)(nb < 1 ? 1 : nb), 2, nz), dim3(kBlock), 0, st, RecordDev{part}, rec_cap(cap));
+        }
+    }
+    return (int)hipGetLastError();
+}
+
 int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n, uint64_t key_lo,
                          uint64_t key_hi, int32_t *row_out, int32_t *col_out, float *w_out, float *y_out, void *stream)
 {
@@ -1054,9 +1175,8 @@ int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w,
     if (n == 0) return 0;
     if (!row || !col || !w || !y || !row_out || !col_out || !w_out || !y_out || row == row_out || col == col_out || w == w_out || y == y_out)
         return GLOVE_E_BADARG;                                   // (not in place: every position reads another one)
-    int h = 1;
-    while (h < 31 && (1ull << (2 * h)) < (uint64_t)n) ++h;       // 2 h bits cover [0, n)
-    if ((1ull << (2 * h)) < (uint64_t)n) return GLOVE_E_BADARG;  // n beyond 2^62: not a stream of this library
+    const int h = feistel_bits(n);                               // bits that cover [0, n)
+    if (h < 0) return GLOVE_E_BADARG;                            // n beyond 2^62: not a stream of this library
     const uint4 key = make_uint4((uint32_t)key_lo, (uint32_t)(key_lo >> 32), (uint32_t)key_hi, (uint32_t)(key_hi >> 32));
     hipLaunchKernelGGL(shuffle_stream_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, row, col, w, y, n, h,
                        key, row_out, col_out, w_out, y_out);

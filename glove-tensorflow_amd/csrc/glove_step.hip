@@ -1433,9 +1433,12 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (!p || !t || !h || !ws) return GLOVE_E_BADARG;
     if (p->B < 0 || p->cap_chunks < 0 || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
     if (!p->counts || !t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->step) return GLOVE_E_BADARG;
-    if (p->B > 0 && (!p->r_partner || !p->r_w || !p->r_y || !p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
-                     !p->heavy || p->heavy_chunks < 1 || !p->c_w || !p->c_y || !p->r_uniq_rec || !p->c_uniq_rec || !p->c_partner || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
+    if (p->B > 0 && (!p->r_chunk_id || !p->r_chunk_start || !p->r_uniq_slot ||
+                     !p->heavy || p->heavy_chunks < 1 || !p->r_uniq_rec || !p->c_uniq_rec || !p->c_chunk_id || !p->c_chunk_start || !p->c_uniq_slot))
         return GLOVE_E_BADARG;
+    // the pair fields: in arrays of the plan's own, or (a plan of a dealt epoch, glove_plan_build_sorted) in its chunk records only
+    const bool own_pairs = p->r_partner && p->r_w && p->r_y && p->c_partner && p->c_w && p->c_y;
+    if (p->B > 0 && !own_pairs && !(p->r_crec && p->c_crec)) return GLOVE_E_BADARG;
     const RowShape shape = pick_row_shape(t->d / 4);
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
@@ -1643,6 +1646,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work
     // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
+    if (!rec && p->B > 0 && !p->r_partner) return GLOVE_E_BADARG;     // (the diagnostic pass needs pair arrays)
 #define LAUNCH(LPR, NV, FULL, REC, FUSE) \
     hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
 #define CALL(LPR, NV)                                                                   \

@@ -63,12 +63,14 @@ FLAGS = (
     Flag("skip-eval", None, False, "checkpoint without the eval pass"),
     Flag("epoch-shuffle", str, "full", "full (default, what the reference's input_fn does — make_csv_dataset reshuffles every "
                                        "epoch): every rank draws a new permutation of its pairs every epoch, the dedup "
-                                       "index of a batch is built when the batch is used; static: the pairs are permuted "
+                                       "pairs were sorted once at load, an epoch is one partition pass of both sorted orders, the index of a batch is numbered when the batch is used; static: the pairs are permuted "
                                        "once, cut into batches whose index is built at load, and every epoch visits the "
                                        "same batches in a new order (faster: no index build per step)"),
-    Flag("no-graphs", None, False, "with --epoch-shuffle full: launch every build and step from Python instead of replaying "
-                                   "captured hipGraphs"),
-    Flag("build-ahead", int, 4, "index builds in flight with --epoch-shuffle full"),
+    Flag("no-graphs", None, False, "launch every step from the host instead of replaying captured hipGraphs"),
+    Flag("index-segment", int, 0, "with --epoch-shuffle full: consecutive batches whose dedup index one set of launches "
+                                  "builds (0: up to 64, as the epoch and 6 GB of staging plans allow)"),
+    Flag("multi-rank-graphs", None, False, "replay multi-rank steps (kernels + RCCL collectives) from hipGraphs as well; "
+                                           "one GPU always does"),
     Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
                                      "nonzero to the rank that owns its row, instead of replicating all tables "
                                      "(BASELINE config 5; Adagrad only)"),

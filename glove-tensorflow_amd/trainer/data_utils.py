@@ -127,7 +127,10 @@ class NonzeroStream:
         # every nonzero belongs to exactly one rank: the first n % world ranks take one more
         lo, hi = rank * (n // world) + min(rank, n % world), (rank + 1) * (n // world) + min(rank + 1, n % world)
         mine = perm[lo:hi] if world > 1 else perm
-        take = lambda a: torch.from_numpy(np.ascontiguousarray(a))[mine].to(self.device)
+        def take(a):        # numpy arrays (the parsed CSV) or tensors already on the device (bench.py's synthetic workloads)
+            if torch.is_tensor(a):
+                return a[mine.to(a.device)].to(self.device)
+            return torch.from_numpy(np.ascontiguousarray(a))[mine].to(self.device)
         self.row, self.col, self.w, self.y = take(coo["row"]), take(coo["col"]), take(coo["w"]), take(coo["y"])
         if route is not None:
             # row-sharded model: every nonzero moves to the rank that owns its row (one all-to-all at load), row ids
@@ -155,13 +158,71 @@ class NonzeroStream:
             self.recut(first=True)
         self._order, self._pos = None, 0
         self._dev_gen = None
+        # --epoch-shuffle full on the HIP backend: the pairs are sorted ONCE, into the two master orders (row-major and
+        # col-major), and every epoch is DEALT from them — a keyed bijection seats the pairs, one stable counting-sort pass
+        # per order by batch number writes the epoch so that every batch arrives sorted by row id and by col id
+        # (glove_masters_build / glove_epoch_deal): no sort per batch.  `row`, `col`, `w`, `y` become the row-major order
+        # (the eval pass reads them), `batch(b)` the row side of batch b of the current epoch.
+        self.masters, self.epoch = None, -1
+        hip = getattr(backend, "hip", None)
+        if not static_plans and hip is not None and self.device.type == "cuda":
+            self.masters = hip.build_masters(self.row.contiguous(), self.col.contiguous(), self.w.contiguous(), self.y.contiguous(),
+                                             self.V, getattr(backend, "shard_rows", 0) or 0)
+            self.row, self.col, self.w, self.y = self.masters.row_major.arrays()
+            from trainer.hip_api import Pairs
+            self._sets = [(Pairs(self.nnz, self.device), Pairs(self.nnz, self.device)) for _ in range(2)]
+            self._deal_ws = hip.deal_workspace(self.nnz, self.B, self.device)
+            self.side = torch.cuda.Stream(device=self.device)       # deals — and the index builds that read them (trainer.stepper)
+            self._dealt_upto, self._dealt_ev = -1, {}
+            # whether work on the COMPUTE stream reads the epoch buffers (`batch(b)` handed to kernels there): a deal then
+            # waits for what that stream holds before it overwrites a buffer set.  The runner, whose index builds run on
+            # `side` itself, turns it off: its deals start at once
+            self.main_reads_epochs = True
+
+    # ---- dealt epochs
+    def _ensure_dealt(self, e: int):
+        """Epochs up to `e` have been dealt (issued on the side stream; epoch e lives in buffer set e % 2)."""
+        hip = self.backend.hip
+        while self._dealt_upto < e:
+            nxt = self._dealt_upto + 1
+            # the set's earlier readers: the index builds of epoch nxt - 2 (same stream) and whatever the compute stream
+            # has been handed of it
+            if self.main_reads_epochs:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+            key = int.from_bytes(torch.randint(0, 256, (16,), generator=self.gen, dtype=torch.uint8).numpy().tobytes(), "little")
+            with torch.cuda.stream(self.side):
+                rs, cs = self._sets[nxt % 2]
+                hip.deal_epoch(self.masters, self.B, key, rs, cs, self._deal_ws)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self._dealt_ev[nxt] = ev
+            self._dealt_ev.pop(nxt - 2, None)
+            self._dealt_upto = nxt
+
+    def epoch_sides(self, e: int | None = None):
+        """(row side, col side) of epoch e (default: the current one) as trainer.hip_api.Pairs: batch k = positions
+        [k B, (k + 1) B) of both, sorted by row id / by col id.  Valid on the side stream, or behind `dealt_event(e)`."""
+        e = self.epoch if e is None else e
+        self._ensure_dealt(e)
+        return self._sets[e % 2]
+
+    def dealt_event(self, e: int):
+        self._ensure_dealt(e)
+        return self._dealt_ev[e]
 
     def reshuffle_in_place(self):
-        """A fresh permutation of this rank's pairs becomes the stream (`row`, `col`, `w`, `y`).  The permutation of the NEXT
-        epoch is drawn and applied on a side stream, into a second set of buffers, while the current epoch trains (as a
-        device randperm plus four gathers it cost a quarter of the epoch's time at 131,072-pair batches of a 1.2 M-pair
-        stream when it sat between two epochs; on the HIP backend it is one gather launch under a keyed bijection); an epoch boundary then is a wait on an event that has
-        usually fired, and a swap of the two sets."""
+        """The next epoch begins: a fresh permutation of this rank's pairs.
+
+        Dealt stream (HIP): epoch e + 1 was dealt on the side stream while epoch e trained; the boundary is a wait on its
+        event and the deal of epoch e + 2 is issued behind it.
+        Otherwise (a CPU test backend): `row`, `col`, `w`, `y` are re-permuted; on a CUDA device without the library the next
+        epoch's permutation is drawn and applied on a side stream into a second set of buffers."""
+        if self.masters is not None:
+            e = self.epoch + 1
+            torch.cuda.current_stream(self.device).wait_event(self.dealt_event(e))
+            self.epoch = e
+            self._ensure_dealt(e + 1)
+            return
         if self.device.type != "cuda":
             if self._dev_gen is None:
                 self._dev_gen = torch.Generator(device=self.device)
@@ -187,21 +248,19 @@ class NonzeroStream:
 
     def _permute_into_spare(self, main):
         self._side.wait_stream(main)                       # the spare set's last readers (the epoch before) are on `main`
-        hip = getattr(self.backend, "hip", None)
         with torch.cuda.stream(self._side):
-            if hip is not None:
-                # one gather launch under a keyed bijection of the positions (glove_shuffle_stream: no sort of nnz random
-                # keys, no index array); the key comes from the stream's seeded host generator
-                key = int.from_bytes(torch.randint(0, 256, (16,), generator=self.gen, dtype=torch.uint8).numpy().tobytes(), "little")
-                hip.shuffle_stream((self.row, self.col, self.w, self.y), self._spare, key)
-            else:
-                p = torch.randperm(self.nnz, generator=self._dev_gen, device=self.device)
-                for dst, src in zip(self._spare, (self.row, self.col, self.w, self.y)):
-                    torch.index_select(src, 0, p, out=dst)
+            p = torch.randperm(self.nnz, generator=self._dev_gen, device=self.device)
+            for dst, src in zip(self._spare, (self.row, self.col, self.w, self.y)):
+                torch.index_select(src, 0, p, out=dst)
             self._ready = torch.cuda.Event()
             self._ready.record(self._side)
 
     def batch(self, b: int):
+        """(row, col, w, y) of batch b of the current epoch — of a dealt epoch in row-major order (its arrival order)."""
+        if self.masters is not None:
+            if self.epoch < 0:
+                raise RuntimeError("no epoch has begun: call reshuffle_in_place() first")
+            return self._sets[self.epoch % 2][0].arrays(b * self.B, (b + 1) * self.B)
         s = slice(b * self.B, (b + 1) * self.B)
         return self.row[s], self.col[s], self.w[s], self.y[s]
 

@@ -150,14 +150,18 @@ class Estimator:
             stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
                                         exchange=p.get("exchange", "auto"))
             stepper.prepare(**plans_or_size)        # collective: the ranks agree on the col-side exchange
-        elif self.world > 1 or not self.reshuffling:
+        elif self.world > 1 or not self.reshuffling or getattr(self.backend, "hip", None) is None:
+            # (a test backend without the library steps through a Stepper also on one rank)
             stepper = Stepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
                               exchange=p.get("exchange", "auto"))
             if self.world > 1:
                 stepper.prepare(**plans_or_size)    # collective: dense all-reduce or touched-rows all-gather
         else:
             stepper = None
-        if stepper is not None and not self.reshuffling and not p.get("no_graphs", False):
+        # hipGraphs: always on one GPU; with several ranks a captured step holds RCCL collectives, which has run through RCCL
+        # with ONE rank only so far (one-GPU boxes): opt-in there (--multi-rank-graphs) until a node has shown replay == eager
+        graphs = not p.get("no_graphs", False) and (self.world == 1 or bool(p.get("multi_rank_graphs", False)))
+        if stepper is not None and not self.reshuffling and graphs:
             stepper.enable_graphs()                 # a resident batch's step (kernels + RCCL collectives) replayed from a hipGraph
         if self.reshuffling:
             # every rank re-permutes ITS shard of the stream each epoch (reference data_utils.py:12-21 reshuffles every
@@ -165,9 +169,8 @@ class Estimator:
             from trainer.stepper import ReshufflingRunner
             stepper = ReshufflingRunner(getattr(self.backend, "hip", None), stream, tables,
                                         self.backend.make_hyper(batch_size=p["batch_size"] * self.world, **hyper_kwargs),
-                                        chunk_cap=p.get("chunk_cap", 0), ahead=p.get("build_ahead", 4),
-                                        burst=64,
-                                        stepper=stepper, graphs=not p.get("no_graphs", False))
+                                        chunk_cap=p.get("chunk_cap", 0), burst=64, segment=p.get("index_segment", 0),
+                                        stepper=stepper, graphs=graphs)
         fresh = self.ckpt.latest() is None
         if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
             flag = torch.tensor([1 if fresh else 0], device=self.device)
@@ -176,6 +179,19 @@ class Estimator:
         if fresh:
             self._save_checkpoint()         # Estimator saves at step 0 too
         t_last, s_last = time.perf_counter(), step
+        try:
+            self._train_loop(stepper, stream, step, max_steps, log_every, t_last, s_last)
+        finally:
+            # captured RCCL collectives must be gone before the process group is (RCCL's teardown waits for them) — also
+            # when the loop ends in an exception (the NaN stop)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            for obj in (stepper, getattr(stepper, "stepper", None)):
+                if hasattr(obj, "release_graphs"):
+                    obj.release_graphs()
+
+    def _train_loop(self, stepper, stream, step, max_steps, log_every, t_last, s_last):
+        p = self.params
         while step < max_steps:
             # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
             if self.reshuffling:
@@ -210,12 +226,6 @@ class Estimator:
                 self._save_checkpoint()
                 if not p.get("skip_eval"):
                     self.evaluate()
-        torch.cuda.synchronize() if self.device.type == "cuda" else None
-        if hasattr(stepper, "release_graphs"):
-            stepper.release_graphs()        # captured RCCL collectives must be gone before the process group is
-            inner = getattr(stepper, "stepper", None)
-            if hasattr(inner, "release_graphs"):
-                inner.release_graphs()
 
     def _save_checkpoint(self):
         """Rank 0 writes; a row-sharded run first gathers the whole model (collective: every rank calls this)."""
@@ -296,9 +306,11 @@ def main(argv=None, adapt_params=None):
         estimator = Estimator(params, dist=dist)
     else:
         estimator = Estimator(params)
-    estimator.train(params["train_steps"])
-    if world > 1:
-        dist.destroy_process_group()
+    try:
+        estimator.train(params["train_steps"])
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 7
+GLOVE_ABI_VERSION = 8
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
 DEFAULT_CHUNK_CAP = 32
@@ -50,6 +50,8 @@ EXPORTED_SYMBOLS = (
     "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_loss_partials_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
     "glove_count_packed_f32", "glove_steps_rebuilt_f32",
+    "glove_masters_workspace_bytes", "glove_masters_build", "glove_epoch_deal_workspace_bytes", "glove_epoch_deal",
+    "glove_plan_sorted_workspace_bytes", "glove_plan_chunk_bound", "glove_plan_build_sorted",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -79,6 +81,10 @@ class GlovePlan(C.Structure):
                 ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp),
                 ("r_crec", _fp), ("c_crec", _fp)]
+
+
+class GlovePairs(C.Structure):
+    _fields_ = [("id", _fp), ("partner", _fp), ("w", _fp), ("y", _fp)]
 
 
 class GlovePackedList(C.Structure):
@@ -120,6 +126,14 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_plan_build_many": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(P(GlovePlan)), vp, sz, vp]),
         "glove_shuffle_stream": (C.c_int, [vp, vp, vp, vp, i64, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
         "glove_plan_fill_records": (C.c_int, [P(GlovePlan), vp]),
+        "glove_masters_workspace_bytes": (sz, [i64]),
+        "glove_masters_build": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, P(GlovePairs), P(GlovePairs), vp, vp, vp, sz, vp]),
+        "glove_epoch_deal_workspace_bytes": (sz, [i64, i64]),
+        "glove_epoch_deal": (C.c_int, [P(GlovePairs), P(GlovePairs), vp, i64, i64, C.c_uint64, C.c_uint64, P(GlovePairs),
+                                       P(GlovePairs), vp, sz, vp]),
+        "glove_plan_sorted_workspace_bytes": (sz, [i64, i32]),
+        "glove_plan_chunk_bound": (i32, [i64, i32, i32]),
+        "glove_plan_build_sorted": (C.c_int, [P(GlovePairs), P(GlovePairs), i64, i64, i32, i32, P(GlovePlan), vp, vp, sz, vp]),
         "glove_step_workspace_bytes": (sz, [i64, i32, i32]),
         "glove_passes_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_rowpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
@@ -443,7 +457,10 @@ class Plan:
                   "c_partner", "c_perm", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy")
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
-                 cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None, links: bool = True):
+                 cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None, links: bool = True,
+                 own_pairs: bool = True):
+        """`own_pairs=False` (a plan with chunk records that glove_plan_build_sorted refills from a dealt epoch): no pair
+        arrays of its own — the records carry partner / w / y, the step functions read nothing else."""
         self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
         self.cap_chunks = int(B if cap_chunks is None else cap_chunks)
         self.cap_uniq = int(min(B, V) if cap_uniq is None else cap_uniq)
@@ -461,12 +478,14 @@ class Plan:
         self.r_crec = self.c_crec = None
         if self.B > 0 and (self.B <= RECORDS_AT_BUILD_MAX if records is None else records):
             self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
-        self.r_partner, self.c_partner = torch.empty(n, **i32), torch.empty(n, **i32)
+        if not own_pairs and self.r_crec is None:
+            raise ValueError("a plan without pair arrays of its own needs chunk records")
+        self.r_partner, self.c_partner = (torch.empty(n, **i32), torch.empty(n, **i32)) if own_pairs else (None, None)
         # c_perm / r_to_c link the two sorted orders; no kernel reads them: `links=False` (the per-step plans of a
         # reshuffled epoch) leaves them out and the build skips the join of its two sorts
         self.r_to_c, self.c_perm = (torch.empty(n, **i32), torch.empty(n, **i32)) if links else (None, None)
-        self.r_w, self.r_y = torch.empty(n, **f32), torch.empty(n, **f32)
-        self.c_w, self.c_y = torch.empty(n, **f32), torch.empty(n, **f32)
+        self.r_w, self.r_y = (torch.empty(n, **f32), torch.empty(n, **f32)) if own_pairs else (None, None)
+        self.c_w, self.c_y = (torch.empty(n, **f32), torch.empty(n, **f32)) if own_pairs else (None, None)
         self.r_chunk_id, self.c_chunk_id = (torch.empty(max(self.cap_chunks, 1), **i32) for _ in range(2))
         self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
         self.r_uniq_slot, self.c_uniq_slot = (torch.zeros(self.cap_uniq + 1, **i32) for _ in range(2))
@@ -549,6 +568,56 @@ class Plan:
     def nbytes(self) -> int:
         n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts") if getattr(self, f) is not None)
         return n + sum(t.numel() * 4 for t in (self.r_crec, self.c_crec) if t is not None)
+
+
+class Pairs:
+    """One sorted order of a set of nonzeros as four device arrays (glove_pairs): the pair's id on the order's own side,
+    its id on the other side, glove_weight, glove_value."""
+
+    def __init__(self, n: int, device):
+        dev = torch.device(device)
+        self.n = int(n)
+        self.id = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.partner = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.w = torch.empty(max(self.n, 1), dtype=torch.float32, device=dev)
+        self.y = torch.empty(max(self.n, 1), dtype=torch.float32, device=dev)
+        self._struct = None
+
+    def struct(self) -> GlovePairs:
+        if self._struct is None:
+            s = GlovePairs()
+            s.id, s.partner, s.w, s.y = _ptr(self.id), _ptr(self.partner), _ptr(self.w), _ptr(self.y)
+            self._struct = s
+        return self._struct
+
+    def arrays(self, lo: int = 0, hi: int | None = None):
+        hi = self.n if hi is None else hi
+        return self.id[lo:hi], self.partner[lo:hi], self.w[lo:hi], self.y[lo:hi]
+
+
+class Masters:
+    """A rank's nonzeros in their two master orders (glove_masters_build): row-major, col-major and the link between them."""
+
+    def __init__(self, row_major: Pairs, col_major: Pairs, link: torch.Tensor, mapped: int):
+        self.row_major, self.col_major, self.link, self.mapped = row_major, col_major, link, mapped
+        self.n = row_major.n
+
+
+class PlanBlock:
+    """Staging plans that glove_plan_build_sorted refills together: the plans, a host array of their structs and the same
+    array in device memory (the kernels read the structs from there: one launch covers the whole block)."""
+
+    def __init__(self, plans: list):
+        self.plans = list(plans)
+        n = len(self.plans)
+        self.host = (GlovePlan * n)()
+        for i, p in enumerate(self.plans):
+            self.host[i] = p.struct()
+        raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8)
+        self.dev = raw.to(self.plans[0].counts.device)
+
+    def __len__(self):
+        return len(self.plans)
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
@@ -647,6 +716,58 @@ class GloveHip:
         ptrs = (C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans])
         _check(self.lib.glove_plan_build_many(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n, V, ptrs, _ptr(ws), ws.numel(),
                                               _stream()), "glove_plan_build_many")
+
+    # ---- epochs dealt from id-sorted master orders (include/glove_hip.h)
+    def build_masters(self, row, col, w, y, V: int, V_row: int = 0) -> Masters:
+        """The rank's nonzeros sorted once: row-major and col-major orders + the link between them (one host sync for the
+        count of ids that were mapped to 0)."""
+        n = int(row.numel())
+        _require(row, torch.int32, n); _require(col, torch.int32, n)
+        _require(w, torch.float32, n); _require(y, torch.float32, n)
+        dev = row.device
+        rm, cm = Pairs(n, dev), Pairs(n, dev)
+        link = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        mapped = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(self.lib.glove_masters_workspace_bytes(n), 256), dtype=torch.uint8, device=dev)
+        _check(self.lib.glove_masters_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), n, V, V_row, C.byref(rm.struct()),
+                                            C.byref(cm.struct()), _ptr(link), _ptr(mapped), _ptr(ws), ws.numel(), _stream()),
+               "glove_masters_build")
+        n_mapped = int(mapped.item())
+        if n_mapped:
+            logger.warning("%d ids outside their table were treated as id 0 (the unknown token)", n_mapped)
+        del ws
+        return Masters(rm, cm, link, n_mapped)
+
+    def deal_workspace(self, n: int, B: int, device) -> torch.Tensor:
+        return torch.empty(max(self.lib.glove_epoch_deal_workspace_bytes(n, B), 256), dtype=torch.uint8, device=device)
+
+    def deal_epoch(self, masters: Masters, B: int, key: int, row_side: Pairs, col_side: Pairs, ws: torch.Tensor) -> None:
+        """One epoch of `masters` under the bijection the 128-bit `key` determines, into row_side / col_side: batch k =
+        positions [k B, (k + 1) B) of both, sorted by row id / by col id."""
+        if row_side.n != masters.n or col_side.n != masters.n:
+            raise GloveHipError("epoch buffers must hold %d pairs" % masters.n)
+        _check(self.lib.glove_epoch_deal(C.byref(masters.row_major.struct()), C.byref(masters.col_major.struct()),
+                                         _ptr(masters.link), masters.n, B, key & (2 ** 64 - 1), (key >> 64) & (2 ** 64 - 1),
+                                         C.byref(row_side.struct()), C.byref(col_side.struct()), _ptr(ws), ws.numel(), _stream()),
+               "glove_epoch_deal")
+
+    def staging_plan(self, B: int, V: int, chunk_cap: int, device, V_row: int = 0, records: bool = True) -> Plan:
+        """A plan for glove_plan_build_sorted to refill: capacity for any batch of B pairs (an id of p pairs has at most
+        p / chunk_cap + 1 chunks), chunk records carrying the pair fields, or pair arrays of its own without records."""
+        cap_uniq = min(B, max(V, V_row or 0))
+        cap_chunks = int(self.lib.glove_plan_chunk_bound(B, cap_uniq, chunk_cap))
+        return Plan(B, V, chunk_cap, device, cap_chunks=cap_chunks, cap_uniq=cap_uniq, V_row=V_row, records=bool(records),
+                    links=False, own_pairs=not records)
+
+    def build_plans_sorted(self, row_side: Pairs, col_side: Pairs, first_batch: int, block: PlanBlock, n: int,
+                           V: int, ws: torch.Tensor) -> None:
+        """The indexes of batches first_batch .. first_batch + n - 1 of a dealt epoch into the first n plans of `block`."""
+        B = block.plans[0].B
+        if n < 0 or n > len(block) or (first_batch + n) * B > row_side.n:
+            raise GloveHipError("batches %d .. %d of %d pairs do not lie inside the epoch" % (first_batch, first_batch + n - 1, B))
+        _check(self.lib.glove_plan_build_sorted(C.byref(row_side.struct()), C.byref(col_side.struct()), first_batch * B, B, n, V,
+                                                block.host, _ptr(block.dev), _ptr(ws), ws.numel(), _stream()),
+               "glove_plan_build_sorted")
 
     def shuffle_stream(self, src, dst, key: int) -> None:
         """dst = the four arrays of `src` (row, col, w, y) under the bijection of positions the 128-bit `key` determines."""

@@ -631,44 +631,41 @@ class ShardedStepper(GraphedSteps):
 
 class ReshufflingRunner:
     """Training over a stream whose pairs are re-permuted every epoch (`--epoch-shuffle full`, the reference's
-    `make_csv_dataset(shuffle=True, num_epochs=None)`, data_utils.py:12-21): the batches are new every epoch, so their
-    dedup index is built when they are used.  One GPU, or any of the multi-GPU forms through its `stepper`:
+    `make_csv_dataset(shuffle=True, num_epochs=None)`, data_utils.py:12-21): the batches are new every epoch, so Keras'
+    Unique + UnsortedSegmentSum (a9) — here the dedup index of a batch — cannot be prepared at load.  One GPU, or any of the
+    multi-GPU forms through its `stepper`.
 
-      * single GPU / data parallel / row-sharded (`Stepper`, `RowShardedStepper`): every rank permutes ITS shard of the
-        stream (no pair changes rank) and indexes each batch into a staging plan just before the step — like an input
-        pipeline that prefetches batches, `ahead` index builds are in flight on their own streams and staging plans while
-        earlier steps run.  A burst of 2^k consecutive batches is captured ONCE as a hipGraph (builds, steps, their
-        cross-stream dependencies and — on RCCL — the collectives) that reads its batches from a fixed window; a burst is
-        replayed by copying its pairs into the window (16 B per pair) and launching the graph of its length, so any number
-        of steps — up to a logging point, up to the epoch's end — is a handful of replays of at most log2(burst) + 1 graphs;
+    On the HIP backend the stream is DEALT (trainer.data_utils.NonzeroStream: the rank's pairs were sorted once, into a
+    row-major and a col-major master order; an epoch is one stable partition pass of both by batch number under a keyed
+    bijection, drawn and written on the stream's side stream while the epoch before trains), so every batch arrives sorted on
+    both sides and nothing is sorted per step.  What is left of the index — numbering chunks and ids, writing the chunk
+    records — is done a SEGMENT of consecutive batches at a time: three launches (glove_plan_build_sorted) refill the
+    staging plans of one of two slots on the side stream while the steps of the segment before run from the other slot.  The
+    builds are ordinary launches ordered by events; only the steps are replayed from hipGraphs: a graph holds 2^k
+    consecutive steps of one slot on ONE stream (kernels and, on RCCL, the collectives).
+
+      * single GPU / data parallel / row-sharded (`Stepper`, `RowShardedStepper`): every rank deals ITS shard (no pair
+        changes rank);
       * both tables sharded (`ShardedStepper`): a batch also needs its fetch lists agreed between the ranks
-        (`add_batch`, collective), so the epoch's batches are prepared together when the epoch starts and stepped through
-        in order.
+        (`add_batch`, collective), so the epoch's batches are prepared together when the epoch starts.
 
     With a test backend (no `hip`: the gloo tests on CPU) the same sequence runs eagerly, one synchronous build per step.
     On one rank every form gives exactly what the single-GPU runner gives.
     """
 
-    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, ahead=4, burst=128, stepper=None, graphs=True, streamed=None):
-        """`streamed` (one GPU): the loop of builds and steps runs in C on real streams (glove_steps_rebuilt_f32) instead of
-        being replayed from hipGraphs.  Not the default at any batch size (tools/exp_runner_modes.py, Adagrad, text8 scale):
-        B = 1,024: 28 k steps/s against 72 k from the replayed bursts with grouped index builds; 16,384: 21 k against 43 k;
-        131,072: 13.7 k against 17.4 k; V = 400 k, d = 300 at B = 1 M: 1,063 against 1,064."""
+    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, burst=64, stepper=None, graphs=True, segment=0,
+                 slot_bytes=16 << 30, max_graphs=256):
+        """`segment`: batches per index build (0: up to 64 — more would push the staging plans of small batches out of the caches —, as the epoch and `slot_bytes` of staging plans per slot allow);
+        `burst`: most steps per graph replay."""
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
-        self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V)
-        self.ahead, self.burst = max(1, int(ahead)), max(1, int(burst))
+        self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V, tables.d)
+        self.burst = max(1, int(burst))
         self.graphs_on = bool(graphs) and hip is not None and (
             stepper is None or transport_is_capturable(stepper.dist, stepper._multi))
-        if streamed is None:
-            streamed = False
-        self.streamed = bool(streamed) and stepper is None and hip is not None
-        if self.streamed:
-            self.graphs_on = False
         self.sharded = isinstance(stepper, ShardedStepper)
         self.loss_out = stepper.loss_out if stepper is not None else torch.zeros(4, dtype=torch.float32, device=tables.device)
-        self.graphs = {}
-        self.grouped = False
+        self.graphs, self.max_graphs = {}, int(max_graphs)
         self.position = 0                      # next batch of the current epoch
         self.handles = None                    # both tables sharded: the epoch's prepared batches
         # batches per epoch: the ranks' shards differ in length (by one pair data parallel, by the ownership of the rows
@@ -685,53 +682,52 @@ class ReshufflingRunner:
             return
         if hip is None:
             return
+        if getattr(stream, "masters", None) is None:
+            raise ValueError("the HIP runner steps over a dealt stream: NonzeroStream(..., static_plans=False) on the HIP backend")
         dev, B, V = tables.device, stream.B, stream.V
         shard_rows = tables.V_row if tables.V_row < tables.V else 0          # row-sharded: the stream carries shard-local row ids
-        # big batches on big tables (one GPU, Adagrad): the staging plans carry chunk records, the step takes its fused form
-        from trainer.hip_api import FUSED_STEP_BYTES, staging_records
-        records = staging_records(B, tables.V_row, V, tables.d) if stepper is None and tables.optimizer == "Adagrad" else None
-        if stepper is None and tables.optimizer == "Adagrad" and getattr(hyper, "step_form", 0) in (2, 3, 4):
-            records = True
-        if records and getattr(hyper, "step_form", 0) not in (2, 3, 4):      # (a forced fused form keeps its records)
-            # the library judges a refilled plan by the MOST ids its batch can hold; whether this stream's batches really
-            # reach the fused regime is looked up once, on the first batch (one sync, here at set-up)
-            probe = hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows)
-            counts = probe.counts.tolist()
-            if (counts[1] + counts[3]) * tables.d * 16 < FUSED_STEP_BYTES:
-                records = None
-            del probe
-        if records and getattr(hyper, "step_form", 0) == 0 and hasattr(tables, "maybe_enable_twin"):
+        single = stepper is None
+        # ---- what the staging plans carry, decided once from the first batch (one sync, here at set-up): chunk records where
+        # the library takes a fused step (big batches on big tables, one GPU, Adagrad: it judges a device-refilled plan by the
+        # most ids its batch can hold) or where the chunks are reasonably filled (the rule of Plan.compact); otherwise pair
+        # arrays of their own.  A plan with records keeps no pair arrays: the records hold the pair fields.
+        from trainer.hip_api import FUSED_STEP_BYTES, PlanBlock, staging_records
+        form = getattr(hyper, "step_form", 0)
+        probe = hip.build_plan(*(t.contiguous() for t in stream.batch(0)), V, chunk_cap=self.cap, V_row=shard_rows, links=False)
+        counts = probe.counts.tolist()
+        del probe
+        fused = single and tables.optimizer == "Adagrad" and (
+            form in (2, 3, 4) or (form == 0 and bool(staging_records(B, tables.V_row, V, tables.d)) and
+                                  (counts[1] + counts[3]) * tables.d * 16 >= FUSED_STEP_BYTES))
+        from trainer.hip_api import RECORDS_AT_BUILD_MAX
+        records = fused or B <= RECORDS_AT_BUILD_MAX or 4 * B >= self.cap * max(counts[0], counts[2], 1)
+        if fused and form == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
-        # small batches: their indexes are built a group of `ahead` at a time by one launch; the ring holds two groups
-        self.grouped = not self.streamed and 2 <= self.ahead <= 8           # (also under a data-parallel / row-sharded stepper)
-        # what one set of launches takes (bs = 1,024: 4 -> 68.8 k steps/s, 8 -> 74.0 k; big batches: four, for the memory
-        # of their staging plans)
-        self.group = (8 if B <= 65536 else 4) if self.ahead >= 4 else self.ahead
-        self.ring = [hip.build_plan(*stream.batch(0), V, chunk_cap=self.cap, V_row=shard_rows, records=records, links=False)
-                     for _ in range(2 * self.group if self.grouped else self.ahead)]
-        self.ring_ws = [torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * (self.group if self.grouped else 1), dtype=torch.uint8,
-                                    device=dev) for _ in range(2 if self.grouped else self.ahead)]
-        self.ring_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ahead)]
-        self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
-        self.window = None
-        if self.graphs_on:
-            self.burst = 1 << (self.burst.bit_length() - 1)             # bursts are powers of two
-            self.window = tuple(torch.empty(self.burst * B, dtype=t.dtype, device=dev)
-                                for t in (stream.row, stream.col, stream.w, stream.y))
-        self.G = hip.dense_grad_buffer(tables) if stepper is None and tables.optimizer == "Adam" else None
-        self.build_ring = hip.make_build_ring(self.ring, self.ring_ws, self.ring_streams) if self.streamed else None
-        # every kernel (and collective) of the sequence runs once outside any capture, on throw-away tables of the same shape
+        self.records = records
+        stream.main_reads_epochs = False        # from here on only the side stream's builds read the epoch buffers
+        first = hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records)
+        per_plan = max(first.nbytes(), 1)
+        self.S = int(segment) if segment else max(1, min(64, self.nb, int(slot_bytes) // per_plan))
+        self.S = max(1, min(self.S, self.nb))
+        plans = [first] + [hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records) for _ in range(2 * self.S - 1)]
+        self.slots = [PlanBlock(plans[:self.S]), PlanBlock(plans[self.S:])]
+        self.sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, self.S), 256), dtype=torch.uint8, device=dev)
+        self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, first.cap_chunks, tables.d), dtype=torch.uint8, device=dev)
+        self.G = hip.dense_grad_buffer(tables) if single and tables.optimizer == "Adam" else None
+        # ---- segments: `_g` = the segment the next step belongs to (counted over all epochs), slot = segment % 2
+        self._g, self._issued, self._entered = 0, 0, -1
+        self._cursor = (stream.epoch, 0)       # (epoch, segment of the epoch) the next build takes
+        self._built, self._freed = {}, {}
+        self._issue_build()                    # segment 0: needed now anyway
+        # every kernel (and collective) of a step runs once outside any capture, on throw-away tables of the same shape
         from trainer.hip_api import DeviceTables
         real = self.tables
         scratch = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
         if getattr(real, "R_ver", None) is not None:
             scratch.enable_twin()           # the same step forms are legal on the scratch tables
         self._swap_tables(scratch)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._issue(0, min(self.ahead + 1, self.nb))
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_event(self._built[0])
+        self._step(self.slots[0].plans[0])
         torch.cuda.synchronize()
         self._swap_tables(real)
         if self.G is not None:
@@ -752,76 +748,66 @@ class ReshufflingRunner:
         else:
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
-    def _issue_grouped(self, first, count, window):
-        """The indexes of `group` consecutive batches come from the launches of ONE build (glove_plan_build_many: a workgroup
-        per batch in the one-workgroup builder, grid.z = batch in the tiled one) — the graph's branches mostly run one after
-        the other, so what counts is the number of launches on the chain: bs = 1,024 Adagrad 22.0 -> 13.5 us per step.  The
-        ring holds two such groups: group g + 1 is built (on its side stream) while group g steps."""
-        B, G = self.stream.B, self.group
-        src = self.window if window else tuple(t[first * B:] for t in (self.stream.row, self.stream.col, self.stream.w, self.stream.y))
-        main = torch.cuda.current_stream()
-        n_groups = (count + G - 1) // G
-        built, stepped = [None] * n_groups, [None] * n_groups
-        start = torch.cuda.Event()
-        start.record(main)
+    def _segments_per_epoch(self) -> int:
+        return (self.nb + self.S - 1) // self.S
 
-        def launch_build(g):
-            st = self.ring_streams[g % 2]
-            st.wait_event(stepped[g - 2] if g >= 2 else start)
-            n = min(G, count - g * G)
-            with torch.cuda.stream(st):
-                self.hip.build_plans(*(t[g * G * B:] for t in src), self.stream.V,
-                                     self.ring[(g % 2) * G:(g % 2) * G + n], ws=self.ring_ws[g % 2])
-                built[g] = torch.cuda.Event()
-                built[g].record(st)
-        for g in range(min(2, n_groups)):
-            launch_build(g)
-        for g in range(n_groups):
-            main.wait_event(built[g])
-            for j in range(min(G, count - g * G)):
-                self._step(self.ring[(g % 2) * G + j])
-            stepped[g] = torch.cuda.Event()
-            stepped[g].record(main)
-            if g + 2 < n_groups:
-                launch_build(g + 2)
-
-    def _issue(self, first, count, window=False):
-        """`count` steps over batches first..first+count-1 of the stream (window: over the first `count` batches of the
-        window) with `ahead` index builds in flight."""
-        if self.grouped:
-            return self._issue_grouped(first, count, window)
-        B = self.stream.B
-        batch = (lambda i: tuple(t[i * B:(i + 1) * B] for t in self.window)) if window else (lambda i: self.stream.batch(first + i))
-        main = torch.cuda.current_stream()
-        built, stepped = [None] * count, [None] * count
-        start = torch.cuda.Event()
-        start.record(main)
-
-        def launch_build(i):
-            st = self.ring_streams[i % self.ahead]
-            st.wait_event(stepped[i - self.ahead] if i >= self.ahead else start)
-            with torch.cuda.stream(st):
-                self.hip.build_plan(*batch(i), self.stream.V, chunk_cap=self.cap,
-                                    into=self.ring[i % self.ahead], ws=self.ring_ws[i % self.ahead])
-                built[i] = torch.cuda.Event()
-                built[i].record(st)
-        for i in range(min(self.ahead, count)):
-            launch_build(i)
-        for i in range(count):
-            main.wait_event(built[i])
-            self._step(self.ring[i % self.ahead])
-            stepped[i] = torch.cuda.Event()
-            stepped[i].record(main)
-            if i + self.ahead < count:
-                launch_build(i + self.ahead)
+    def _issue_build(self):
+        """The index of the next segment — three launches on the stream's side stream, behind the deal of its epoch and the
+        last step that read the slot it refills."""
+        g, slot = self._issued, self._issued % 2
+        epoch, seg = self._cursor
+        first = seg * self.S
+        n = min(self.S, self.nb - first)
+        rs, cs = self.stream.epoch_sides(epoch)             # (issues the epoch's deal if nobody has yet)
+        side = self.stream.side
+        if slot in self._freed:
+            side.wait_event(self._freed[slot])
+        with torch.cuda.stream(side):
+            self.hip.build_plans_sorted(rs, cs, first, self.slots[slot], n, self.stream.V, self.sorted_ws)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._built[g] = ev
+        self._issued += 1
+        self._cursor = (epoch, seg + 1) if seg + 1 < self._segments_per_epoch() else (epoch + 1, 0)
 
     def _prepare_epoch(self):
         """Both tables sharded: the fetch lists and indexes of all batches of the epoch (collective)."""
         self.stepper.clear_batches()
-        self.handles = [self.stepper.add_batch(*self.stream.batch(b), self.cap) for b in range(self.nb)]
+        self.handles = [self.stepper.add_batch(*(t.contiguous() for t in self.stream.batch(b)), self.cap) for b in range(self.nb)]
+
+    def _launch(self, slot: int, off: int, count: int):
+        """Steps off .. off + count - 1 of a slot: replayed from the hipGraph of that run (captured the first time it is
+        asked for), or launched one by one."""
+        plans = self.slots[slot].plans
+        key = (slot, off, count)
+        graph = self.graphs.get(key) if self.graphs_on else None
+        if self.graphs_on and graph is None and len(self.graphs) < self.max_graphs:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    for j in range(off, off + count):
+                        self._step(plans[j])
+            except Exception as exc:                # a transport that refuses capture: the same launches, eagerly, from now on
+                if self.stepper is None:
+                    raise
+                import logging
+                logging.getLogger(__name__).warning("hipGraph capture of the multi-rank step failed (%s: %s): launching eagerly",
+                                                    type(exc).__name__, exc)
+                torch.cuda.synchronize()
+                self.graphs_on, self.graphs, graph = False, {}, None
+            else:
+                self.graphs[key] = graph
+        if graph is not None:
+            graph.replay()
+            return
+        for j in range(off, off + count):
+            self._step(plans[j])
 
     def run(self, n_steps: int) -> int:
-        """Up to `n_steps` steps, never across an epoch boundary; returns the number done (the caller asks again)."""
+        """Up to `n_steps` steps, never across a segment's or the epoch's end; returns the number done (the caller asks again)."""
+        if n_steps <= 0:
+            return 0
         nb = self.nb
         if self.position >= nb:
             self.stream.reshuffle_in_place()
@@ -829,45 +815,46 @@ class ReshufflingRunner:
             if self.sharded:
                 self._prepare_epoch()
         first = self.position
-        count = min(n_steps, nb - first) if self.streamed else min(n_steps, nb - first, self.burst)
         if self.sharded:
+            count = min(n_steps, nb - first, self.burst)
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
         elif self.hip is None:                     # a test backend: one synchronous build per step
+            count = min(n_steps, nb - first, self.burst)
             for b in range(first, first + count):
                 self.stepper.step(self.stepper.backend.build_plan(*self.stream.batch(b), self.stream.V, self.cap))
-        elif self.streamed:
-            B = self.stream.B
-            s0 = first * B
-            self.hip.steps_rebuilt(self.stream.row[s0:], self.stream.col[s0:], self.stream.w[s0:], self.stream.y[s0:], B, count,
-                                   self.stream.V, self.build_ring, self.tables, self.hyper, self.step_ws, self.G, self.loss_out)
-        elif self.graphs_on:
-            count = 1 << (count.bit_length() - 1)      # the largest power of two that fits: the caller comes back for the rest
-            B = self.stream.B
-            for dst, src in zip(self.window, (self.stream.row, self.stream.col, self.stream.w, self.stream.y)):
-                dst[:count * B].copy_(src[first * B:(first + count) * B])
-            if count not in self.graphs:
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    self._issue(0, count, window=True)
-                self.graphs[count] = graph
-            self.graphs[count].replay()
         else:
-            self._issue(first, count)                  # the same sequence, launched eagerly
+            S = self.S
+            seg, off = first // S, first % S
+            seg_len = min(S, nb - seg * S)
+            g, slot = self._g, self._g % 2
+            main = torch.cuda.current_stream()
+            if self._entered != g:                  # the segment's first step: its index, then the next segment's behind it
+                while self._issued <= g:
+                    self._issue_build()
+                main.wait_event(self._built.pop(g))
+                self._entered = g
+                if self._issued == g + 1:
+                    self._issue_build()            # into the other slot, free since the segment before this one ended
+            count = min(n_steps, seg_len - off, self.burst)
+            if self.graphs_on:
+                count = 1 << (count.bit_length() - 1)      # the largest power of two that fits: the caller comes back for the rest
+            self._launch(slot, off, count)
+            if off + count == seg_len:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._freed[slot] = ev
+                self._g += 1
         self.position += count
         return count
 
     def release_graphs(self):
-        """Drops the captured bursts (before the process group is destroyed: see GraphedSteps.release_graphs)."""
+        """Drops the captured runs of steps (before the process group is destroyed: see GraphedSteps.release_graphs)."""
         if self.graphs:
             torch.cuda.synchronize()
             self.graphs = {}
 
     def __del__(self):
-        # the captured bursts go before the side streams they were captured on: a runner dropped with its graphs alive
-        # (attributes torn down in arbitrary order, nothing synchronised) made the replay of ANOTHER object's graph
-        # segfault later in the same process (tests/rccl_graph_case.py, the grouped small-batch bursts)
         try:
             self.release_graphs()
         except Exception:

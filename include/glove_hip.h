@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 7   /* 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 8   /* 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -199,6 +199,53 @@ int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w
 int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n,
                          uint64_t key_lo, uint64_t key_hi,
                          int32_t *row_out, int32_t *col_out, float *w_out, float *y_out, void *stream);
+
+/* ---- epochs dealt from id-sorted master orders ----------------------------------------------------------------------------
+ * The reference's input_fn reshuffles the file every epoch (data_utils.py:12-21: make_csv_dataset(shuffle=True,
+ * num_epochs=None)), so Keras' Unique + UnsortedSegmentSum see new batches every step (a9).  Instead of sorting every batch
+ * when it is used (glove_plan_build: two stable sorts per step), a rank sorts its nonzeros ONCE:
+ *
+ *   glove_masters_build   the two master orders of the rank's nonzeros — row-major = sorted by (row id, col id, stream
+ *                         index), col-major = sorted by (col id, row id, stream index) — and link[q] = the row-major position
+ *                         of the pair at col-major position q.  Ids outside their table count as id 0 (the reference's
+ *                         unknown-token id, estimator.py:26-28): *mapped_out (device int32, optional) = how many.
+ *   glove_epoch_deal      one epoch: a bijection seat() of [0, n) determined by the 128-bit key (the Feistel network of
+ *                         glove_shuffle_stream) gives the pair at row-major position p the seat seat(p), i.e. batch
+ *                         seat(p) / B; a stable counting sort by batch number writes both orders so that batch k occupies
+ *                         positions [k B, (k + 1) B) of row_side and of col_side, sorted by row id / by col id — ties in
+ *                         master order.  Every full batch holds exactly B pairs; the n mod B pairs of the last, partial
+ *                         batch sit behind them and wait for the next epoch's deal.  Out of place.
+ *   glove_plan_build_sorted   the dedup indexes of n_batches consecutive batches of a dealt epoch in three launches, no
+ *                         sort (below).
+ *
+ * A batch of a dealt epoch "arrives" in row-major order: its index is what glove_plan_build gives for the row side's pairs
+ * (row_side.id, row_side.partner, w, y) handed over in that order — the stable sort of that order by col id is the col side's
+ * (col id, row id, stream index) order. */
+typedef struct glove_pairs {
+    int32_t *id;                /* [n] the pair's id on this order's own side (row ids in the row-major order) */
+    int32_t *partner;           /* [n] its id on the other side */
+    float *w, *y;               /* [n] glove_weight, glove_value */
+} glove_pairs;
+size_t glove_masters_workspace_bytes(int64_t n);
+int glove_masters_build(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n, int32_t V,
+                        int32_t V_row /* 0 = V */, const glove_pairs *row_major, const glove_pairs *col_major, int32_t *link,
+                        int32_t *mapped_out, void *ws, size_t ws_bytes, void *stream);
+size_t glove_epoch_deal_workspace_bytes(int64_t n, int64_t B);
+int glove_epoch_deal(const glove_pairs *row_major, const glove_pairs *col_major, const int32_t *link, int64_t n, int64_t B,
+                     uint64_t key_lo, uint64_t key_hi, const glove_pairs *row_side, const glove_pairs *col_side,
+                     void *ws, size_t ws_bytes, void *stream);
+/* plans[j] (a HOST array of n_batches structs; plans_dev = the same array in device memory, which the kernels read: one
+ * launch covers any number of batches and no plan travels in an argument block) indexes the batch at positions
+ * [first_pair + j B, first_pair + (j + 1) B) of the two orders.  All plans have the same B, chunk_cap and kind.  A plan
+ * with chunk records needs no pair arrays of its own (r_partner .. c_y all NULL: the records carry the pair fields, the
+ * step functions read nothing else); a plan without records gets them copied.  c_perm / r_to_c must be NULL.  Capacities:
+ * cap_uniq >= min(B, V) and cap_chunks >= glove_plan_chunk_bound(B, cap_uniq, chunk_cap) — an id of p pairs has at most
+ * p / chunk_cap + 1 chunks. */
+size_t glove_plan_sorted_workspace_bytes(int64_t B, int32_t n_batches);
+int32_t glove_plan_chunk_bound(int64_t B, int32_t cap_uniq, int32_t chunk_cap);
+int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_side, int64_t first_pair, int64_t B,
+                            int32_t n_batches, int32_t V, const struct glove_plan *plans, const struct glove_plan *plans_dev,
+                            void *ws, size_t ws_bytes, void *stream);
 
 /* (Re)builds r_crec / c_crec of a plan whose other arrays are complete (both must be non-NULL). */
 int glove_plan_fill_records(const glove_plan *plan, void *stream);

@@ -327,6 +327,73 @@ def build_plan(row, col, chunk_cap, heavy_chunks=8, V=None):
 
 
 # --------------------------------------------------------------------------------------
+# Epochs of a resident stream (glove_masters_build / glove_epoch_deal) — integer work, bit-exact target.
+# The reference reshuffles the file every epoch (src/models/data_utils.py:12-21: make_csv_dataset(shuffle=True,
+# num_epochs=None)); WHICH permutation it draws is unseeded and irrelevant — what is restated here is the build's own
+# keyed bijection, so that the device deal can be checked pair for pair.
+# --------------------------------------------------------------------------------------
+def _feistel_mix(x, k):
+    """glove_common.h feistel_mix on uint32 arrays (wrap-around arithmetic)."""
+    x = ((x.astype(np.uint64) + np.uint64(k)) & np.uint64(0xffffffff)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * np.uint64(0x7feb352d)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    return x
+
+
+def feistel_walk(x, n, key):
+    """The keyed bijection of [0, n) of glove_common.h: a Feistel network over b = ceil(log2 n) bits (halves of b // 2 high and
+    b - b // 2 low bits, four rounds alternately rewriting the high half from the low one and back), cycle walking.
+    `key`: 128-bit int (round keys = its four 32-bit words, lowest first)."""
+    b = 2
+    while (1 << b) < n:
+        b += 1
+    hb = b // 2
+    lb = b - hb
+    hmask, lmask = np.uint32((1 << hb) - 1), np.uint32((1 << lb) - 1)
+    ks = [(key >> (32 * r)) & 0xffffffff for r in range(4)]
+    x = np.asarray(x, np.uint64).copy()
+    todo = np.ones(x.shape, bool)
+    while todo.any():
+        v = x[todo]
+        H, L = (v >> np.uint64(lb)).astype(np.uint32), (v & np.uint64(lmask)).astype(np.uint32)
+        H = H ^ (_feistel_mix(L, ks[0]) & hmask)
+        L = L ^ (_feistel_mix(H, ks[1]) & lmask)
+        H = H ^ (_feistel_mix(L, ks[2]) & hmask)
+        L = L ^ (_feistel_mix(H, ks[3]) & lmask)
+        v = (H.astype(np.uint64) << np.uint64(lb)) | L.astype(np.uint64)
+        x[todo] = v
+        todo[todo] = v >= np.uint64(n)
+    return x.astype(np.int64)
+
+
+def build_masters(row, col, V, V_row=None):
+    """The two master orders of a rank's nonzeros: perm_r = positions sorted by (row id, col id, stream index), perm_c by
+    (col id, row id, stream index); link[q] = row-major position of the pair at col-major position q.  Ids outside their
+    table count as id 0 (the unknown token, src/models/estimator.py:26-28) before anything is sorted."""
+    row, col = np.asarray(row, np.int64), np.asarray(col, np.int64)
+    Vr = V if not V_row else V_row
+    row = np.where((row < 0) | (row >= Vr), 0, row)
+    col = np.where((col < 0) | (col >= V), 0, col)
+    perm_r = np.lexsort((np.arange(len(row)), col, row))
+    perm_c = np.lexsort((np.arange(len(row)), row, col))
+    inv_r = np.empty(len(row), np.int64)
+    inv_r[perm_r] = np.arange(len(row))
+    return dict(row=row, col=col, perm_r=perm_r, perm_c=perm_c, link=inv_r[perm_c])
+
+
+def deal_epoch(masters, B, key):
+    """One epoch: the pair at row-major position p takes seat feistel_walk(p) and belongs to batch seat // B; both orders
+    are stably partitioned by batch number.  Returns the stream indices of the pairs in the row side's and the col side's
+    epoch order: batch k = positions [k B, (k + 1) B) of either, sorted by row id / by col id."""
+    n = len(masters["perm_r"])
+    batch_r = feistel_walk(np.arange(n), n, key) // B              # by row-major position
+    order_r = np.argsort(batch_r, kind="stable")
+    order_c = np.argsort(batch_r[masters["link"]], kind="stable")
+    return masters["perm_r"][order_r], masters["perm_c"][order_c]
+
+
+# --------------------------------------------------------------------------------------
 # Data-side functions (pinned by the importable reference module src/data/text8.py).
 # --------------------------------------------------------------------------------------
 def glove_weight(count, alpha=0.75, x_max=100):

@@ -73,7 +73,8 @@ extern "C" int glove_test_check_plan(const glove_plan *plan, int32_t V, int32_t 
     hipStream_t st = (hipStream_t)stream;
     const int32_t Vr = plan->V_row > 0 ? plan->V_row : V;
     const int nb = (int)((plan->B + 255) / 256 < 2048 ? (plan->B + 255) / 256 : 2048);
-    hipLaunchKernelGGL(check_pairs, dim3(nb), dim3(256), 0, st, *plan, V, Vr, errors8);
+    if (plan->r_partner && plan->c_partner)        // (a plan of a dealt epoch may keep its pair fields in its chunk records only)
+        hipLaunchKernelGGL(check_pairs, dim3(nb), dim3(256), 0, st, *plan, V, Vr, errors8);
     hipLaunchKernelGGL(check_sides, dim3(nb, 2), dim3(256), 0, st, *plan, V, Vr, errors8);
     return (int)hipGetLastError();
 }

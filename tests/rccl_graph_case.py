@@ -60,28 +60,28 @@ def run(hip):
         # ---- reshuffled epochs: single-GPU runner == data-parallel runner through RCCL, graphs on == graphs off
         Br = 1000
         coo = {k: v for k, v in zip(("row", "col", "w", "y"), make_batch(7, 5 * Br + 123, V))}
-        outs = []
+        outs, alive = [], []
         for mode in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("single", "dp eager", "dp graphs", "row-sharded graphs")):
             tabs = tables_from_oracle(t, DeviceTables)
             stream = NonzeroStream(coo, Br, V, backend, "cuda:0", seed=3, static_plans=False)
             if mode == "single":
-                runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, **kw), ahead=3, burst=4)
+                runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, **kw), burst=4, segment=2)
             else:
                 cls = RowShardedStepper if mode.startswith("row") else Stepper
                 st = cls(backend, tabs, kw, Br, 1, dist, exchange="dense" if mode.startswith("dp") else "rows", collectives=True)
                 st.prepare(batch_size=Br)
-                runner = ReshufflingRunner(hip, stream, tabs, st.hyper, ahead=3, burst=4, stepper=st, graphs=mode.endswith("graphs"))
+                runner = ReshufflingRunner(hip, stream, tabs, st.hyper, burst=4, segment=2, stepper=st, graphs=mode.endswith("graphs"))
                 assert runner.graphs_on == mode.endswith("graphs")
             print("reshuffled epochs:", mode, flush=True)
             done = 0
             while done < 23:                             # four and a half epochs of five batches, bursts of up to four
                 done += runner.run(23 - done)
             outs.append((mode, tabs, runner.read_loss()))
-            # as the trainer does at the end of train(): a runner's captured bursts are released before the next runner is
-            # built.  (With the grouped small-batch bursts of the single-GPU runner still alive, the replay of the
-            # row-sharded runner's graph three runners later segfaulted inside hipGraphLaunch; releasing on deletion is too
-            # late: the name is rebound after the next runner has been constructed.)
-            runner.release_graphs()
+            # The runners are deliberately KEPT ALIVE with their graphs while the next ones are built and replayed.  (Round 3:
+            # with the first runner's graphs alive — bursts that captured index builds on forked side streams — the replay
+            # of the fourth runner's graph segfaulted inside hipGraphLaunch; a runner's graphs now hold steps on one stream
+            # only, the builds are ordinary launches: DESIGN.md §7.)
+            alive.append(runner)
         base = outs[0]
         for mode, tabs, loss in outs[1:]:
             exact = mode.startswith("dp")                # the dense data-parallel form on one rank sums in the sparse step's order

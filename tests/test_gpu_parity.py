@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import glove_ref as ref
-from helpers import assert_tables_close, make_batch, oracle_tables, tables_from_oracle, to_dev
+from helpers import assert_tables_close, make_batch, oracle_tables, tables_from_oracle, to_dev, PLAN_ARRAYS, _poison, _assert_plan_equals_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -143,64 +143,6 @@ def test_plan_build_bit_exact(hip, B, V, cap):
     cp = plan.compact()
     assert cp.cap_chunks == max(nc_r, nc_c) and cp.cap_uniq == max(nu_r, nu_c)
     np.testing.assert_array_equal(cp.r_chunk_start.cpu().numpy()[:nc_r + 1], want["r_chunk_start"])
-
-
-PLAN_ARRAYS = ("r_partner", "r_w", "r_y", "r_to_c", "r_chunk_id", "r_chunk_start", "r_uniq_slot", "r_uniq_rec", "c_partner",
-               "c_perm", "c_w", "c_y", "c_chunk_id", "c_chunk_start", "c_uniq_slot", "c_uniq_rec", "heavy", "counts")
-
-
-def _poison(plan, ws):
-    """0xFF into every array of a plan and into the build workspace: -1 as an id or position, NaN as a float — whatever a
-    build leaves unwritten, or expects zeroed from allocation time, shows."""
-    for n in PLAN_ARRAYS + ("r_crec", "c_crec"):
-        t = getattr(plan, n)
-        if t is not None:
-            t.view(torch.uint8).fill_(0xFF)
-    ws.fill_(0xFF)
-
-
-def _assert_plan_equals_oracle(plan, want, B, w, y):
-    counts = plan.counts.cpu().numpy()
-    np.testing.assert_array_equal(counts, want["counts"])
-    nc_r, nu_r, nc_c, nu_c, n_heavy = counts[:5]
-    np.testing.assert_array_equal(np.sort(plan.heavy.cpu().numpy()[:n_heavy]), want["heavy"])
-    for name, exp, n in (("r_partner", want["r_partner"], B), ("c_partner", want["c_partner"], B), ("c_perm", want["c_perm"], B),
-                         ("r_to_c", want["r_to_c"], B), ("r_chunk_id", want["r_chunk_id"], nc_r),
-                         ("r_chunk_start", want["r_chunk_start"], nc_r + 1), ("r_uniq_slot", want["r_uniq_slot"], nu_r + 1),
-                         ("c_chunk_id", want["c_chunk_id"], nc_c), ("c_chunk_start", want["c_chunk_start"], nc_c + 1),
-                         ("c_uniq_slot", want["c_uniq_slot"], nu_c + 1)):
-        if getattr(plan, name) is not None:                     # (c_perm / r_to_c are optional: Plan(links=False))
-            np.testing.assert_array_equal(getattr(plan, name).cpu().numpy()[:n], exp, err_msg=name)
-    np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
-    np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
-    np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
-    np.testing.assert_array_equal(plan.c_y.cpu().numpy()[:B], y[want["perm_r"]][want["c_perm"]])
-    if plan.r_crec is None:
-        return
-    # per-chunk records: every header, every pair slot, and the padding of the blocks a reader touches (weight 0, valid id)
-    capP = (plan.chunk_cap + 7) // 8 * 8
-    rd = 4 + 3 * capP
-    wr, yr = w[want["perm_r"]], y[want["perm_r"]]
-    for side, nc, partner, ww, yy in (("r", nc_r, want["r_partner"], wr, yr), ("c", nc_c, want["c_partner"], wr[want["c_perm"]], yr[want["c_perm"]])):
-        ids, starts = np.asarray(want[side + "_chunk_id"]), np.asarray(want[side + "_chunk_start"])
-        rec = plan.records(side, nc).cpu().numpy()
-        n = np.diff(starts)
-        first = np.r_[True, ids[1:] != ids[:-1]]
-        run_id = np.cumsum(first) - 1
-        run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
-        np.testing.assert_array_equal(rec[:, 0], ids, err_msg=side + " record id")
-        np.testing.assert_array_equal(rec[:, 1], n, err_msg=side + " record pairs")
-        np.testing.assert_array_equal(rec[:, 2], run_id, err_msg=side + " record id position")
-        np.testing.assert_array_equal(rec[:, 3].view(np.uint32), (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31),
-                                      err_msg=side + " record chunks-behind word")
-        blocks = rec[:, 4:].reshape(nc, capP // 8, 3, 8)
-        slot = np.arange(capP)[None, :]
-        used, padding = slot < n[:, None], (slot >= n[:, None]) & (slot < ((n + 7) // 8 * 8)[:, None])
-        fields = [blocks[:, :, f, :].reshape(nc, capP) for f in range(3)]
-        np.testing.assert_array_equal(fields[0][used], partner, err_msg=side + " record partners")
-        np.testing.assert_array_equal(fields[1][used].view(np.float32), ww, err_msg=side + " record weights")
-        np.testing.assert_array_equal(fields[2][used].view(np.float32), yy, err_msg=side + " record values")
-        assert (fields[1][padding].view(np.float32) == 0).all() and ((fields[0][padding] >= 0) & (fields[0][padding] < plan.V)).all()
 
 
 @pytest.mark.parametrize("B,V,cap", [(1000, 300, 8), (4096, 12000, 16), (9000, 97, 3), (131072, 10000, 16), (70000, 300000, 32),
