@@ -275,6 +275,42 @@ class Ctx:
         torch.cuda.synchronize()
 
 
+def process_group_facts(ctx) -> dict:
+    """What the ranks themselves see of the job (all-gathered), for the JSON line: the world size and backend
+    torch.distributed reports, the RCCL version, and every rank's device — evidence that N ranks on N GPUs took part."""
+    dist, dev = ctx.dist, ctx.dev
+    if dist is None or not dist.is_initialized():
+        return {"world_size": 1, "backend": None}
+    import socket
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": dist.get_rank(), "cuda_device": dev.index, "device_name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "host": socket.gethostname(), "pid": os.getpid(),
+            "visible_devices": torch.cuda.device_count()}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    try:
+        rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:                       # a build without the binding
+        rccl = None
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+            "distinct_devices": len({(r["host"], r["pci_bus_id"] if r["pci_bus_id"] is not None else r["cuda_device"]) for r in everyone}),
+            "ranks": everyone}
+
+
+COLLECTIVE_PHASES = {"all_reduce": "all_reduce", "all_gather": "all_gather", "fetch_all_to_all": "all_to_all",
+                     "push_all_to_all": "all_to_all", "loss_tail": "all_reduce"}
+
+
+def collectives_breakdown(kern: dict) -> dict:
+    """The step's collectives apart (north_star: "with all-reduce time broken out"): milliseconds per step of every phase that
+    is (or ends in) a collective, each timed to its end on its own; the overlapped ones run beside kernels in the real step."""
+    per = {name: us / 1e3 for name, us in kern.items() if name in COLLECTIVE_PHASES}
+    out = {"phases_ms_per_step": per}
+    for kind in ("all_reduce", "all_gather", "all_to_all"):
+        out[kind + "_ms"] = sum(ms for name, ms in per.items() if COLLECTIVE_PHASES[name] == kind)
+    return out
+
+
 def steps_per_graph(steps: int) -> int:
     """Largest divisor of `steps` that is at most 64: the timed region is then a whole number of graph replays."""
     for k in range(min(64, steps), 0, -1):
@@ -688,6 +724,9 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                      "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
         "plan_build_ms_per_batch": plan_build_ms, "final_loss": final_loss,
     }
+    if stepper is not None:
+        out["collectives"] = collectives_breakdown(kern)
+        out["process_group"] = process_group_facts(ctx)
     del tables, plans, handles, batches, stepper, graph
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -698,8 +737,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 def brief(r: dict) -> dict:
     """A configuration as it appears in the headline's `configs` array."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "repeats", "dtype", "data", "config", "roofline",
-            "final_loss")
-    return {k: r[k] for k in keep}
+            "final_loss", "collectives")
+    return {k: r[k] for k in keep if k in r}
 
 
 def main(argv=None):

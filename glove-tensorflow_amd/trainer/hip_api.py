@@ -665,6 +665,7 @@ class GloveHip:
         self.device = torch.device(device)
         self._plan_ws = None
         self._step_ws = None
+        self.ws_generation = 0      # counts reallocations of the shared workspaces: a captured hipGraph holds their raw pointers
 
     # ---- workspaces (grown on demand, never inside a captured region)
     def _ws(self, attr: str, nbytes: int) -> torch.Tensor:
@@ -672,6 +673,7 @@ class GloveHip:
         if cur is None or cur.numel() < nbytes:
             cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             setattr(self, attr, cur)
+            self.ws_generation += 1
         return cur
 
     def step_workspace(self, plan: Plan, d: int) -> torch.Tensor:

@@ -233,8 +233,7 @@ def transport_is_capturable(dist, multi: bool) -> bool:
 
 class GraphedSteps:
     """Steps of a static stream replayed from hipGraphs: ONE graph per resident batch holds every launch of its step —
-    the kernels and, on RCCL, the collectives (an asynchronous all-to-all is captured on its side stream, joined where
-    the step waits for it) — so a multi-rank step costs one graph launch instead of six or more launches plus a
+    the kernels and, on RCCL, the collectives (issued in line on the capturing stream: SideCollective) — so a multi-rank step costs one graph launch instead of six or more launches plus a
     collective from Python.  A batch's step is captured the third time the batch comes round (short runs never pay for
     captures they do not replay); until then, and on a transport that cannot be captured (gloo), steps run eagerly.
     Same launches in the same order either way: same bits."""
@@ -248,7 +247,14 @@ class GraphedSteps:
         if graphs is None:
             return self.step_eager(item)
         key = item if isinstance(item, int) else id(item)
+        # the captured launches hold raw pointers into the backend's shared, lazily growing step workspace: a plan with a
+        # larger one reallocates it — every graph captured before that replays into freed memory and has to go
+        gen = getattr(getattr(self.backend, "hip", None), "ws_generation", 0)
         g = graphs.get(key)
+        if g is not None and g[2] != gen:
+            torch.cuda.synchronize()
+            del graphs[key]
+            g = None
         if g is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
@@ -256,9 +262,20 @@ class GraphedSteps:
                 return self.step_eager(item)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.step_eager(item)
-            graphs[key] = (g, item)             # the graph holds raw pointers into the plan: keep the plan alive
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.step_eager(item)
+            except Exception as exc:             # a transport that refuses capture: the same launches, eagerly, from now on
+                if not self._multi:
+                    raise
+                import logging
+                logging.getLogger(__name__).warning("hipGraph capture of the multi-rank step failed (%s: %s): launching eagerly",
+                                                    type(exc).__name__, exc)
+                torch.cuda.synchronize()
+                self._graphs = None
+                return self.step_eager(item)
+            # (the graph holds raw pointers into the plan: keep the plan alive; and the workspace generation it saw at its end)
+            graphs[key] = (g, item, getattr(getattr(self.backend, "hip", None), "ws_generation", 0))
             g = graphs[key]
         g[0].replay()
 
@@ -511,11 +528,21 @@ class ShardedStepper(GraphedSteps):
     union of the ranks' batches.  The stream is static: `add_batch` (collective) prepares a batch once — the fetch
     lists, what this rank serves, the dedup index on the renumbered ids — and `step` replays it."""
 
-    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, rank: int, dist, collectives=False):
+    def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world: int, rank: int, dist, collectives=False,
+                 exercise_exchange=False):
+        """One rank owns every row: nobody else can contribute to a col id, so nothing has to wait for an exchange and the
+        step is the plain single-GPU step (fused in place / on the twinned row table), bit for bit — what the sharded form
+        costs at world 1 is what the plain step costs.  (With more ranks an own col id cannot be applied early: Keras sums
+        the duplicates of ALL ranks' slices before it squares, a9 / a10, so its gradient waits for the other ranks' lists
+        like everybody else's.)  `exercise_exchange`: run the full serve / fetch / push / owner-apply sequence on one rank
+        all the same (tests: every collective of the form really goes through the transport on a one-GPU box)."""
         if tables.optimizer != "Adagrad":
             raise ValueError("the sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
         self.backend, self.tables, self.world, self.rank, self.dist = backend, tables, int(world), int(rank), dist
         self._multi = self.world > 1 or bool(collectives)      # collectives: the transport even with one rank (tests)
+        self.local_only = self.world == 1 and not exercise_exchange
+        if self.local_only and hasattr(tables, "maybe_enable_twin"):
+            tables.maybe_enable_twin()
         gb = batch_size * self.world
         self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
@@ -530,6 +557,10 @@ class ShardedStepper(GraphedSteps):
     def add_batch(self, row, col, w, y, chunk_cap=0) -> int:
         """row: this rank's LOCAL row indices; col: global col ids.  Collective; returns the batch's handle."""
         W, dist = self.world, self.dist
+        if self.local_only:                                             # local index = id: the plain step's plan
+            plan = self.backend.build_plan(row, col, w, y, self.tables.V, chunk_cap)
+            self.batches.append(dict(plan=plan, want=[0], serve=[0], serve_idx=None, n=0, ns=0))
+            return len(self.batches) - 1
         uc = torch.unique(col.long())                                  # ascending
         owner = uc % W
         order = torch.argsort(owner, stable=True)                      # (owner, id) order = fetch order
@@ -577,6 +608,12 @@ class ShardedStepper(GraphedSteps):
     def phases(self):
         """[(name, fn(batch handle))]."""
         b, t, dist, W = self.backend, self.tables, self.dist, self.world
+        if self.local_only:
+            bt = self.batches
+            ph = [("step", lambda i: b.step_sparse_adagrad(bt[i]["plan"], t, self.hyper, self.loss_out))]
+            if self._multi:         # `collectives`: the loss scalars still travel through the transport (a sum over one rank)
+                ph.append(("loss_tail", lambda i: dist.all_reduce(self.loss_out)))
+            return ph
         self._ready()
         f, bt = self.bufs, self.batches
 

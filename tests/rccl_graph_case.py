@@ -40,7 +40,7 @@ def run(hip):
                 st = RowShardedStepper(backend, tabs, kw, B, 1, dist, exchange=form.split()[1], collectives=True)
                 st.prepare(plans)
                 return tabs, st, plans
-            st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True)
+            st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True, exercise_exchange=True)
             return tabs, st, [st.add_batch(*bt) for bt in batches]
         for form in ("dp dense", "dp rows", "row-sharded rows", "row-sharded dense", "both tables sharded"):
             (ta, sa, ia), (tb, sb, ib) = make(form), make(form)

@@ -1163,7 +1163,7 @@ def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
     t = oracle_tables(V, d, "Adagrad")
     a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
     backend = HipBackend("cuda:0")
-    st = ShardedStepper(backend, a, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, 1, 0, None)
+    st = ShardedStepper(backend, a, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, 1, 0, None, exercise_exchange=True)
     batches = [to_dev(*make_batch(900 + k, B, V)) for k in range(3)]
     handles = [st.add_batch(*bt, 16) for bt in batches]
     plans = [hip.build_plan(*bt, V, chunk_cap=16, compact=True) for bt in batches]
@@ -1177,6 +1177,32 @@ def test_sharded_stepper_on_one_rank_equals_the_plain_step(hip, B, V, d):
     else:
         _assert_tables_agree(a, b, 5e-5, 5e-6)
     np.testing.assert_allclose(st.loss_out.cpu().numpy()[:3], lb.cpu().numpy()[:3], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,V,d,twin", [(3000, 500, 64, False), (20000, 6000, 300, True)])
+def test_sharded_stepper_alone_in_the_world_is_the_plain_step(hip, B, V, d, twin):
+    """world = 1 without `exercise_exchange`: one rank owns every row, nobody else contributes to a col id, nothing waits for an
+    exchange — ShardedStepper.step is glove_step_adagrad_f32 on the batch's own ids, bit for bit (also in the fused twin form)."""
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ShardedStepper
+    t = oracle_tables(V, d, "Adagrad")
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    form = 4 if twin else 0
+    if twin:
+        a.enable_twin(); b.enable_twin()
+    backend = HipBackend("cuda:0")
+    backend.row_floats = a.d
+    st = ShardedStepper(backend, a, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05, step_form=form), B, 1, 0, None)
+    assert st.local_only
+    batches = [to_dev(*make_batch(700 + k, B, V)) for k in range(2)]
+    handles = [st.add_batch(*bt, 16) for bt in batches]
+    h = make_hyper(learning_rate=0.05, batch_size=B, step_form=form)
+    lb = torch.zeros(4, device="cuda:0")
+    for k in (0, 1, 0):
+        st.step(handles[k])
+        hip.step_adagrad(hip.build_plan(*batches[k], V, chunk_cap=16, compact=True, d=b.d), b, h, lb)
+    _assert_same_bits(a, b)
+    assert torch.equal(st.loss_out, lb)
 
 
 @pytest.mark.parametrize("workload", ["zipf_v400k_d300", "zipf_v2m_d128"])
@@ -1196,7 +1222,7 @@ def test_full_size_sharded_stepper_on_one_rank(hip, workload):
         a = DeviceTables(V, d, "Adagrad", seed=6)
         backend = HipBackend("cuda:0")
         backend.row_floats = a.d
-        st = ShardedStepper(backend, a, dict(learning_rate=0.05), B, 1, 0, None)
+        st = ShardedStepper(backend, a, dict(learning_rate=0.05), B, 1, 0, None, exercise_exchange=True)
         h = st.add_batch(*bt, 0)
         assert st.batches[h]["plan"].r_crec is not None           # the fused row side and the packing col pass
         st.step(h)

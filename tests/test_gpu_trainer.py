@@ -167,7 +167,7 @@ def test_exchange_forms_through_rccl_with_one_rank(hip):
         assert not st.rows and "all_reduce" in dict(st.phases())
         runs["row-sharded, dense"] = (tabs, st, plans)
         tabs = tables_from_oracle(t, DeviceTables)
-        st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True)
+        st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True, exercise_exchange=True)
         handles = [st.add_batch(*bt) for bt in batches]
         runs["both tables sharded"] = (tabs, st, handles)
         for s in range(steps):
@@ -300,7 +300,7 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     job = tmp_path / "job"
     argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
             "--embedding-size", "32", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
-            "--train-steps", "60", "--log-every", "10"]                # unseeded: rank 0 draws the seed for both
+            "--train-steps", "60", "--log-every", "10", "--seed", "21", "--save-checkpoints-secs", "0"]    # (an eval pass at every logging point)
     mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(tmp_path)), nprocs=2, join=True)
     a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
     for n in ("R", "C", "br", "bc"):
@@ -308,12 +308,11 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     assert a["g"] == b["g"] and a["step"] == b["step"] == 60
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
     assert [r["global_step"] for r in log] == [10, 20, 30, 40, 50, 60]
-    # a log line is the loss of ONE batch of 128 pairs (the run is unseeded and the batches are reshuffled): ~ 4 at step 10,
-    # ~ 2 +- 0.4 by step 50 — the mean of the last two lines against the first is far outside that noise
-    assert (log[-1]["loss"] + log[-2]["loss"]) / 2 < log[0]["loss"]
+    # (a log line is the loss of ONE batch of 128 pairs: too noisy to order; the eval pass weighs the whole file)
+    assert all(np.isfinite(r["loss"]) for r in log)
     assert (job / "model.ckpt-60.pt").exists()
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
-    assert ev[-1]["global_step"] == 60 and ev[-1]["average_loss"] > 0
+    assert ev[0]["global_step"] <= 10 and ev[-1]["global_step"] == 60 and 0 < ev[-1]["average_loss"] < ev[0]["average_loss"]
 
 
 def test_two_rank_trainer_with_touched_rows_exchange_on_one_gpu(hip, tmp_path):
@@ -553,9 +552,10 @@ def test_cli_with_full_epoch_shuffle(hip, tmp_path):
     estimator.main(["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
                     "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "64",
                     "--train-steps", "150", "--log-every", "25", "--seed", "5", "--epoch-shuffle", "full",
-                    "--index-segment", "3"])
+                    "--index-segment", "3", "--save-checkpoints-secs", "0"])
     log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
-    assert log[-1]["global_step"] == 150 and log[-1]["loss"] < log[0]["loss"]
+    ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+    assert log[-1]["global_step"] == 150 and ev[-1]["global_step"] == 150 and ev[-1]["average_loss"] < ev[0]["average_loss"]
     assert all(b["global_step"] - a["global_step"] < 50 for a, b in zip(log, log[1:]))     # a line per crossed multiple of --log-every
     assert (job / "model.ckpt-150.pt").exists()
 
@@ -590,3 +590,45 @@ def test_two_rank_row_sharded_trainer_on_one_gpu(hip, tmp_path):
     # a single process resumes from it as an ordinary (unsharded) run
     estimator.main([x for x in argv if x != "--row-sharded"][:-6] + ["--train-steps", "70", "--log-every", "10", "--seed", "9"])
     assert (job / "model.ckpt-70.pt").exists()
+
+
+def test_train_then_train_more_in_one_interpreter(hip, tmp_path):
+    """A process that trains, keeps the first Estimator (stream, tables, staging plans) alive and trains on with a second one
+    — a notebook, or train -> evaluate -> train: the second reshuffling runner captures and replays its hipGraphs beside
+    whatever the first left behind, resumes from the first's checkpoint and reaches the absolute step count.  A third runner
+    is built and stepped while the second one's graphs are still alive (round 3: a replay segfaulted in that situation when
+    graphs held index builds on forked side streams)."""
+    from trainer import estimator
+    from trainer.config_utils import parse_args
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ReshufflingRunner
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "16", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "32",
+            "--log-every", "40", "--seed", "2", "--skip-eval"]
+    first = estimator.Estimator(parse_args(argv + ["--train-steps", "80"]))
+    first.train(80)
+    second = estimator.Estimator(parse_args(argv + ["--train-steps", "200"]))
+    assert second.model.tables.global_step == 80                  # resumed from the first one's checkpoint
+    second.train(200)
+    assert second.model.tables.global_step == 200 and first.model.tables.global_step == 80
+    # runners by hand, graphs kept alive across each other
+    backend = HipBackend("cuda:0")
+    coo = {k: getattr(first.stream(), k).cpu().numpy() for k in ("row", "col", "w", "y")}
+    stream_a, stream_b = (NonzeroStream(coo, 32, first.vocab_size, backend, "cuda:0", seed=s, static_plans=False) for s in (1, 2))
+    ta, tb = DeviceTables(first.vocab_size, 16, "Adagrad", seed=1), DeviceTables(first.vocab_size, 16, "Adagrad", seed=1)
+    ra = ReshufflingRunner(hip, stream_a, ta, make_hyper(batch_size=32, learning_rate=0.05), burst=8, segment=4)
+    done = 0
+    while done < 50:
+        done += ra.run(50 - done)
+    assert ra.graphs
+    rb = ReshufflingRunner(hip, stream_b, tb, make_hyper(batch_size=32, learning_rate=0.05), burst=8, segment=4)
+    for _ in range(3):
+        for r in (rb, ra):                                          # interleaved replays of both runners' graphs
+            done = 0
+            while done < 30:
+                done += r.run(30 - done)
+    assert ta.global_step == 140 and tb.global_step == 90
+    assert np.isfinite(ra.read_loss()["loss"]) and np.isfinite(rb.read_loss()["loss"])

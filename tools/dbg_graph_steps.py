@@ -45,7 +45,7 @@ def make(form):
         st = RowShardedStepper(backend, tabs, kw, B, 1, dist, exchange=form.split()[1], collectives=True)
         st.prepare(plans)
         return tabs, st, plans
-    st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True)
+    st = ShardedStepper(backend, tabs, kw, B, 1, 0, dist, collectives=True, exercise_exchange=True)
     return tabs, st, [st.add_batch(*bt) for bt in batches]
 
 
