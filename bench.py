@@ -85,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--collectives", action="store_true",
                     help="with --row-sharded / --force-dense on one GPU: issue every collective through RCCL although there is one rank")
-    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table")
+    ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table, 5 tagged step (latency-bound regime)")
     ap.add_argument("--static-index", action="store_true",
                     help="one GPU: the trainer's --epoch-shuffle static (the index of every resident batch built at load, "
                          "outside the clock) instead of its default, epochs dealt and indexed inside the timed region")
@@ -396,6 +396,8 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     backend.row_floats = tables.d
     if step_form == 4:
         tables.enable_twin()
+    if step_form == 5:
+        tables.enable_tags()
     t0 = time.perf_counter()
     stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False)
     torch.cuda.synchronize()
@@ -426,8 +428,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     slot = runner.slots[0]
 
     def steps_once():
-        for j in range(n0):
-            runner._step(slot.plans[j])
+        runner._steps(slot.plans[:n0])
     steps_once()
     torch.cuda.synchronize()
     kg = torch.cuda.CUDAGraph()               # replayed, so that kernels shorter than a host call are timed on the GPU's clock
@@ -517,6 +518,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     tables = DeviceTables(V, d, optimizer, device=dev, seed=1, V_row=V_row, V_col=V_col)   # identical replicas on every rank
     if mode == "single" and step_form == 4:
         tables.enable_twin()
+    if mode == "single" and step_form == 5:
+        tables.enable_tags()
     backend = HipBackend(dev)
     backend.hip = hip
     backend.row_floats = tables.d
@@ -551,6 +554,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
         stepper.prepare(plans)
 
+    if mode == "single" and step_form in (0, 5) and not adam and plans[0].r_crec is not None:
+        tables.maybe_enable_tags(B)         # small batches on small tables: the tagged step (as Stepper does)
     if mode == "single" and step_form == 0 and not adam and plans[0].r_crec is not None and \
             (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES:
         tables.maybe_enable_twin()          # the library will take a fused form: give it the twinned row table (as Stepper does)
@@ -592,8 +597,13 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                for i in range(spg):
-                    step(i)
+                if stepper is None and not adam:
+                    # as the trainer's static mode issues them (Stepper.step_many): one host call; on step-tagged tables the
+                    # library chains consecutive small batches, one launch per step
+                    hip.steps_adagrad([plans[i % nb] for i in range(spg)], tables, hyper, loss_out, ws=ws)
+                else:
+                    for i in range(spg):
+                        step(i)
         except Exception as exc:             # a transport that refuses capture: the same steps, launched eagerly
             if mode == "single":
                 raise
@@ -640,7 +650,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         else:
             fused_auto = plans[0].r_crec is not None and (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES
             if form == 0:
-                form = (4 if tables.R_ver is not None else 3) if fused_auto else 1
+                form = 5 if tables.R_tag is not None and B <= 2048 else (4 if tables.R_ver is not None else 3) if fused_auto else 1
             if form == 1 or plans[0].r_crec is None:
                 calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)      # row side + col side, one launch
                 calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)

@@ -1187,6 +1187,367 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The sparse Adagrad step for the latency-bound regime (GLOVE_STEP_TAGGED): ONE launch does all the work on the rows — forward,
+// gradients AND the Adagrad applies — and a one-workgroup epilogue launch does the once-per-step scalars.  The reference's
+// default batch of 1,024 pairs (reference configs/app.ini:39-53) runs the two-launch form as two ramps, a kernel boundary and
+// four dependent memory round trips (record -> rows -> partial rows | id record -> partial + table rows -> rows), nothing in
+// them is bandwidth; here a chunk is record -> rows -> new row.
+// What lets one launch both read every row as it was when the step began and update rows: both tables are twinned and
+// step-tagged (glove_tables.R_tag / C_tag).  tag[u] = 0, or (1 + step that wrote row u) << 1 | the copy it wrote.  During step t
+// a reader takes the copy the tag names unless the tag says "written in step t": then it takes the OTHER copy — the pre-step
+// row, which nobody touches during step t.  The writer (the one lane group that owns row u in this step) puts the new row into
+// the copy it did not read and then stores the tag.  A racing reader sees the old tag or the new one; either way it is led to
+// the pre-step row.  No barrier, no fence, no atomic (a device-scope fence costs 3 - 6 us on this chip: measured).
+//   * the tag is not waited for: the own row and the first trip's partner rows are requested in BOTH copies together with
+//     their tags (one round trip; the tables of this regime live in the caches) and the copy is chosen in registers;
+//   * an id's chunks are all done by the lane group that holds its FIRST chunk, one after the other (the groups that were
+//     dealt its other chunks skip them): per-chunk sums added in chunk order — for ids up to plan.heavy_chunks chunks the very
+//     order of the two-launch form's apply, bit for bit — then G = sum + activity-L2 term and Adagrad, expression for
+//     expression as AdagradApply.  No partial rows in memory.  (An id of many chunks is a long serial chain: the form is for
+//     batches whose ids have few chunks — GLOVE_STEP_AUTO takes it up to 2,048 pairs.)
+//   * every row-side workgroup leaves its loss partials; scalars_kernel (one workgroup, behind it on the stream) sums them in
+//     the fixed order of the two-launch form, updates the global bias, writes the loss and advances global_step — the one
+//     dependency between consecutive steps that needs all pairs, i.e. a grid-wide reduction: a kernel boundary is the
+//     cheapest one there is.
+// ------------------------------------------------------------------------------------------
+struct OneSide {
+    const int32_t *crec;
+    float *own, *own_bias;              // this side's table and bias vector, twinned
+    const float *other, *other_bias;    // the partner table, twinned
+    float *S1, *S1b;                    // Adagrad accumulators (never twinned: only the id's owner touches them)
+    uint64_t *own_tag;
+    const uint64_t *other_tag;
+    int own_twin, other_twin;           // rows between the two copies
+    int n_host, count_index, capP, cap_chunks;
+};
+
+// which copy (0 / 1) holds the row as it was when step t began
+__device__ inline uint32_t pre_step_copy(uint64_t tag, uint64_t t1 /* 1 + t */) { return (uint32_t)(tag & 1ull) ^ ((tag >> 1) == t1 ? 1u : 0u); }
+
+// A chain record = what one step of a chain leaves for the next: [0] global bias and [1] its accumulator as they were when the
+// step BEGAN, [8 + 4 b ..] the loss partials of its row-side workgroup b.
+constexpr int kChainHead = 8;
+
+template <int LPR, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_step_kernel(
+    const int32_t *__restrict__ counts, OneSide rowside, OneSide colside, int row_blocks, const float *__restrict__ scalars,
+    const int64_t *__restrict__ step, int d4, float inv_batch, int head, float neg_factor, StepConsts kc,
+    const float *__restrict__ prev, int prev_blocks, float *__restrict__ mine, int chain_i)
+{
+    constexpr int GPB = kBlock / LPR;
+    constexpr int U = PassUnroll<NV>::value;
+    constexpr int kRecStride = 4 + 3 * kChunkMax + 4;
+    __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * kRecStride];
+    uint32_t *rec = fld_raw + (threadIdx.x / LPR) * kRecStride;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool is_row = (int)blockIdx.x < row_blocks;
+    const OneSide &sd = is_row ? rowside : colside;
+    const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
+    const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
+    // the number of chunks is not waited for either (a plan refilled on the device keeps it in memory), nor the bias below: the
+    // group's first record is requested before anything else (records exist up to the plan's capacity; one that lies behind
+    // the side's last chunk is dropped unread)
+    constexpr int kPre = (1 + 3 * kChunkMax / 4 + LPR - 1) / LPR;
+    uint4 pre[kPre];
+    {
+        const int jf = bid * GPB + grp;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)(jf < sd.cap_chunks ? jf : sd.cap_chunks - 1) * rec_stride_q(sd.capP);
+        const int rq0 = 1 + 3 * sd.capP / 4;
+#pragma unroll
+        for (int x = 0; x < kPre; ++x) {
+            const int f = lg + x * LPR;
+            pre[x] = rp[rec_gq(f < rq0 ? f : 0)];
+        }
+    }
+    const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
+    // global_step stands still during a chain (its last launch's epilogue advances it): this is step *step + chain_i
+    const uint64_t t1 = (uint64_t)(*step) + (uint64_t)chain_i + 1ull;
+    float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
+    const int capP = sd.capP;
+    const int rq = 1 + 3 * capP / 4;
+    const int sq = rec_stride_q(capP);
+    // ---- the global bias of THIS step.  The one thing a step needs of ALL pairs of the step before is sum e (the global bias'
+    // gradient): a grid-wide reduction.  Instead of a launch (or a device-scope fence: 3 - 6 us) between the steps, every
+    // workgroup of step i derives the bias itself — from the bias step i - 1 began with and the loss partials its row-side
+    // workgroups left (prev), summed in the fixed order of the two-launch form: same bits in every workgroup — and leaves what
+    // it began with, and its own partials, in a record of its own (mine), which nobody of this launch reads.
+    __shared__ float s_g[2];
+    if (prev) {
+        float tot[kPartials];
+        sum_blockpart(prev + kChainHead, prev_blocks, tot);
+        if (threadIdx.x == 0) {
+            const float g0 = prev[0];
+            const float dg = tot[3] + 2.0f * kc.m * kc.l2 * g0;
+            float gn = g0, Ag = prev[1];
+            adagrad_elem(gn, Ag, dg, kc.lr, kc.eps);
+            s_g[0] = gn; s_g[1] = Ag;
+        }
+    } else if (threadIdx.x == 0) {
+        s_g[0] = scalars[0]; s_g[1] = scalars[1];
+    }
+    __syncthreads();
+    const float g = s_g[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mine[0] = g; mine[1] = s_g[1]; }
+    float *blockpart = mine + kChainHead;
+
+    for (int j0 = bid * GPB + grp; j0 < n_chunks; j0 += nblk * GPB) {
+        // ---- round trip 1: the record (descriptor + pair fields) in contiguous 16-B loads -> LDS as is
+        {
+            uint4 *lrec = reinterpret_cast<uint4 *>(rec);
+            if (j0 == bid * GPB + grp) {                        // (requested at the kernel's start)
+#pragma unroll
+                for (int x = 0; x < kPre; ++x) {
+                    const int f = lg + x * LPR;
+                    if (f < rq) lrec[f] = pre[x];
+                }
+            } else {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j0 * sq;
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[rec_gq(f)];
+            }
+        }
+        uint4 hdr = *reinterpret_cast<const uint4 *>(rec);      // same wave wrote it: LDS ops of one wave complete in order
+        if (!(hdr.w >> 31)) continue;                           // not the first chunk of its id: the group that holds the first one does it
+        const int32_t u = (int32_t)hdr.x;
+        const int chunks = 1 + (int)(hdr.w & 0x7fffffffu);
+        // ---- round trip 2: the own row in both copies, its tag, the accumulator (and, below, the first trip's partner rows)
+        f4 r[NV], r1[NV], A[NV], G[NV];
+        load_row<LPR, NV>(r, sd.own, u, d4, lg);
+        load_row<LPR, NV>(r1, sd.own, u + sd.own_twin, d4, lg);
+        const uint64_t own_tg = sd.own_tag[u];
+        const float ob0 = sd.own_bias[u], ob1 = sd.own_bias[u + sd.own_twin];
+        load_row<LPR, NV>(A, sd.S1, u, d4, lg);
+        float Ab = sd.S1b[u];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) G[k] = f4{0.f, 0.f, 0.f, 0.f};
+        float Gb = 0.f, own_b = 0.f, bg = 0.f;
+        uint32_t own_copy = 0;
+        int pairs = 0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int j = j0 + ch;
+            if (ch > 0) {                                       // the id's next chunk: its record (a round trip of its own)
+                const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * sq;
+                uint4 *lrec = reinterpret_cast<uint4 *>(rec);
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[rec_gq(f)];
+                hdr = *reinterpret_cast<const uint4 *>(rec);
+            }
+            const int n = (int)hdr.y;
+            pairs += n;
+            // the tags of all partners of the chunk: lane t looks pair t's up and leaves the row that is current in the record
+            // (consumed from the second trip on; the first trip does not wait for it)
+            uint64_t ptag[(kChunkMax + LPR - 1) / LPR];
+#pragma unroll
+            for (int x = 0; x < (kChunkMax + LPR - 1) / LPR; ++x) {
+                const int t = lg + x * LPR;
+                ptag[x] = t < n ? sd.other_tag[rec[rec_pair(t)]] : 0ull;
+            }
+            f4 acc[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+            float se_c = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
+            for (int q0 = 0; q0 < n; q0 += U) {
+                int32_t col[U];
+                float w2[U], yq[U];
+#pragma unroll
+                for (int a4 = 0; a4 < U; a4 += 4) {
+                    const int rp0 = rec_pair(q0 + a4);
+                    const uint4 pc = *reinterpret_cast<const uint4 *>(&rec[rp0]);
+                    const uint4 pw = *reinterpret_cast<const uint4 *>(&rec[rp0 + kRecPad]);
+                    const uint4 py = *reinterpret_cast<const uint4 *>(&rec[rp0 + 2 * kRecPad]);
+                    col[a4] = (int32_t)pc.x; col[a4 + 1] = (int32_t)pc.y; col[a4 + 2] = (int32_t)pc.z; col[a4 + 3] = (int32_t)pc.w;
+                    const float sc2 = 2.0f * inv_batch;
+                    w2[a4] = sc2 * __uint_as_float(pw.x); w2[a4 + 1] = sc2 * __uint_as_float(pw.y);
+                    w2[a4 + 2] = sc2 * __uint_as_float(pw.z); w2[a4 + 3] = sc2 * __uint_as_float(pw.w);
+                    yq[a4] = __uint_as_float(py.x); yq[a4 + 1] = __uint_as_float(py.y);
+                    yq[a4 + 2] = __uint_as_float(py.z); yq[a4 + 3] = __uint_as_float(py.w);
+                }
+                f4 c[U][NV];
+                float bcv[U];
+                if (q0 == 0) {
+                    // first trip: both copies of every partner row travel with the tags; the choice happens in registers
+                    f4 c1[U][NV];
+                    float b0[U], b1[U];
+#pragma unroll
+                    for (int a = 0; a < U; ++a) {
+                        load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                        load_row_fast<LPR, NV, FULL>(c1[a], sd.other, col[a] + sd.other_twin, d4, lg);
+                        b0[a] = b1[a] = 0.f;
+                        if (lg == 0) {
+                            b0[a] = sd.other_bias[col[a]];
+                            b1[a] = sd.other_bias[col[a] + sd.other_twin];
+                        }
+                    }
+                    if (ch == 0) {                              // (the own row's copy: known with this trip)
+                        own_copy = pre_step_copy(own_tg, t1);
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) r[k] = own_copy ? r1[k] : r[k];
+                        own_b = own_copy ? ob1 : ob0;
+                        bg = own_b + g;
+                    }
+                    // the partners' tags, handed round: pair a of this trip was looked up by lane a % LPR (slot a / LPR)
+#pragma unroll
+                    for (int a = 0; a < U; ++a) {
+                        const uint64_t tg = __shfl(ptag[a / LPR], (int)((threadIdx.x & 63) / LPR * LPR + a % LPR), 64);
+                        const bool second = pre_step_copy(tg, t1) != 0;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) c[a][k] = second ? c1[a][k] : c[a][k];
+                        bcv[a] = second ? b1[a] : b0[a];
+                    }
+                    // later trips read the current row straight away: the record's ids become row numbers
+#pragma unroll
+                    for (int x = 0; x < (kChunkMax + LPR - 1) / LPR; ++x) {
+                        const int t = lg + x * LPR;
+                        if (t < n && t >= U) rec[rec_pair(t)] += pre_step_copy(ptag[x], t1) ? (uint32_t)sd.other_twin : 0u;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) {
+                        load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                        bcv[a] = 0.f;
+                        if (lg == 0) bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sd.other_bias) + (uint32_t)col[a] * 4u);
+                    }
+                }
+                float dp[U], cc[U];
+#pragma unroll
+                for (int a = 0; a < U; ++a) {
+                    dp[a] = 0.f; cc[a] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) { dp[a] += dot4(r[k], c[a][k]); cc[a] += dot4(c[a][k], c[a][k]); }
+                    dp[a] += bcv[a];
+                }
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0xB1>(dp[a]);
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x4E>(dp[a]);
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x141>(dp[a]);
+                if (LPR >= 16) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x140>(dp[a]);
+                }
+                if (LPR >= 32) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 16, 64);
+                }
+                if (LPR >= 64) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 32, 64);
+                }
+#pragma unroll
+                for (int a = 0; a < U; ++a) {
+                    const float valid = (q0 + a < n) ? 1.0f : 0.f;
+                    float e;
+                    if (head == GLOVE_HEAD_REGRESSION) {
+                        const float diff = (dp[a] + bg) - yq[a];
+                        e = w2[a] * diff;
+                        ed += e * diff;
+                    } else {
+                        const float p = dp[a] + bg;
+                        const float en = expf(-fabsf(p));
+                        const float s = (p >= 0.f ? 1.0f : en) / (1.0f + en);
+                        const float lse = log1pf(en);
+                        const float wn = 2.0f * inv_batch * neg_factor * valid * yq[a];
+                        e = 0.5f * (w2[a] * (s - 1.0f) + wn * s);
+                        ed += w2[a] * (fmaxf(-p, 0.f) + lse) + wn * (fmaxf(p, 0.f) + lse);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
+                    se_c += e;
+                    cc_sum += valid * cc[a];
+                    bsq += valid * bcv[a] * bcv[a];
+                }
+            }
+            if (is_row) {
+                float rr = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
+                part[1] += cc_sum + (float)n * rr;
+                if (lg == 0) {
+                    part[0] += ed;
+                    part[2] += bsq + (float)n * own_b * own_b;
+                    part[3] += se_c;
+                }
+            }
+            // the id's sums: chunk sums in chunk order (the first one taken as it is, like the apply launch's traversal)
+            if (ch == 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) G[k] = acc[k];
+                Gb = se_c;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) G[k] += acc[k];
+                Gb += se_c;
+            }
+        }
+        // ---- G = summed gradient + activity-L2 term, then Adagrad (for_each_id + AdagradApply, expression for expression)
+        {
+            float bval = own_b;
+            const float cnt = (float)pairs;
+            const float kcn = kc.kappa * cnt;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) G[k] += kcn * r[k];
+            Gb += kc.kappa_b * cnt * bval;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], G[k], kc.lr, kc.eps);
+            store_row<LPR, NV>(sd.S1, (size_t)u, d4, lg, A);
+            const int32_t new_at = u + (own_copy ? 0 : sd.own_twin);      // the copy nobody reads during this step
+            store_row<LPR, NV>(sd.own, (size_t)new_at, d4, lg, r);
+            if (lg == 0) {
+                adagrad_elem(bval, Ab, Gb, kc.lr, kc.eps);
+                sd.S1b[u] = Ab;
+                sd.own_bias[new_at] = bval;
+                sd.own_tag[u] = t1 << 1 | (uint64_t)(own_copy ^ 1u);
+            }
+        }
+    }
+    if (is_row) {
+        part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
+        block_partials_store(part, blockpart);
+    }
+}
+
+// The end of a chain of n tagged steps: the last step's loss partials -> the loss scalars and the global bias the NEXT step
+// begins with, into the tables; global_step advances by n.  One workgroup.
+__global__ __launch_bounds__(kBlock) void tagged_flush_kernel(float *__restrict__ scalars, int64_t *__restrict__ step,
+                                                              const float *__restrict__ last, int nblocks, int n, StepConsts k,
+                                                              float *__restrict__ loss_out)
+{
+    float tot[kPartials];
+    sum_blockpart(last + kChainHead, nblocks, tot);
+    if (threadIdx.x == 0) {
+        const float g = last[0];
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
+        float gn = g, Ag = last[1];
+        adagrad_elem(gn, Ag, dg, k.lr, k.eps);
+        scalars[1] = Ag;
+        scalars[0] = gn;
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
+        *step += n;
+    }
+}
+
+// Step-tagged twinned tables back to the plain form: rows whose current copy is the second one are copied home, tags cleared
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void untag_kernel(float *__restrict__ W, float *__restrict__ bias, uint64_t *__restrict__ tag,
+                                                       int V, int d4)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int u = blockIdx.x * GPB + grp; u < V; u += gridDim.x * GPB) {
+        const uint64_t tg = tag[u];
+        if (tg == 0) continue;
+        if (tg & 1ull) {
+            f4 v[NV];
+            load_row<LPR, NV>(v, W, u + V, d4, lg);
+            store_row<LPR, NV>(W, (size_t)u, d4, lg, v);
+            if (lg == 0) bias[u] = bias[u + V];
+        }
+        if (lg == 0) tag[u] = 0;
+    }
+}
+
 // Twinned row table back to its plain form: every row whose current copy is the second one is copied into the first,
 // all versions become 0.  Everything but the fused twin step expects this form.
 template <int LPR, int NV>
@@ -1443,6 +1804,8 @@ static int check_common(const glove_plan *p, const glove_tables *t, const glove_
     if (shape.lpr == 0 || pass_shape(t->d / 4).lpr == 0 || p->chunk_cap <= 0) return GLOVE_E_BADARG;
     if ((uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32) || t->V_row < 0 || t->V_row > t->V) return GLOVE_E_BADARG;   // 32-bit row offsets
     if (t->R_ver && 2ull * (uint64_t)(t->V_row > 0 ? t->V_row : t->V) * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;
+    if ((t->R_tag != nullptr) != (t->C_tag != nullptr) || (t->R_tag && t->R_ver)) return GLOVE_E_BADARG;   // tags: both tables, not beside R_ver
+    if (t->R_tag && 2ull * (uint64_t)t->V * (uint64_t)t->d * 4u >= (1ull << 32)) return GLOVE_E_BADARG;
     if (t->d_model < 0 || t->d_model > t->d) return GLOVE_E_BADARG;
     if (p->chunk_cap > kChunkMax) return GLOVE_E_BADARG;
     if (h->head != GLOVE_HEAD_REGRESSION && h->head != GLOVE_HEAD_LOGISTIC) return GLOVE_E_BADARG;
@@ -1556,7 +1919,7 @@ int glove_abi_version(void) { return GLOVE_ABI_VERSION; }
 // brings the table back to that form (one small launch over V_row version bytes plus the rows whose second copy was
 // current; nothing without a twin).  A caller that mixes step forms, or steps and anything else, on one twinned table
 // therefore never reads a stale copy.
-static int plain_table(const glove_tables *t, void *stream) { return t && t->R_ver ? glove_canonicalize_f32(t, stream) : 0; }
+static int plain_table(const glove_tables *t, void *stream) { return t && (t->R_ver || t->R_tag) ? glove_canonicalize_f32(t, stream) : 0; }
 #ifdef GLOVE_STAMPS
 int glove_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
 #endif
@@ -2060,6 +2423,8 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     if (sides_of(h) != 3) return GLOVE_STEP_TWO_LAUNCH;
     if (!p->r_crec || !p->c_crec) return GLOVE_STEP_TWO_LAUNCH;      // the fused forms read the id layout from the chunk records
     if (h->step_form != GLOVE_STEP_AUTO) return h->step_form;
+    // the latency-bound regime on step-tagged tables: everything in one launch
+    if (t->R_tag && t->C_tag && p->B <= 2048) return GLOVE_STEP_TAGGED;     // (measured against the two-launch form, 64 staging plans: 512 / 1,024 / 2,048 pairs -16 / -16 / -13 %, 4,096 +12 %)
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are known on the host for a plan whose build has been synchronised (a resident plan)
     // (a plan refilled on the device every step — a reshuffled epoch — is judged by the most ids its batch can hold)
@@ -2071,10 +2436,70 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 
+// n consecutive tagged steps as chains: one launch per step, the global bias handed from step to step through chain records in
+// the workspace (the tagged form keeps nothing else there: no partial rows), one epilogue launch per chain.
+static int launch_tagged_chain(const glove_plan *const *plans, int n, const glove_tables *t, const glove_hyper *h, void *ws,
+                               size_t ws_bytes, float *loss_out, void *stream)
+{
+    if (!plans || n < 1 || !t || !h || !ws) return GLOVE_E_BADARG;
+    const int d4 = t->d / 4;
+    int most_blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        const glove_plan *p = plans[i];
+        if (int rc = check_common(p, t, h, ws)) return rc;
+        if (!t->R_tag || !t->C_tag || !p->r_crec || !p->c_crec) return GLOVE_E_BADARG;
+        const int rb = rowpass_blocks(p, pass_shape(d4).lpr);
+        most_blocks = rb > most_blocks ? rb : most_blocks;
+    }
+    if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc || sides_of(h) != 3) return GLOVE_E_BADARG;
+    const size_t rec_floats = (size_t)kChainHead + (size_t)kPartials * most_blocks;
+    const size_t fit = ws_bytes / (rec_floats * sizeof(float));
+    if (fit < 1) return GLOVE_E_WORKSPACE;
+    const RowShape shape = pass_shape(d4);
+    const int Vr = v_row(t);
+    const StepConsts kc = make_consts(t, h);
+    hipStream_t st = (hipStream_t)stream;
+    float *recs = (float *)ws;
+    for (int i0 = 0; i0 < n; i0 += (int)fit) {
+        const int m = n - i0 < (int)fit ? n - i0 : (int)fit;
+        int prev_blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            const glove_plan *p = plans[i0 + i];
+            const int row_blocks = rowpass_blocks(p, shape.lpr), nb = 2 * row_blocks;     // the classic passes' grid and chunk assignment
+            OneSide rs, cs;
+            rs.crec = p->r_crec; rs.own = t->R; rs.own_bias = t->br; rs.other = t->C; rs.other_bias = t->bc;
+            rs.S1 = t->s1_R; rs.S1b = t->s1_br; rs.own_tag = t->R_tag; rs.other_tag = t->C_tag; rs.own_twin = Vr; rs.other_twin = t->V;
+            rs.n_host = p->host_counts[0]; rs.count_index = 0; rs.capP = rec_cap(p->chunk_cap);
+            cs.crec = p->c_crec; cs.own = t->C; cs.own_bias = t->bc; cs.other = t->R; cs.other_bias = t->br;
+            cs.S1 = t->s1_C; cs.S1b = t->s1_bc; cs.own_tag = t->C_tag; cs.other_tag = t->R_tag; cs.own_twin = t->V; cs.other_twin = Vr;
+            cs.n_host = p->host_counts[2]; cs.count_index = 2; cs.capP = rs.capP;
+            rs.cap_chunks = cs.cap_chunks = p->cap_chunks > 0 ? p->cap_chunks : 1;
+            const float *prev = i > 0 ? recs + (size_t)(i - 1) * rec_floats : nullptr;
+            float *mine = recs + (size_t)i * rec_floats;
+#define CALL(LPR, NV)                                                                                                           \
+            if (LPR * NV == d4)                                                                                                 \
+                hipLaunchKernelGGL((tagged_step_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, row_blocks, \
+                                   (const float *)t->scalars, (const int64_t *)t->step, d4, h->inv_batch, (int)h->head,        \
+                                   h->neg_factor, kc, prev, prev_blocks, mine, i);                                             \
+            else                                                                                                                \
+                hipLaunchKernelGGL((tagged_step_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, row_blocks, \
+                                   (const float *)t->scalars, (const int64_t *)t->step, d4, h->inv_batch, (int)h->head,        \
+                                   h->neg_factor, kc, prev, prev_blocks, mine, i)
+            GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
+#undef CALL
+            prev_blocks = row_blocks;
+        }
+        hipLaunchKernelGGL(tagged_flush_kernel, dim3(1), dim3(kBlock), 0, st, t->scalars, t->step,
+                           (const float *)(recs + (size_t)(m - 1) * rec_floats), prev_blocks, m, kc, i0 + m == n ? loss_out : nullptr);
+    }
+    return (int)hipGetLastError();
+}
+
 int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                            float *loss_out, void *stream)
 {
     const int form = pick_step_form(p, t, h);
+    if (form == GLOVE_STEP_TAGGED) return launch_tagged_chain(&p, 1, t, h, ws, ws_bytes, loss_out, stream);
     // only the twin form follows the version bytes of a twinned row table: every other form first brings it home
     // (a step of another form behind a twin step would otherwise read and write copy 0 of rows whose current copy is the second)
     if (form != GLOVE_STEP_FUSED_TWIN)
@@ -2129,13 +2554,23 @@ int glove_rowside_step_adagrad_f32(const glove_plan *p, const glove_tables *t, c
 int glove_canonicalize_f32(const glove_tables *t, void *stream)
 {
     if (!t || !t->R || !t->br || t->V <= 0 || t->d <= 0 || (t->d % 4) != 0) return GLOVE_E_BADARG;
-    if (!t->R_ver) return 0;
+    if (!t->R_ver && !t->R_tag) return 0;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
     if (shape.lpr == 0) return GLOVE_E_BADARG;
     const int Vr = v_row(t);
     const int nb = blocks_for(Vr, kBlock / shape.lpr);
     hipStream_t st = (hipStream_t)stream;
+    if (t->R_tag) {                             // step-tagged twins of both tables (the one-launch step)
+        if (!t->C_tag || !t->C || !t->bc || t->R_ver) return GLOVE_E_BADARG;
+        const int nbc = blocks_for(t->V, kBlock / shape.lpr);
+#define CALL(LPR, NV)                                                                                                  \
+        hipLaunchKernelGGL((untag_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, t->R, t->br, t->R_tag, Vr, d4);     \
+        hipLaunchKernelGGL((untag_kernel<LPR, NV>), dim3(nbc), dim3(kBlock), 0, st, t->C, t->bc, t->C_tag, (int)t->V, d4)
+        GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+        return (int)hipGetLastError();
+    }
 #define CALL(LPR, NV) hipLaunchKernelGGL((canonicalize_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, t->R, t->br, t->R_ver, Vr, d4)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
@@ -2146,8 +2581,18 @@ int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glo
                             void *ws, size_t ws_bytes, float *loss_out, void *stream)
 {
     if (!plans || n < 0) return GLOVE_E_BADARG;
-    for (int32_t i = 0; i < n; ++i)
+    // runs of consecutive steps that take the tagged form go out as chains: one launch per step
+    for (int32_t i = 0; i < n;) {
+        int32_t k = i;
+        while (k < n && plans[k] && pick_step_form(plans[k], t, h) == GLOVE_STEP_TAGGED) ++k;
+        if (k > i) {
+            if (int rc = launch_tagged_chain(plans + i, k - i, t, h, ws, ws_bytes, k == n ? loss_out : nullptr, stream)) return rc;
+            i = k;
+            continue;
+        }
         if (int rc = glove_step_adagrad_f32(plans[i], t, h, ws, ws_bytes, i == n - 1 ? loss_out : nullptr, stream)) return rc;
+        ++i;
+    }
     return 0;
 }
 

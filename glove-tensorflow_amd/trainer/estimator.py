@@ -140,6 +140,8 @@ class Estimator:
             hyper_kwargs["step_form"] = int(p["step_form"])
             if int(p["step_form"]) == 4 and self.world == 1:
                 tables.enable_twin()        # the form needs the second copy of the row table
+            if int(p["step_form"]) == 5 and self.world == 1:
+                tables.enable_tags()        # the tagged form needs both tables twinned and step-tagged
         if self.logistic:       # logistic_matrix_factorisation.py:50-54: the stream's (w, y) are (pos, neg) weights
             hyper_kwargs.update(head=1, neg_factor=p.get("neg_factor", 1.0))
         log_every = max(1, int(p.get("log_every", 100)))

@@ -18,9 +18,10 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 8
+GLOVE_ABI_VERSION = 9
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
-STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN = 0, 1, 2, 3, 4   # glove_hyper.step_form
+STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
+TAGGED_STEP_MAX_BATCH = 2048      # GLOVE_STEP_AUTO takes the tagged step up to this batch size on step-tagged tables
 DEFAULT_CHUNK_CAP = 32
 RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
@@ -62,7 +63,7 @@ class GloveTables(C.Structure):
                 ("R", _fp), ("C", _fp), ("br", _fp), ("bc", _fp),
                 ("s1_R", _fp), ("s1_C", _fp), ("s1_br", _fp), ("s1_bc", _fp),
                 ("s2_R", _fp), ("s2_C", _fp), ("s2_br", _fp), ("s2_bc", _fp),
-                ("scalars", _fp), ("step", _fp), ("R_ver", _fp)]
+                ("scalars", _fp), ("step", _fp), ("R_ver", _fp), ("R_tag", _fp), ("C_tag", _fp)]
 
 
 class GloveHyper(C.Structure):
@@ -257,9 +258,10 @@ class DeviceTables:
             t[:, :self.d_model] = uni(rows, self.d_model)
             return t
 
-        self._R, self.C = table(self.V_row), table(self.V_col)
-        self._br, self.bc = uni(self.V_row), uni(self.V_col)
+        self._R, self._C = table(self.V_row), table(self.V_col)
+        self._br, self._bc = uni(self.V_row), uni(self.V_col)
         self.R_ver = None           # uint8[V_row] once enable_twin() has doubled R and br (glove_tables.R_ver)
+        self.R_tag = self.C_tag = None    # once enable_tags() has doubled both tables (glove_tables.R_tag)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.s1, self.s2 = {}, {}
@@ -298,10 +300,55 @@ class DeviceTables:
         if value.data_ptr() != view.data_ptr():
             view.copy_(value)
 
+    @property
+    def C(self) -> torch.Tensor:
+        self.canonicalize()
+        return self._C[:self.V_col]
+
+    @C.setter
+    def C(self, value):
+        view = self.C
+        if value.data_ptr() != view.data_ptr():
+            view.copy_(value)
+
+    @property
+    def bc(self) -> torch.Tensor:
+        self.canonicalize()
+        return self._bc[:self.V_col]
+
+    @bc.setter
+    def bc(self, value):
+        view = self.bc
+        if value.data_ptr() != view.data_ptr():
+            view.copy_(value)
+
+    def enable_tags(self):
+        """Second copies of BOTH tables + a step tag per row (glove_tables.R_tag / C_tag): what the tagged step
+        (GLOVE_STEP_TAGGED) needs to read pre-step rows while it updates rows in the same launch.  For the latency-bound
+        regime — small tables: costs (V_row + V) x d x 4 B of HBM."""
+        if self.R_tag is not None or self.optimizer != "Adagrad" or self.R_ver is not None:
+            return
+        if self.V_col != self.V or 2 * max(self.V_row, self.V) * self.d * 4 >= 1 << 32:
+            return                               # a sharded col table goes through views; 32-bit row offsets
+        for name in ("_R", "_br", "_C", "_bc"):
+            old = getattr(self, name)
+            new = torch.zeros((2 * old.shape[0],) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+            new[:old.shape[0]].copy_(old)
+            setattr(self, name, new)
+        self.R_tag = torch.zeros(self.V_row, dtype=torch.int64, device=self.device)
+        self.C_tag = torch.zeros(self.V, dtype=torch.int64, device=self.device)
+        self._struct = None
+
+    def maybe_enable_tags(self, batch_size: int):
+        """The policy: batches the library steps in the tagged form (at most TAGGED_STEP_MAX_BATCH pairs) on tables small enough
+        that the step is a latency chain (both tables within the caches: 64 MB)."""
+        if self.optimizer == "Adagrad" and batch_size <= TAGGED_STEP_MAX_BATCH and (self.V_row + self.V) * self.d * 4 <= (64 << 20):
+            self.enable_tags()
+
     def enable_twin(self):
         """Second copy of the row table + per-row version bytes: lets the fused step write a row's update beside the old
         row instead of through a partial-row slot (GLOVE_STEP_FUSED_TWIN).  Costs V_row x d x 4 B of HBM."""
-        if self.R_ver is not None or self.optimizer != "Adagrad":
+        if self.R_ver is not None or self.optimizer != "Adagrad" or self.R_tag is not None:
             return
         if 2 * self.V_row * self.d * 4 >= 1 << 32:
             return                               # 32-bit row offsets: the table cannot be doubled
@@ -326,7 +373,7 @@ class DeviceTables:
         current).  Called by every accessor except the Adagrad step's."""
         # `_twin_dirty` is sticky: once a step that may flip versions has been issued (possibly inside a captured graph
         # that is replayed without any further Python call), every reader pays this one small launch
-        if self.R_ver is not None and getattr(self, "_twin_dirty", False):
+        if (self.R_ver is not None or self.R_tag is not None) and getattr(self, "_twin_dirty", False):
             _check(load_library().glove_canonicalize_f32(C.byref(self.struct(twin_ok=True)), _stream()),
                    "glove_canonicalize_f32")
 
@@ -340,10 +387,11 @@ class DeviceTables:
             s.V, s.d, s.V_row = self.V, self.d, (0 if self.V_row == self.V else self.V_row)
             s.d_model = 0 if self.d_model == self.d else self.d_model
             for n in self.NAMES:
-                setattr(s, n, _ptr(getattr(self, "_" + n, None) if n in ("R", "br") else getattr(self, n)))
+                setattr(s, n, _ptr(getattr(self, "_" + n)))
                 setattr(s, "s1_" + n, _ptr(self.s1[n]))
                 setattr(s, "s2_" + n, _ptr(self.s2.get(n)))
             s.scalars, s.step, s.R_ver = _ptr(self.scalars), _ptr(self.step), _ptr(self.R_ver)
+            s.R_tag, s.C_tag = _ptr(self.R_tag), _ptr(self.C_tag)
             self._struct = s
         return self._struct
 
@@ -440,7 +488,7 @@ class TablesView:
         for name, _ in GloveTables._fields_:
             setattr(s, name, getattr(src, name))
         s.V, s.V_row = self.V, (0 if self.V_row == self.V else self.V_row)
-        s.R_ver = None                                           # views are plain: base.struct() above made the table canonical
+        s.R_ver = s.R_tag = s.C_tag = None            # views are plain: base.struct() above made the tables canonical
         for name, tensor in replace.items():
             _require(tensor, torch.float32)
             setattr(s, name, tensor.data_ptr())
@@ -644,6 +692,12 @@ def _step_struct(tables, plans, hyper):
     """The tables as the Adagrad step may see them: a twinned row table stays twinned between steps.  Marks the tables
     as possibly twinned when one of the plans can take the twin form (the rule of glove_step.hip pick_step_form), so
     that the next reader of R / br brings them home first."""
+    if getattr(tables, "R_tag", None) is not None:
+        # step-tagged tables: the tagged step leaves rows in their second copies (the rule of glove_step.hip pick_step_form)
+        form = hyper.step_form
+        if form == STEP_TAGGED or (form == STEP_AUTO and any(p.r_crec is not None and p.B <= TAGGED_STEP_MAX_BATCH for p in plans)):
+            tables._twin_dirty = True
+        return tables.struct(twin_ok=True)
     if getattr(tables, "R_ver", None) is None:
         return tables.struct()
     form = hyper.step_form
@@ -918,12 +972,14 @@ class GloveHip:
                                                _ptr(ws), ws.numel(), _ptr(loss_out), _stream()),
                "glove_step_adagrad_f32")
 
-    def steps_adagrad(self, plans, tables, hyper, loss_out=None):
-        """len(plans) consecutive Adagrad steps from one host call (the launch loop runs in C)."""
+    def steps_adagrad(self, plans, tables, hyper, loss_out=None, ws=None):
+        """len(plans) consecutive Adagrad steps from one host call (the launch loop runs in C; on step-tagged tables consecutive
+        small batches go out as a chain: ONE launch per step, glove_steps_adagrad_f32)."""
         if not plans:
             return
-        big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
-        ws = self.step_workspace(big, tables.d)
+        if ws is None:
+            big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
+            ws = self.step_workspace(big, tables.d)
         arr = (C.POINTER(GlovePlan) * len(plans))(*[C.pointer(p.struct()) for p in plans])
         _check(self.lib.glove_steps_adagrad_f32(arr, len(plans), C.byref(_step_struct(tables, plans, hyper)), C.byref(hyper), _ptr(ws),
                                                 ws.numel(), _ptr(loss_out), _stream()), "glove_steps_adagrad_f32")

@@ -319,6 +319,7 @@ class Stepper(GraphedSteps):
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
         self.dense = self._multi or tables.optimizer != "Adagrad"
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
+            tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
             tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
         self.exchange, self.rows, self.bufs = exchange, False, None
@@ -741,6 +742,8 @@ class ReshufflingRunner:
         if fused and form == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
         self.records = records
+        if single and records and tables.optimizer == "Adagrad" and form in (0, 5) and hasattr(tables, "maybe_enable_tags"):
+            tables.maybe_enable_tags(B)     # small batches on small tables: the tagged step (one launch for all the row work)
         stream.main_reads_epochs = False        # from here on only the side stream's builds read the epoch buffers
         first = hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records)
         per_plan = max(first.nbytes(), 1)
@@ -762,6 +765,8 @@ class ReshufflingRunner:
         scratch = DeviceTables(real.V, real.d_model, real.optimizer, device=dev, seed=0, V_row=real.V_row)
         if getattr(real, "R_ver", None) is not None:
             scratch.enable_twin()           # the same step forms are legal on the scratch tables
+        if getattr(real, "R_tag", None) is not None:
+            scratch.enable_tags()
         self._swap_tables(scratch)
         torch.cuda.current_stream().wait_event(self._built[0])
         self._step(self.slots[0].plans[0])
@@ -823,8 +828,7 @@ class ReshufflingRunner:
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    for j in range(off, off + count):
-                        self._step(plans[j])
+                    self._steps(plans[off:off + count])
             except Exception as exc:                # a transport that refuses capture: the same launches, eagerly, from now on
                 if self.stepper is None:
                     raise
@@ -838,8 +842,16 @@ class ReshufflingRunner:
         if graph is not None:
             graph.replay()
             return
-        for j in range(off, off + count):
-            self._step(plans[j])
+        self._steps(plans[off:off + count])
+
+    def _steps(self, plans):
+        """Consecutive steps.  One GPU, Adagrad: one host call (on step-tagged tables the library chains them: one launch per
+        step, the global bias handed on through the workspace)."""
+        if self.stepper is None and self.G is None:
+            self.hip.steps_adagrad(plans, self.tables, self.hyper, self.loss_out, ws=self.step_ws)
+        else:
+            for plan in plans:
+                self._step(plan)
 
     def run(self, n_steps: int) -> int:
         """Up to `n_steps` steps, never across a segment's or the epoch's end; returns the number done (the caller asks again)."""

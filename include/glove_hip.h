@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 8   /* 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 9   /* 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -60,6 +60,15 @@ typedef struct glove_tables {
      * slot.  EVERY other entry point expects the plain form — all versions 0, rows 0 .. V_row-1 current — which
      * glove_canonicalize_f32 restores. */
     uint8_t *R_ver;
+    /* Optional step tags of BOTH tables (NULL = none; not together with R_ver).  With them R and br hold 2 x V_row rows /
+     * entries and C and bc 2 x V — row V_side + u is the second copy of row u — and tag[u] (uint64) says where row u is: 0 =
+     * copy 0, never written by a tagged step; otherwise (1 + global_step of the step that wrote it) << 1 | copy it wrote.
+     * The tagged step (GLOVE_STEP_TAGGED) reads, during step t, the copy the tag names — unless the tag says "written in step
+     * t", in which case it reads the OTHER copy, the row as it was when the step began — and writes a row's update into the
+     * copy it did not read: every pair sees pre-step rows although rows are updated in the same launch, with no barrier and
+     * no apply launch.  EVERY other entry point expects the plain form, which glove_canonicalize_f32 restores (current rows
+     * copied home, tags cleared). */
+    uint64_t *R_tag, *C_tag;
 } glove_tables;
 
 typedef struct glove_hyper {
@@ -95,7 +104,16 @@ typedef struct glove_hyper {
      *                                  bc in place (nothing reads them any more), then the apply launch
      *   GLOVE_STEP_FUSED_TWIN          the three-launch form on a twinned row table (glove_tables.R_ver): the row side
      *                                  writes its new rows into the other copy, the apply launch only flips versions
-     *                                  (AUTO picks it whenever R_ver is set and the fused form pays) */
+     *                                  (AUTO picks it whenever R_ver is set and the fused form pays)
+     *   GLOVE_STEP_TAGGED              for the latency-bound regime (the reference's default batch of 1,024 pairs: the two-launch
+     *                                  form is two ramps, a boundary and four dependent memory round trips, nothing in them is
+     *                                  bandwidth): on step-tagged twinned tables (glove_tables.R_tag) ONE launch forms the
+     *                                  gradients AND applies Adagrad — the lane group that holds an id's first chunk does all
+     *                                  of the id's chunks and writes the new row beside the old one — and a one-workgroup
+     *                                  launch behind it does the once-per-step scalars (global bias, loss, global_step).  Ids of
+     *                                  up to heavy_chunks chunks come out bit-identical to the two-launch form, the others
+     *                                  within fp32 rounding of their sums' order.  Needs chunk records.  AUTO picks it for
+     *                                  batches of at most 2,048 pairs when the tables carry tags. */
     int32_t step_form;
 } glove_hyper;
 
@@ -107,6 +125,7 @@ typedef struct glove_hyper {
 #define GLOVE_STEP_FUSED_ONE_PASS 2
 #define GLOVE_STEP_FUSED_THREE_LAUNCH 3
 #define GLOVE_STEP_FUSED_TWIN 4
+#define GLOVE_STEP_TAGGED 5
 
 /*
  * The dedup index of ONE batch of co-occurrence nonzeros ("plan").  It replaces, per batch,

@@ -65,7 +65,9 @@ def run(hip):
             tabs = tables_from_oracle(t, DeviceTables)
             stream = NonzeroStream(coo, Br, V, backend, "cuda:0", seed=3, static_plans=False)
             if mode == "single":
-                runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, **kw), burst=4, segment=2)
+                # (two-launch form: what the dense data-parallel form reproduces bit for bit on one rank; the single-GPU default
+                # at this batch size, the tagged step, sums an id of more than heavy_chunks chunks in another order)
+                runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, step_form=1, **kw), burst=4, segment=2)
             else:
                 cls = RowShardedStepper if mode.startswith("row") else Stepper
                 st = cls(backend, tabs, kw, Br, 1, dist, exchange="dense" if mode.startswith("dp") else "rows", collectives=True)
