@@ -2414,7 +2414,14 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
     return (int)hipGetLastError();
 }
 
-size_t glove_fused_step_bytes(void) { return (size_t)256 << 20; }
+// Forms 1 / 3 / 4 on the same resident plans, one process, interleaved rounds (tools/ab_step_forms.py, round 4; us per step):
+//   V = 50 k,  d = 300 (table 61 MB):  146 MB of touched rows  71.0 /  70.7 /  72.8    221 MB 105.9 / 101.0 / 103.2    311 MB 175.3 / 152.5 / 153.0
+//   V = 400 k, d = 300 (486 MB):       226 MB 102.5 / 104.8 /  98.7                    388 MB 178.2 / 163.6 / 151.9    649 MB 333.0 / 277.1 / 247.5
+//   V = 2 M,   d = 128 (1 GB):         209 MB 128.6 / 122.9 / 120.6                    368 MB 220.3 / 199.4 / 188.8
+//   V = 10 k,  d = 64, B = 1 M (20 MB touched): 55.2 / 82.3 / 87.7
+// A tie at 146 MB, 4 - 6 % for the fused forms from 209 MB on (the twin form on tables beyond the Infinity Cache, the
+// three-launch form on the 61 MB table): the switch sits between.
+size_t glove_fused_step_bytes(void) { return (size_t)192 << 20; }
 
 // Which form a sparse Adagrad step takes (glove_hyper.step_form; see include/glove_hip.h).
 static int pick_step_form(const glove_plan *p, const glove_tables *t, const glove_hyper *h)
@@ -2432,7 +2439,7 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     const int64_t ids = p->host_counts[1] >= 0 && p->host_counts[3] >= 0 ? (int64_t)p->host_counts[1] + p->host_counts[3] : most;
     // (V = 50 k, d = 300, B = 131,072: 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches
     // 106 us, fused 103 - 111; V = 400 k at B = 131,072, 336 MB: 172 against 156; V = 50 k at B = 1 M, 432 MB: 378 against 314)
-    if (ids * t->d * 16 < (int64_t)glove_fused_step_bytes()) return GLOVE_STEP_TWO_LAUNCH;
+    if (ids * t->d * 16 < (int64_t)glove_fused_step_bytes()) return GLOVE_STEP_TWO_LAUNCH;        // (the table of measurements: glove_fused_step_bytes)
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 

@@ -27,7 +27,7 @@ RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk record
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
-FUSED_STEP_BYTES = 256 << 20    # glove_fused_step_bytes(): touched ids x row bytes x 4 beyond which the fused step pays (re-read from the library at load)
+FUSED_STEP_BYTES = 192 << 20    # glove_fused_step_bytes(): touched ids x row bytes x 4 beyond which the fused step pays (re-read from the library at load)
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -361,11 +361,13 @@ class DeviceTables:
         self._struct = None
 
     def maybe_enable_twin(self):
-        """The policy: row tables of 32 MB and more — the ones whose batches can reach the fused step's regime — get the twin.
+        """The policy: row tables of 128 MB and more — beyond the Infinity Cache, where batches reach the fused step's regime — get the twin.
         Measured per step, three-launch form -> twin form with its id triage: V = 400 k, d = 300: 678 -> 627 us;
         V = 2 M, d = 128: 578 -> 539 us (the passes pay ~20 us each for looking up which copy of a row is current, the
         apply launch shrinks from 95 to 15 us); V = 50 k, d = 300 (Infinity-Cache resident): no gain, not enabled."""
-        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (32 << 20):
+        # (round 4, tools/ab_step_forms.py: on the 61 MB table of V = 50 k, d = 300 — Infinity-Cache resident — the three-launch
+        # form beats the twin form 101.0 to 103.2 us; on tables beyond the cache the twin form wins by 4 - 11 %)
+        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (128 << 20):
             self.enable_twin()
 
     def canonicalize(self):
@@ -605,7 +607,8 @@ class Plan:
         # empty (V = 400 k, B = 1 M: 2.6 pairs per 16-slot chunk -> 7 % more traffic, measured slower)
         fused = d is not None and (nu_r + nu_c) * d * 16 >= FUSED_STEP_BYTES
         if records is None:
-            records = fused or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)
+            # (small batches always: the tagged step of the latency-bound regime reads nothing but the records)
+            records = fused or out.B <= TAGGED_STEP_MAX_BATCH or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)
         if lib is not None and out.B > 0 and records:
             n = max(out.cap_chunks, 1) * out.rec_dwords
             out.r_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)

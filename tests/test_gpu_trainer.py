@@ -519,6 +519,7 @@ def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, graphs):
         nb = stream.batches_per_epoch
         steps = nb + 2                                       # across an epoch boundary
         if mode == "runner":
+            tables.enable_twin()      # (the policy twins row tables of 128 MB and more; this one has 73 MB: asked for here)
             runner = ReshufflingRunner(hip, stream, tables, hyper, burst=4, graphs=graphs, segment=2)
             assert tables.R_ver is not None and runner.slots[0].plans[0].r_crec is not None and runner.slots[0].plans[0].r_partner is None
             done = 0
