@@ -703,6 +703,26 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
     // lanes 0 .. 32: chunk_start[j0 + lane]; lanes 0 .. 31: the chunk's id and header words 2, 3
     const int jl = j0 + lane < n_chunks ? j0 + lane : n_chunks;       // chunk_start[n_chunks] = B closes the last chunk
     const int cs = lane <= 32 ? chunk_start[jl] : 0;
+    // The pair fields of the wave's 32 chunks are one contiguous run of positions (a few hundred for the short chunks of a big
+    // batch): fetched coalesced into LDS once, the records are put together from there.  (Every lane pulling its four values of
+    // a field out of global memory by itself was 16 scattered 4-byte load instructions per lane: 39 us per 1 M-pair batch of
+    // V = 400 k against 33 with the staging.)  A run too long for the stage — the full chunks
+    // of the Zipf head — is read directly as before.
+    constexpr int kStage = 384;
+    __shared__ int32_t st_p[kBlock / 64][kStage];
+    __shared__ float st_w[kBlock / 64][kStage], st_y[kBlock / 64][kStage];
+    const int wv = threadIdx.x >> 6;
+    const int p0 = __shfl(cs, 0, 64);
+    const int last = n_chunks - j0 < 32 ? n_chunks - j0 : 32;
+    const int span = __shfl(cs, last, 64) - p0;
+    const bool staged = span <= kStage;
+    if (staged) {
+        for (int i = lane; i < span; i += 64) {
+            st_p[wv][i] = partner[p0 + i];
+            st_w[wv][i] = w[p0 + i];
+            st_y[wv][i] = y[p0 + i];
+        }
+    }
     int32_t cid = 0;
     int2 ax = make_int2(0, 0);
     if (lane < 32 && j0 + lane < n_chunks) {
@@ -751,7 +771,10 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
                 for (int x = 0; x < 4; ++x) {
                     const int t = t0 + x;
                     const int k = s + (t < n ? t : 0);              // padding replays pair 0 with weight 0
-                    o[x] = field == 0 ? partner[k] : field == 1 ? __float_as_int(t < n ? w[k] : 0.f) : __float_as_int(y[k]);
+                    if (staged)                                     // (same wave wrote the stage: LDS ops of one wave complete in order)
+                        o[x] = field == 0 ? st_p[wv][k - p0] : field == 1 ? __float_as_int(t < n ? st_w[wv][k - p0] : 0.f) : __float_as_int(st_y[wv][k - p0]);
+                    else
+                        o[x] = field == 0 ? partner[k] : field == 1 ? __float_as_int(t < n ? w[k] : 0.f) : __float_as_int(y[k]);
                 }
                 v = make_int4(o[0], o[1], o[2], o[3]);
             }
