@@ -27,7 +27,11 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE", ftot), per_kernel(sys.argv[2], "WRITE_SIZE", wtot)
     meta = dict(kv.split("=", 1) for kv in sys.argv[4:])
     out = {"meta": meta, "kernels": {}}
-    step = ("sidepass", "rowpass", "colpass", "apply_adagrad")          # the kernels of one sparse-Adagrad step
+    step = ("sidepass", "rowpass", "colpass", "apply_adagrad", "triage", "tagged_step", "tagged_flush")   # the kernels of one sparse-Adagrad step
+    # an epoch dealt and indexed inside the timed region (meta index=dealt): the deal and the index build count as well
+    index = ("side_tiles", "side_emit", "fill_records", "csort_hist<8, glove::DealJob", "csort_scatter<8, glove::DealJob", "csort_scan")
+    if meta.get("index") == "dealt":
+        step = step + index
     total = 0.0
     for k in sorted(set(fetch) | set(write)):
         rd, wr = 2.0 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
@@ -35,11 +39,13 @@ def main():
                              "read_bytes_corrected": rd, "write_bytes": wr, "dispatches": ftot.get(k, (0, 0))[1]}
     # a step = every launch of the step's kernels between two apply launches (the fused forms launch the pass kernel
     # twice): all their bytes over all dispatches, divided by the number of steps = apply launches
-    def per_step(tot, scale):
-        steps = sum(n for k, (_, n) in tot.items() if k.startswith("apply_adagrad"))
-        return scale * 1024 * sum(s_ for k, (s_, _) in tot.items() if any(k.startswith(x) for x in step)) / max(steps, 1)
+    def per_step(tot, scale, names=None):
+        steps = sum(n for k, (_, n) in tot.items() if k.startswith("apply_adagrad")) or sum(n for k, (_, n) in tot.items() if k.startswith("tagged_step"))
+        return scale * 1024 * sum(s_ for k, (s_, _) in tot.items() if any(k.startswith(x) for x in (names or step))) / max(steps, 1)
     total = per_step(ftot, 2.0) + per_step(wtot, 1.0)
     out["traffic_bytes_per_step"] = total
+    if meta.get("index") == "dealt":        # the index work's share of it
+        out["index_traffic_bytes_per_step"] = per_step(ftot, 2.0, index) + per_step(wtot, 1.0, index)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["traffic_bytes_per_step"]))
 
