@@ -21,7 +21,7 @@ pd.DataFrame({"row_token": tok[row.numpy()], "col_token": tok[col.numpy()], "glo
               "glove_value": y.numpy()}).to_csv(tmp / "interaction.csv", index=False)
 for opt, lr, extra in (("Adagrad", "0.05", ["--epoch-shuffle", "static"]), ("Adam", "0.001", ["--epoch-shuffle", "static"]),
                        ("Adagrad", "0.05", ["--epoch-shuffle", "full"]), ("Adam", "0.001", ["--epoch-shuffle", "full"]),
-                       ("Adam", "0.001", ["--epoch-shuffle", "full", "--build-ahead", "8"])):
+                       ("Adagrad", "0.05", ["--epoch-shuffle", "full", "--step-form", "1"])):
     job = tmp / ("job_" + opt + "_".join(extra))
     estimator.main(["--train-csv", str(tmp / "interaction.csv"), "--vocab-txt", str(tmp / "vocab.txt"), "--job-dir", str(job),
                     "--disable-datetime-path", "--optimizer", opt, "--learning-rate", lr, "--train-steps", "20000",

@@ -18,9 +18,8 @@ run c5_three_launch --workload zipf_v2m_d128 --batch-size 1048576 --steps 40 --w
 run c5_twin --workload zipf_v2m_d128 --batch-size 1048576 --steps 40 --warmup 10
 run c5_sharded_world1 --workload zipf_v2m_d128 --batch-size 1048576 --row-sharded --steps 40 --warmup 10 --max-batches 8
 run c5_rowsharded_world1 --workload zipf_v2m_d128 --batch-size 1048576 --row-sharded --cols-replicated --steps 40 --warmup 10 --max-batches 8
-run dyn_131k --dynamic
-run dyn_131k_ahead6 --dynamic --build-ahead 6
-run dyn_1024 --dynamic --batch-size 1024 --steps 2000 --warmup 200
+run static_131k --static-index
+run static_1024 --static-index --batch-size 1024 --steps 2000 --warmup 200
 run dp1_dense --force-dense --exchange dense
 run dp1_rows --force-dense --exchange rows
 run c4_131k_dp1_dense --workload zipf_v400k_d300 --batch-size 131072 --force-dense --exchange dense --steps 60 --warmup 10 --max-batches 8

@@ -70,12 +70,12 @@ if "runners" in forms:
         tabs = tables_from_oracle(t, DeviceTables)
         stream = NonzeroStream(coo, Br, V, backend, "cuda:0", seed=3, static_plans=False)
         if mode == "single":
-            runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, **kw), ahead=3, burst=4)
+            runner = ReshufflingRunner(hip, stream, tabs, make_hyper(batch_size=Br, **kw), burst=4, segment=2)
         else:
             cls = RowShardedStepper if mode.startswith("row") else Stepper
             st = cls(backend, tabs, kw, Br, 1, dist, exchange="dense" if mode.startswith("dp") else "rows", collectives=True)
             st.prepare(batch_size=Br)
-            runner = ReshufflingRunner(hip, stream, tabs, st.hyper, ahead=3, burst=4, stepper=st, graphs=mode.endswith("graphs"))
+            runner = ReshufflingRunner(hip, stream, tabs, st.hyper, burst=4, segment=2, stepper=st, graphs=mode.endswith("graphs"))
         say("  constructed")
         done = 0
         while done < 23:
