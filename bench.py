@@ -403,7 +403,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     torch.cuda.synchronize()
     masters_ms = (time.perf_counter() - t0) * 1e3
     hyper = make_hyper(batch_size=B, learning_rate=lr, step_form=step_form)
-    runner = ReshufflingRunner(hip, stream, tables, hyper, chunk_cap=chunk_cap, burst=64, graphs=not no_graph, segment=segment)
+    runner = ReshufflingRunner(hip, stream, tables, hyper, chunk_cap=chunk_cap, burst=64, graphs=False if no_graph else None, segment=segment)
     cap, S, nb = runner.cap, runner.S, runner.nb
     log("  masters in %.1f ms (once, at load); %d batches per epoch, index built %d batches at a time, chunk records: %s" % (
         masters_ms, nb, S, runner.records))
@@ -426,6 +426,14 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     # ---- the pieces apart, each on its own with HIP events on its launch stream (the timed region overlaps them)
     n0 = min(S, nb)
     slot = runner.slots[0]
+    rs, cs = stream.epoch_sides()
+    with torch.cuda.stream(stream.side):        # slot 0 indexed afresh, its counts adopted as the runner does at a segment's start
+        hip.build_plans_sorted(rs, cs, 0, slot, n0, V, runner.sorted_ws)
+        if runner.host_counts:
+            slot.fetch_counts()
+    torch.cuda.synchronize()
+    if runner.host_counts:
+        slot.adopt_counts(n0)
 
     def steps_once():
         runner._steps(slot.plans[:n0])
@@ -435,7 +443,6 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     with torch.cuda.graph(kg):
         steps_once()
     kern = {"step": event_us(kg.replay) / n0}
-    rs, cs = stream.epoch_sides()
     kern["index_build"] = event_us(lambda: hip.build_plans_sorted(rs, cs, 0, slot, n0, V, runner.sorted_ws), stream=stream.side) / n0
     spare = stream._sets[(stream.epoch + 1) % 2]
     kern["epoch_deal"] = event_us(lambda: hip.deal_epoch(stream.masters, B, 12345, spare[0], spare[1], stream._deal_ws),
@@ -455,7 +462,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
                    "index": "rebuilt every step: epochs dealt from the sorted master orders (one partition pass per epoch), the "
                             "index of %d consecutive batches numbered by 3 launches on a side stream, inside the timed region" % S,
                    "launch": "the trainer's runner: steps replayed from hipGraphs of 2^k steps" if runner.graphs_on else
-                             "the trainer's runner: eager launches",
+                             "the trainer's runner: every run of steps issued by one C call (glove_steps_adagrad_f32)",
                    "parallelism": "single GPU", "chunk_records": bool(runner.records)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,

@@ -172,7 +172,7 @@ class Estimator:
             stepper = ReshufflingRunner(getattr(self.backend, "hip", None), stream, tables,
                                         self.backend.make_hyper(batch_size=p["batch_size"] * self.world, **hyper_kwargs),
                                         chunk_cap=p.get("chunk_cap", 0), burst=64, segment=p.get("index_segment", 0),
-                                        stepper=stepper, graphs=graphs)
+                                        stepper=stepper, graphs=None if graphs else False)
         fresh = self.ckpt.latest() is None
         if self.world > 1:                  # saving may be collective (row-sharded): rank 0's view of job_dir decides
             flag = torch.tensor([1 if fresh else 0], device=self.device)

@@ -661,6 +661,12 @@ class PlanBlock:
     def __init__(self, plans: list):
         self.plans = list(plans)
         n = len(self.plans)
+        # the plans' counts side by side in ONE tensor: a whole block's counts come back to the host in one copy
+        self.counts = torch.zeros(n, 8, dtype=torch.int32, device=self.plans[0].counts.device)
+        self.counts_host = torch.zeros(n, 8, dtype=torch.int32).pin_memory() if self.counts.is_cuda else torch.zeros(n, 8, dtype=torch.int32)
+        for i, p in enumerate(self.plans):
+            p.counts = self.counts[i]
+            p._struct = None
         self.host = (GlovePlan * n)()
         for i, p in enumerate(self.plans):
             self.host[i] = p.struct()
@@ -669,6 +675,20 @@ class PlanBlock:
 
     def __len__(self):
         return len(self.plans)
+
+    def fetch_counts(self):
+        """Starts the copy of every plan's counts to pinned host memory (on the current stream: behind the build that wrote them)."""
+        self.counts_host.copy_(self.counts, non_blocking=True)
+
+    def adopt_counts(self, n: int):
+        """The fetched counts of the first n plans become their host counts: the step then sizes its grids by what the batch
+        holds, like a resident plan's (call once the copy has completed).  The structs a BUILD reads (`host`) keep -1."""
+        got = self.counts_host[:n].tolist()
+        for p, c in zip(self.plans[:n], got):
+            p.host_counts = [c[0], c[1], c[2], c[3], c[4], -1, -1, -1]
+            st = p.struct()
+            for i in range(8):
+                st.host_counts[i] = p.host_counts[i]
 
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,

@@ -691,10 +691,17 @@ class ReshufflingRunner:
     On one rank every form gives exactly what the single-GPU runner gives.
     """
 
-    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, burst=64, stepper=None, graphs=True, segment=0,
+    GRAPH_MAX_BATCH = 8192
+
+    def __init__(self, hip, stream, tables, hyper, chunk_cap=0, burst=64, stepper=None, graphs=None, segment=0,
                  slot_bytes=16 << 30, max_graphs=256):
         """`segment`: batches per index build (0: up to 64 — more would push the staging plans of small batches out of the caches —, as the epoch and `slot_bytes` of staging plans per slot allow);
-        `burst`: most steps per graph replay."""
+        `burst`: most steps per graph replay; `graphs`: None = replay the steps from hipGraphs up to GRAPH_MAX_BATCH pairs per
+        batch (the latency-bound regime: a step is one to three short launches) and issue them from one C call per run beyond
+        (measured, graphs / C loop, us per step: B = 16,384 17.5 / 17.2; text8 B = 131,072 32.0 / 29.4; V = 50 k, d = 300
+        120 / 117; C4 674 / 687), True / False force it."""
+        if graphs is None:
+            graphs = stream.B <= self.GRAPH_MAX_BATCH
         from trainer.hip_api import auto_chunk_cap
         self.hip, self.stream, self.tables, self.hyper, self.stepper = hip, stream, tables, hyper, stepper
         self.cap = chunk_cap or auto_chunk_cap(stream.B, stream.V, tables.d)
@@ -757,7 +764,12 @@ class ReshufflingRunner:
         # ---- segments: `_g` = the segment the next step belongs to (counted over all epochs), slot = segment % 2
         self._g, self._issued, self._entered = 0, 0, -1
         self._cursor = (stream.epoch, 0)       # (epoch, segment of the epoch) the next build takes
-        self._built, self._freed = {}, {}
+        self._built, self._built_n, self._freed = {}, {}, {}
+        # One GPU, steps issued by C calls (no graphs: big batches): the counts of every indexed batch come back to the host
+        # with the build, so that a staging plan is stepped like a resident one — exact grids, the form picked by the ids the
+        # batch really holds (V = 50 k, d = 300: 107 -> 99 us per step; V = 2 M, d = 128: 537 -> 517).  A captured graph bakes
+        # its grids in: there the plans keep their counts on the device.
+        self.host_counts = single and not self.graphs_on
         self._issue_build()                    # segment 0: needed now anyway
         # every kernel (and collective) of a step runs once outside any capture, on throw-away tables of the same shape
         from trainer.hip_api import DeviceTables
@@ -769,6 +781,9 @@ class ReshufflingRunner:
             scratch.enable_tags()
         self._swap_tables(scratch)
         torch.cuda.current_stream().wait_event(self._built[0])
+        if self.host_counts:
+            self._built[0].synchronize()
+            self.slots[0].adopt_counts(self._built_n[0])
         self._step(self.slots[0].plans[0])
         torch.cuda.synchronize()
         self._swap_tables(real)
@@ -806,9 +821,12 @@ class ReshufflingRunner:
             side.wait_event(self._freed[slot])
         with torch.cuda.stream(side):
             self.hip.build_plans_sorted(rs, cs, first, self.slots[slot], n, self.stream.V, self.sorted_ws)
+            if self.host_counts:
+                self.slots[slot].fetch_counts()
             ev = torch.cuda.Event()
             ev.record(side)
         self._built[g] = ev
+        self._built_n[g] = n
         self._issued += 1
         self._cursor = (epoch, seg + 1) if seg + 1 < self._segments_per_epoch() else (epoch + 1, 0)
 
@@ -881,7 +899,14 @@ class ReshufflingRunner:
             if self._entered != g:                  # the segment's first step: its index, then the next segment's behind it
                 while self._issued <= g:
                     self._issue_build()
-                main.wait_event(self._built.pop(g))
+                ev = self._built.pop(g)
+                main.wait_event(ev)
+                if self.host_counts:
+                    # the counts of the segment's batches, read back: its steps size their grids and pick their form by what
+                    # the batches hold, as on resident plans (the build was issued a segment ago: the wait is short, and the
+                    # host stays at most one segment ahead of the GPU)
+                    ev.synchronize()
+                    self.slots[slot].adopt_counts(self._built_n.pop(g))
                 self._entered = g
                 if self._issued == g + 1:
                     self._issue_build()            # into the other slot, free since the segment before this one ended
