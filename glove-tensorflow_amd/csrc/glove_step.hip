@@ -1658,6 +1658,133 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
 
 
 // ------------------------------------------------------------------------------------------
+// The other Keras optimizers `tf.keras.optimizers.get(name)` resolves (reference src/models/train_utils.py:13-16), as apply
+// epilogues on the same traversal as AdagradApply.  Semantics: include/glove_hip.h glove_hyper.optimizer; restated in
+// oracle/glove_ref.py (_sgd, _rmsprop_dense_decay, _adamax).
+// ------------------------------------------------------------------------------------------
+struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; };
+
+template <int LPR, int NV, int OPT>
+struct SparseOptApply {
+    SideBufs rs, cs;
+    float *S2_R, *S2_C, *S2_br, *S2_bc;
+    int d4, lg;
+    OptConsts o;
+    struct State { f4 A[NV], B[NV]; float Ab, Bb; };
+    __device__ void prefetch(bool is_row, int32_t id, State &st) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+        if (OPT == GLOVE_OPT_SGD && o.momentum == 0.f) return;
+        load_row<LPR, NV>(st.A, sb.S1, id, d4, lg);
+        st.Ab = sb.S1b[id];
+        if (OPT == GLOVE_OPT_ADAMAX) {
+            load_row<LPR, NV>(st.B, is_row ? S2_R : S2_C, id, d4, lg);
+            st.Bb = (is_row ? S2_br : S2_bc)[id];
+        }
+    }
+    __device__ static void sgd(float &w, float &a, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        if (o.momentum == 0.f) { w -= o.lr * g; return; }
+        a = a * o.momentum - o.lr * g;
+        w += o.nesterov ? a * o.momentum - o.lr * g : a;
+    }
+    __device__ static void adamax(float &w, float &m, float &v, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = fmaxf(o.b2 * v, fabsf(g));
+        w -= o.lr_t * m / (v + o.eps);
+    }
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+        const bool slots = !(OPT == GLOVE_OPT_SGD && o.momentum == 0.f);
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            float w[4] = {Wv[kk].x, Wv[kk].y, Wv[kk].z, Wv[kk].w}, a[4] = {st.A[kk].x, st.A[kk].y, st.A[kk].z, st.A[kk].w};
+            float b[4] = {st.B[kk].x, st.B[kk].y, st.B[kk].z, st.B[kk].w};
+            const float g[4] = {G[kk].x, G[kk].y, G[kk].z, G[kk].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (OPT == GLOVE_OPT_SGD) sgd(w[i], a[i], g[i], o);
+                else adamax(w[i], a[i], b[i], g[i], o);
+            }
+            Wv[kk] = f4{w[0], w[1], w[2], w[3]};
+            st.A[kk] = f4{a[0], a[1], a[2], a[3]};
+            st.B[kk] = f4{b[0], b[1], b[2], b[3]};
+        }
+        if (slots) store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, st.A);
+        if (OPT == GLOVE_OPT_ADAMAX) store_row<LPR, NV>(is_row ? S2_R : S2_C, (size_t)id, d4, lg, st.B);
+        store_row<LPR, NV>(sb.W, (size_t)wid, d4, lg, Wv);
+        if (lg == 0) {
+            if (OPT == GLOVE_OPT_SGD) sgd(bval, st.Ab, Gb, o);
+            else adamax(bval, st.Ab, st.Bb, Gb, o);
+            if (slots) sb.S1b[id] = st.Ab;
+            if (OPT == GLOVE_OPT_ADAMAX) (is_row ? S2_br : S2_bc)[id] = st.Bb;
+            sb.bias[wid] = bval;
+        }
+    }
+};
+
+template <int LPR, int NV, int OPT>
+__global__ __launch_bounds__(kBlock) void apply_sparse_opt_kernel(
+    IdWork wk, SideBufs rs, SideBufs cs, float *S2_R, float *S2_C, float *S2_br, float *S2_bc, int d4, StepConsts k, OptConsts o,
+    double ln_beta1, const int64_t *__restrict__ step, float *__restrict__ scalars, const float *__restrict__ blockpart,
+    int nblocks_rowpass, float *__restrict__ loss_out)
+{
+    // t = global_step after rowpass advanced it (Adamax: lr_t = lr / (1 - beta1^t))
+    if (OPT == GLOVE_OPT_ADAMAX) o.lr_t = o.lr / -expm1f((float)((double)(*step) * ln_beta1));
+    const bool scalar_duty = for_each_id<LPR, NV>(wk, rs, cs, d4, k,
+                                                  SparseOptApply<LPR, NV, OPT>{rs, cs, S2_R, S2_C, S2_br, S2_bc, d4, (int)(threadIdx.x % LPR), o});
+    if (scalar_duty) {
+        float tot[kPartials];
+        sum_blockpart(blockpart, nblocks_rowpass, tot);
+        if (threadIdx.x == 0) {
+            const float g = scalars[0];
+            float loss, L, reg;
+            loss_from_partials(tot, k, g, loss, L, reg);
+            const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
+            float gn = g, a = scalars[1], b = scalars[2];
+            if (OPT == GLOVE_OPT_SGD) SparseOptApply<LPR, NV, OPT>::sgd(gn, a, dg, o);
+            else SparseOptApply<LPR, NV, OPT>::adamax(gn, a, b, dg, o);
+            scalars[0] = gn; scalars[1] = a; scalars[2] = b;
+            if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
+        }
+    }
+}
+
+// Keras-legacy RMSprop over [R | C | br | bc], consuming (and zeroing) G_flat: every rms entry decays, entries with a gradient move
+__global__ __launch_bounds__(kBlock) void dense_rmsprop_kernel(
+    DenseSegs segs, StepConsts k, float rho, float *__restrict__ scalars, float *__restrict__ tail,
+    float *__restrict__ loss_out, int do_scalars)
+{
+#pragma clang fp contract(off)
+    const DenseSeg sg = segs.s[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * kBlock) {
+        const float gv = sg.G[i];
+        const float a = rho * sg.S1[i] + (1.0f - rho) * gv * gv;
+        sg.S1[i] = a;
+        if (gv != 0.f) {
+            sg.W[i] -= k.lr * gv / (sqrtf(a) + k.eps);
+            sg.G[i] = 0.f;
+        }
+    }
+    if (do_scalars && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const float g = scalars[0];
+        const float tot[kPartials] = {tail[1], tail[2], tail[3], tail[0]};
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = tail[0] + 2.0f * k.m * k.l2 * g;
+        const float a = rho * scalars[1] + (1.0f - rho) * dg * dg;
+        scalars[1] = a;
+        scalars[0] = g - k.lr * dg / (sqrtf(a) + k.eps);
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tail[0]; }
+        tail[0] = tail[1] = tail[2] = tail[3] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Keras-legacy Adam in ONE launch behind the passes (single GPU, batches that touch a minority of the rows:
 // the reference's default, 1,024 pairs against a 10^4-row vocabulary).  The passes left mark[id] = 1 for
 // every id of the batch (in the bias segments of G_flat, which is otherwise unused on this path).
@@ -2649,6 +2776,53 @@ int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_
     if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
     if (int rc = launch_dense_grad(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
     return glove_dense_adam_f32(t, h, G_flat, loss_out, stream);
+}
+
+int glove_step_sparse_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
+                          float *G_flat, float *loss_out, void *stream)
+{
+    if (!h) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_ADAGRAD) return glove_step_adagrad_f32(p, t, h, ws, ws_bytes, loss_out, stream);
+    if (h->optimizer == GLOVE_OPT_ADAM) return glove_step_adam_f32(p, t, h, ws, ws_bytes, G_flat, loss_out, stream);
+    if (int rc = plain_table(t, stream)) return rc;
+    if (int rc = check_common(p, t, h, ws)) return rc;
+    if (sides_of(h) != 3 || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const StepConsts k = make_consts(t, h);
+    if (h->optimizer == GLOVE_OPT_RMSPROP) {
+        if (!G_flat || !(h->rho > 0.f && h->rho < 1.f)) return GLOVE_E_BADARG;
+        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
+        if (int rc = launch_dense_grad(p, t, h, ws, ws_bytes, G_flat, stream)) return rc;
+        DenseSegs segs; float *tail; int nbx, sides;
+        if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx, sides)) return rc;
+        hipLaunchKernelGGL(dense_rmsprop_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, h->rho, t->scalars, tail, loss_out, 1);
+        return (int)hipGetLastError();
+    }
+    if (h->optimizer != GLOVE_OPT_SGD && h->optimizer != GLOVE_OPT_ADAMAX) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_ADAMAX && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc || !(h->beta1 > 0.0 && h->beta1 < 1.0) ||
+                                             !(h->beta2 > 0.0 && h->beta2 < 1.0)))
+        return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_SGD && !(h->momentum >= 0.f && h->momentum < 1.f)) return GLOVE_E_BADARG;
+    if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
+    const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+    const int d4 = t->d / 4;
+    const RowShape shape = pick_row_shape(d4);
+    IdWork wk = id_work(p);
+    const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
+    const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
+    const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
+    const OptConsts o = {h->learning_rate, h->epsilon, h->momentum, 0.f, (float)h->beta1, (float)h->beta2, h->nesterov ? 1 : 0};
+    const double ln_b1 = h->optimizer == GLOVE_OPT_ADAMAX ? log((double)(float)h->beta1) : 0.0;
+#define CALL(LPR, NV)                                                                                                       \
+    if (h->optimizer == GLOVE_OPT_SGD)                                                                                      \
+        hipLaunchKernelGGL((apply_sparse_opt_kernel<LPR, NV, GLOVE_OPT_SGD>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
+                           t->s2_br, t->s2_bc, d4, k, o, ln_b1, (const int64_t *)t->step, t->scalars, (const float *)w.blockpart, nb_row, loss_out); \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((apply_sparse_opt_kernel<LPR, NV, GLOVE_OPT_ADAMAX>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
+                           t->s2_br, t->s2_bc, d4, k, o, ln_b1, (const int64_t *)t->step, t->scalars, (const float *)w.blockpart, nb_row, loss_out)
+    GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    return (int)hipGetLastError();
 }
 
 int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t, const glove_hyper *h,

@@ -18,8 +18,9 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 9
+GLOVE_ABI_VERSION = 10
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
+OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4}      # glove_hyper.optimizer (GLOVE_OPT_*)
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
 TAGGED_STEP_MAX_BATCH = 2048      # GLOVE_STEP_AUTO takes the tagged step up to this batch size on step-tagged tables
 DEFAULT_CHUNK_CAP = 32
@@ -52,7 +53,7 @@ EXPORTED_SYMBOLS = (
     "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
     "glove_count_packed_f32", "glove_steps_rebuilt_f32",
     "glove_masters_workspace_bytes", "glove_masters_build", "glove_epoch_deal_workspace_bytes", "glove_epoch_deal",
-    "glove_plan_sorted_workspace_bytes", "glove_plan_chunk_bound", "glove_plan_build_sorted",
+    "glove_plan_sorted_workspace_bytes", "glove_plan_chunk_bound", "glove_plan_build_sorted", "glove_step_sparse_f32",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -70,7 +71,8 @@ class GloveHyper(C.Structure):
     _fields_ = [("beta1", C.c_double), ("beta2", C.c_double),
                 ("l2_reg", C.c_float), ("reg_mult", C.c_float), ("learning_rate", C.c_float),
                 ("epsilon", C.c_float), ("inv_batch", C.c_float), ("sides", C.c_int32),
-                ("head", C.c_int32), ("neg_factor", C.c_float), ("step_form", C.c_int32)]
+                ("head", C.c_int32), ("neg_factor", C.c_float), ("step_form", C.c_int32),
+                ("optimizer", C.c_int32), ("momentum", C.c_float), ("nesterov", C.c_int32), ("rho", C.c_float)]
 
 
 class GlovePlan(C.Structure):
@@ -148,6 +150,7 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_steps_adagrad_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
+        "glove_step_sparse_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_packed_entry_floats": (sz, [i32]),
         "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
@@ -236,8 +239,8 @@ class DeviceTables:
         TablesView, the plain kernels expect V col rows."""
         if d <= 0:
             raise ValueError("embedding size must be positive, got %d" % d)
-        if optimizer not in ("Adagrad", "Adam"):
-            raise ValueError("optimizer must be 'Adagrad' or 'Adam' (Keras names), got %r" % (optimizer,))
+        if optimizer not in OPTIMIZER_CODES:
+            raise ValueError("optimizer must be one of %s (Keras names), got %r" % (", ".join(OPTIMIZER_CODES), optimizer))
         self.V, self.d_model, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
         self.d = (int(d) + 3) // 4 * 4
         self.V_row = int(V if V_row is None else V_row)
@@ -269,9 +272,10 @@ class DeviceTables:
             w = getattr(self, n)
             if optimizer == "Adagrad":
                 self.s1[n] = torch.full_like(w, 0.1)   # initial_accumulator_value
-            else:
+            else:                                      # Adam m / v, Adamax m / v; SGD momentum accumulator, RMSprop rms: zeros
                 self.s1[n] = torch.zeros_like(w)
-                self.s2[n] = torch.zeros_like(w)
+                if optimizer in ("Adam", "Adamax"):
+                    self.s2[n] = torch.zeros_like(w)
         if optimizer == "Adagrad":
             self.scalars[1] = 0.1
         self._struct = None
@@ -693,11 +697,13 @@ class PlanBlock:
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
                batch_size=None, inv_batch=None, sides=0, head=HEAD_REGRESSION, neg_factor=1.0,
-               step_form=STEP_AUTO) -> GloveHyper:
+               step_form=STEP_AUTO, optimizer="Adagrad", momentum=0.0, nesterov=False, rho=0.9) -> GloveHyper:
     """`sides`: 0/3 both sides, 1 row side only, 2 col side only; `head`: HEAD_REGRESSION (GloVe) or
     HEAD_LOGISTIC (pos/neg logistic matrix factorisation, with `neg_factor`) — see glove_hyper in the header."""
     h = GloveHyper()
     h.sides, h.head, h.neg_factor, h.step_form = sides, head, neg_factor, step_form
+    h.optimizer = OPTIMIZER_CODES[optimizer] if isinstance(optimizer, str) else int(optimizer)     # read by glove_step_sparse_f32 only
+    h.momentum, h.nesterov, h.rho = momentum, int(bool(nesterov)), rho
     h.beta1, h.beta2 = beta1, beta2
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
     h.inv_batch = inv_batch if inv_batch is not None else 1.0 / batch_size
@@ -1012,6 +1018,15 @@ class GloveHip:
         _check(self.lib.glove_step_adam_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
                                             _ptr(ws), ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_step_adam_f32")
+
+    def step_sparse(self, plan, tables, hyper, G_flat=None, loss_out=None, ws=None):
+        """One step under the Keras optimizer `tables.optimizer` names (glove_step_sparse_f32: SGD, RMSprop, Adamax; Adagrad and
+        Adam go to their own entry points).  G_flat: the dense gradient buffer RMSprop and Adam need."""
+        ws = self.step_workspace(plan, tables.d) if ws is None else ws
+        hyper.optimizer = OPTIMIZER_CODES[tables.optimizer]
+        struct = _step_struct(tables, (plan,), hyper) if tables.optimizer == "Adagrad" else tables.struct()
+        _check(self.lib.glove_step_sparse_f32(C.byref(plan.struct()), C.byref(struct), C.byref(hyper), _ptr(ws), ws.numel(),
+                                              _ptr(G_flat), _ptr(loss_out), _stream()), "glove_step_sparse_f32")
 
     def steps_adam(self, plans, tables, hyper, G_flat, loss_out=None):
         """len(plans) consecutive Adam steps from one host call."""

@@ -46,7 +46,10 @@ class HipBackend:
         return self.hip.dense_grad_buffer(tables)
 
     def step_sparse_adagrad(self, plan, tables, hyper, loss_out):
-        self.hip.step_adagrad(plan, tables, hyper, loss_out)
+        if tables.optimizer == "Adagrad":
+            self.hip.step_adagrad(plan, tables, hyper, loss_out)
+        else:                                   # SGD, Adamax: passes + their apply epilogue (glove_step_sparse_f32)
+            self.hip.step_sparse(plan, tables, hyper, None, loss_out)
 
     def steps_sparse_adagrad(self, plans, tables, hyper, loss_out):
         self.hip.steps_adagrad(plans, tables, hyper, loss_out)
@@ -61,8 +64,10 @@ class HipBackend:
     def apply_dense(self, tables, hyper, G, loss_out):
         if tables.optimizer == "Adagrad":
             self.hip.dense_adagrad(tables, hyper, G, loss_out)
-        else:
+        elif tables.optimizer == "Adam":
             self.hip.dense_adam(tables, hyper, G, loss_out)
+        else:
+            raise ValueError("no dense apply for %s" % tables.optimizer)
 
     # ---- pieces of the row-sharded step (hyper.sides selects the side)
     def passes(self, plan, tables, hyper):
@@ -314,10 +319,14 @@ class Stepper(GraphedSteps):
             raise ValueError("exchange must be auto, dense or rows")
         if exchange == "rows" and tables.optimizer != "Adagrad":
             raise ValueError("the touched-rows exchange is for Adagrad (Keras' Adam moves every row every step)")
+        if self._multi and tables.optimizer not in ("Adagrad", "Adam"):
+            raise ValueError("the multi-GPU forms are implemented for Adagrad and Adam, got %s" % tables.optimizer)
         self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
-        # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer
-        self.dense = self._multi or tables.optimizer != "Adagrad"
+        # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer; RMSprop (whole-slot decay) too,
+        # inside its own entry point
+        self.dense = self._multi or tables.optimizer == "Adam"
+        self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer == "RMSprop" else None
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
             tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
@@ -353,6 +362,8 @@ class Stepper(GraphedSteps):
         """The step as named pieces [(name, fn(plan))]: what step() runs, in order (bench.py times them apart)."""
         b, t, h = self.backend, self.tables, self.hyper
         if not self.dense:
+            if self._rms_G is not None:
+                return [("step", lambda p: b.hip.step_sparse(p, t, h, self._rms_G, self.loss_out))]
             return [("step", lambda p: b.step_sparse_adagrad(p, t, h, self.loss_out))]
         if self.rows:
             ph = [("passes", lambda p: b.passes_packing(p, t, h, self.bufs["send"])),
@@ -371,7 +382,7 @@ class Stepper(GraphedSteps):
 
     def step_many(self, plans):
         """Several consecutive steps; on one GPU they are issued by one C call."""
-        if not self.dense and hasattr(self.backend, "steps_sparse_adagrad"):
+        if not self.dense and self.tables.optimizer == "Adagrad" and hasattr(self.backend, "steps_sparse_adagrad"):
             self.backend.steps_sparse_adagrad(plans, self.tables, self.hyper, self.loss_out)
         elif (not self._multi and self.tables.optimizer == "Adam" and not self.rows and hasattr(self.backend, "steps_dense_adam")):
             self.backend.steps_dense_adam(plans, self.tables, self.hyper, self.G, self.loss_out)
@@ -760,7 +771,7 @@ class ReshufflingRunner:
         self.slots = [PlanBlock(plans[:self.S]), PlanBlock(plans[self.S:])]
         self.sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, self.S), 256), dtype=torch.uint8, device=dev)
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, first.cap_chunks, tables.d), dtype=torch.uint8, device=dev)
-        self.G = hip.dense_grad_buffer(tables) if single and tables.optimizer == "Adam" else None
+        self.G = hip.dense_grad_buffer(tables) if single and tables.optimizer in ("Adam", "RMSprop") else None
         # ---- segments: `_g` = the segment the next step belongs to (counted over all epochs), slot = segment % 2
         self._g, self._issued, self._entered = 0, 0, -1
         self._cursor = (stream.epoch, 0)       # (epoch, segment of the epoch) the next build takes
@@ -800,10 +811,12 @@ class ReshufflingRunner:
     def _step(self, plan):
         if self.stepper is not None:
             self.stepper.step(plan)
-        elif self.G is None:
+        elif self.tables.optimizer == "Adagrad":
             self.hip.step_adagrad(plan, self.tables, self.hyper, self.loss_out, self.step_ws)
-        else:
+        elif self.tables.optimizer == "Adam":
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
+        else:                                   # SGD, RMSprop, Adamax by their Keras names
+            self.hip.step_sparse(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
     def _segments_per_epoch(self) -> int:
         return (self.nb + self.S - 1) // self.S
@@ -865,7 +878,7 @@ class ReshufflingRunner:
     def _steps(self, plans):
         """Consecutive steps.  One GPU, Adagrad: one host call (on step-tagged tables the library chains them: one launch per
         step, the global bias handed on through the workspace)."""
-        if self.stepper is None and self.G is None:
+        if self.stepper is None and self.tables.optimizer == "Adagrad":
             self.hip.steps_adagrad(plans, self.tables, self.hyper, self.loss_out, ws=self.step_ws)
         else:
             for plan in plans:

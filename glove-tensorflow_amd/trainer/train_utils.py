@@ -22,6 +22,9 @@ EVAL_INTERVAL = 300
 OPTIMIZERS = {
     "Adagrad": {"initial_accumulator_value": 0.1, "epsilon": 1e-7},
     "Adam": {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7},
+    "SGD": {"momentum": 0.0, "nesterov": False},
+    "RMSprop": {"rho": 0.9, "momentum": 0.0, "epsilon": 1e-7, "centered": False},
+    "Adamax": {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7},
 }
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 9   /* 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 10   /* 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -115,7 +115,28 @@ typedef struct glove_hyper {
      *                                  within fp32 rounding of their sums' order.  Needs chunk records.  AUTO picks it for
      *                                  batches of at most 2,048 pairs when the tables carry tags. */
     int32_t step_form;
+    /* which Keras optimizer glove_step_sparse_f32 applies (reference src/models/train_utils.py:13-16 resolves any Keras name
+     * with `tf.keras.optimizers.get`, handing over the learning rate only: everything else keeps its Keras-legacy default):
+     *   GLOVE_OPT_ADAGRAD  glove_step_adagrad_f32            GLOVE_OPT_ADAM  glove_step_adam_f32
+     *   GLOVE_OPT_SGD      momentum == 0: var -= lr G on the touched rows; otherwise (slot1 = accumulator, zeros) the
+     *                      deduplicated rows take accum = accum momentum - lr G; var += accum (nesterov: var += accum
+     *                      momentum - lr G); untouched rows and their accumulators do not move
+     *   GLOVE_OPT_RMSPROP  (slot1 = rms, zeros) the WHOLE rms slot decays by rho every step — the sparse path of the legacy
+     *                      optimizer does, like its Adam —, (1 - rho) G^2 is added on the touched rows, which alone move:
+     *                      var -= lr G / (sqrt(rms) + epsilon); momentum 0, not centered
+     *   GLOVE_OPT_ADAMAX   (slot1 = m, slot2 = v, zeros) lazy: touched rows only: m = beta1 m + (1 - beta1) G;
+     *                      v = max(beta2 v, |G|); var -= lr / (1 - beta1^t) m / (v + epsilon) */
+    int32_t optimizer;
+    float momentum;             /* SGD, Keras default 0 */
+    int32_t nesterov;           /* SGD, Keras default 0 */
+    float rho;                  /* RMSprop, Keras default 0.9 */
 } glove_hyper;
+
+#define GLOVE_OPT_ADAGRAD 0
+#define GLOVE_OPT_SGD 1
+#define GLOVE_OPT_RMSPROP 2
+#define GLOVE_OPT_ADAMAX 3
+#define GLOVE_OPT_ADAM 4
 
 #define GLOVE_HEAD_REGRESSION 0
 #define GLOVE_HEAD_LOGISTIC 1
@@ -421,6 +442,13 @@ typedef struct glove_build_ring {
 int glove_steps_rebuilt_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
                             int32_t n_steps, int32_t V, const glove_build_ring *ring, const glove_tables *t,
                             const glove_hyper *h, void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
+
+/* One step under the Keras optimizer glove_hyper.optimizer names (passes + one apply launch; RMSprop: passes + the dense
+ * gradient + one sweep over its slots).  G_flat: as glove_step_adam_f32 uses it — needed for GLOVE_OPT_RMSPROP and GLOVE_OPT_ADAM
+ * (glove_dense_grad_floats floats, all zero on entry and on return), ignored otherwise.  GLOVE_OPT_ADAGRAD / GLOVE_OPT_ADAM go to
+ * glove_step_adagrad_f32 / glove_step_adam_f32. */
+int glove_step_sparse_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
+                          void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
 
 /* One Keras-legacy Adam step.  G_flat (glove_dense_grad_floats floats, all zero on entry) is scratch and is all zero
  * again on return.  A batch of at most (V_row + V) / 2 pairs takes two launches: the passes also mark the batch's

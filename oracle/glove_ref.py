@@ -62,6 +62,11 @@ class Hyper:
     # logistic_matrix_factorisation.py:50-54 (then w = positive weight, y = negative weight)
     head: int = 0
     neg_factor: float = 1.0
+    # Keras-legacy defaults of the other optimizers `tf.keras.optimizers.get(name)` resolves (train_utils.py:13-16 hands over
+    # the name and the learning rate only): SGD(momentum=0.0, nesterov=False), RMSprop(rho=0.9, momentum=0.0, centered=False)
+    momentum: float = 0.0
+    nesterov: bool = False
+    rho: float = 0.9
 
 
 class Tables:
@@ -87,8 +92,19 @@ class Tables:
                 setattr(self, "V_" + n, np.zeros_like(getattr(self, n)))
             self.M_g = dtype(0.0)
             self.V_g = dtype(0.0)
+        elif optimizer in ("SGD", "RMSprop"):
+            # SGD: slot "momentum" (zeros; only used with momentum > 0); RMSprop: slot "rms" (zeros)
+            for n in names:
+                setattr(self, "A_" + n, np.zeros_like(getattr(self, n)))
+            self.A_g = dtype(0.0)
+        elif optimizer == "Adamax":
+            for n in names:
+                setattr(self, "M_" + n, np.zeros_like(getattr(self, n)))
+                setattr(self, "V_" + n, np.zeros_like(getattr(self, n)))
+            self.M_g = dtype(0.0)
+            self.V_g = dtype(0.0)
         else:
-            raise ValueError("optimizer must be Adagrad or Adam, got %r" % (optimizer,))
+            raise ValueError("optimizer must be Adagrad, Adam, SGD, RMSprop or Adamax, got %r" % (optimizer,))
 
     def astype(self, dtype):
         out = Tables.__new__(Tables)
@@ -207,6 +223,35 @@ def _adam_dense_decay(W, M, Vv, G, lr_t, b1, b2, eps):
     W -= lr_t * M / (np.sqrt(Vv) + eps)
 
 
+def _sgd(W, A, G, touched, lr, mom, nesterov):
+    """Keras-legacy SGD on an IndexedSlices gradient (optimizer_v2/gradient_descent.py, pinned keras 2.11, stated from knowledge
+    of that source like the other third-party semantics): momentum == 0: scatter-add of -lr g on the touched rows; otherwise
+    ResourceSparseApplyKerasMomentum on the deduplicated rows: accum = accum momentum - lr g; var += accum (nesterov: var +=
+    accum momentum - lr g).  Untouched rows (and their accumulators) do not move."""
+    if mom == 0:
+        W[touched] -= lr * G[touched]
+        return
+    A[touched] = A[touched] * mom - lr * G[touched]
+    W[touched] += (A[touched] * mom - lr * G[touched]) if nesterov else A[touched]
+
+
+def _rmsprop_dense_decay(W, A, G, lr, rho, eps):
+    """Keras-legacy RMSprop `_resource_apply_sparse` (optimizer_v2/rmsprop.py; momentum 0, not centered): the WHOLE rms slot
+    decays by rho, (1 - rho) g^2 is scatter-added on the touched rows, and only those rows move:
+    var -= lr g / (sqrt(rms) + eps).  With g = 0 elsewhere the dense form below is the same."""
+    A *= rho
+    A += (1 - rho) * G * G
+    W -= lr * G / (np.sqrt(A) + eps)
+
+
+def _adamax(W, M, Vv, G, touched, lr_t, b1, b2, eps):
+    """Keras-legacy Adamax `_resource_apply_sparse` (optimizer_v2/adamax.py): lazy — m, v and var of the touched rows only:
+    m = b1 m + (1 - b1) g; v = max(b2 v, |g|); var -= lr_t m / (v + eps), lr_t = lr / (1 - b1^t)."""
+    M[touched] = b1 * M[touched] + (1 - b1) * G[touched]
+    Vv[touched] = np.maximum(b2 * Vv[touched], np.abs(G[touched]))
+    W[touched] -= lr_t * M[touched] / (Vv[touched] + eps)
+
+
 def apply_update(t: Tables, gr, hp: Hyper):
     """Optimizer update of the five variables from summed gradients `gr`; step += 1."""
     dt = t.dtype
@@ -219,6 +264,29 @@ def apply_update(t: Tables, gr, hp: Hyper):
         _adagrad(t.bc, t.A_bc, gr["G_bc"], gr["touched_c"], lr, eps)
         t.A_g = t.A_g + dg * dg
         t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
+    elif t.optimizer == "SGD":
+        mom = dt(np.float32(hp.momentum))
+        for n, side in (("R", "r"), ("C", "c"), ("br", "r"), ("bc", "c")):
+            _sgd(getattr(t, n), getattr(t, "A_" + n), gr["G_" + n], gr["touched_" + side], lr, mom, hp.nesterov)
+        if mom == 0:
+            t.g = t.g - lr * dg
+        else:
+            t.A_g = t.A_g * mom - lr * dg
+            t.g = t.g + ((t.A_g * mom - lr * dg) if hp.nesterov else t.A_g)
+    elif t.optimizer == "RMSprop":
+        rho = dt(np.float32(hp.rho))
+        for n in ("R", "C", "br", "bc"):
+            _rmsprop_dense_decay(getattr(t, n), getattr(t, "A_" + n), gr["G_" + n], lr, rho, eps)
+        t.A_g = rho * t.A_g + (1 - rho) * dg * dg
+        t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
+    elif t.optimizer == "Adamax":
+        b1, b2 = dt(np.float32(hp.beta1)), dt(np.float32(hp.beta2))
+        lr_t = dt(float(lr) / (1.0 - float(b1) ** (t.step + 1)))
+        for n, side in (("R", "r"), ("C", "c"), ("br", "r"), ("bc", "c")):
+            _adamax(getattr(t, n), getattr(t, "M_" + n), getattr(t, "V_" + n), gr["G_" + n], gr["touched_" + side], lr_t, b1, b2, eps)
+        t.M_g = b1 * t.M_g + (1 - b1) * dg
+        t.V_g = max(b2 * t.V_g, abs(dg))
+        t.g = t.g - lr_t * t.M_g / (t.V_g + eps)
     else:
         # Keras casts the hyper-parameters to the variable dtype before use (OptimizerV2._get_hyper(name, var_dtype)):
         # beta_2 = float32(0.999) = 0.99900001287..., so 1 - beta_2 is 1.3e-5 (relative) away from 0.001

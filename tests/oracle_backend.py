@@ -23,7 +23,8 @@ class OracleBackend:
     def build_plan(self, row, col, w, y, V, chunk_cap):
         return tuple(np.asarray(a) for a in (row, col, w, y))
 
-    def make_hyper(self, batch_size, l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, sides=0, head=0, neg_factor=1.0, step_form=0):
+    def make_hyper(self, batch_size, l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, sides=0, head=0, neg_factor=1.0, step_form=0,
+                   optimizer="Adagrad"):
         return dict(hp=ref.Hyper(l2_reg=l2_reg, reg_mult=reg_mult, learning_rate=learning_rate, head=head,
                                  neg_factor=neg_factor),
                     inv_batch=1.0 / batch_size, sides=sides or 3)

@@ -236,3 +236,67 @@ def test_oracle_steps_match_an_independent_autodiff_and_optimizer(optimizer, lr,
             np.testing.assert_allclose(P[n].detach().numpy(), getattr(t, n), err_msg="%s after step %d" % (n, s + 1), **tol)
         np.testing.assert_allclose(P["g"].item(), t.g, **tol)
     assert untouched_moved == (optimizer == "Adam")
+
+
+@pytest.mark.parametrize("optimizer,kw", [("SGD", {}), ("SGD", {"momentum": 0.9}), ("RMSprop", {}), ("Adamax", {})])
+def test_other_keras_optimizers_match_independent_updates(optimizer, kw):
+    """The optimizers `tf.keras.optimizers.get(name)` resolves beyond Adagrad / Adam (train_utils.py:13-16), restated with their
+    Keras-legacy sparse semantics, against machinery the oracle shares no code with: gradients by torch.autograd, the update by
+    torch.optim.SGD (Keras' accum = accum m - lr g, var += accum is torch's buf = m buf + g, var -= lr buf for a constant lr)
+    and torch.optim.RMSprop (alpha = rho; Keras decays the whole rms slot, rows without gradient do not move: the dense form).
+    Adamax is lazy in Keras (touched rows only) and keeps eps in the denominator where torch has it inside the max: checked
+    against a hand-written float64 update of the touched rows."""
+    import torch
+    B, V, d, lr = 48, 9, 5, 0.01
+    hp = ref.Hyper(learning_rate=lr, l2_reg=0.05, reg_mult=2.0, **kw)
+    t = ref.Tables(V, d, optimizer, dtype=np.float64, seed=4)
+    t.g = np.float64(0.1)
+    P = {n: torch.tensor(np.array(getattr(t, n)), dtype=torch.float64, requires_grad=True) for n in ("R", "C", "br", "bc")}
+    P["g"] = torch.tensor(float(t.g), dtype=torch.float64, requires_grad=True)
+    params = list(P.values())
+    f32 = lambda v: float(np.float32(v))
+    opt = None
+    if optimizer == "SGD":
+        opt = torch.optim.SGD(params, lr=f32(lr), momentum=f32(kw.get("momentum", 0.0)))
+    elif optimizer == "RMSprop":
+        opt = torch.optim.RMSprop(params, lr=f32(lr), alpha=f32(0.9), eps=f32(1e-7))
+    state = {n: (np.zeros_like(getattr(t, n)), np.zeros_like(getattr(t, n))) for n in ("R", "C", "br", "bc")}
+    mg, vg = 0.0, 0.0
+    for s in range(5):
+        row, col, w, y = make_batch(70 + s, B, V)
+        row[row == 3] = 4                                       # row 3 is never touched: it must not move (nor its slots)
+        r_, c_ = torch.from_numpy(row).long(), torch.from_numpy(col).long()
+        wt, yt = torch.from_numpy(w).double(), torch.from_numpy(y).double()
+        r, c = P["R"][r_], P["C"][c_]
+        p = (r * c).sum(-1) + P["br"][r_] + P["bc"][c_] + P["g"]
+        L = (wt * (p - yt) ** 2).sum() / B
+        reg = hp.l2_reg / (d * B) * ((r ** 2).sum() + (c ** 2).sum()) + hp.l2_reg / B * ((P["br"][r_] ** 2).sum() + (P["bc"][c_] ** 2).sum()) \
+            + hp.l2_reg * P["g"] ** 2
+        loss = L + hp.reg_mult * reg
+        for q in params:
+            q.grad = None
+        loss.backward()
+        before = P["R"].detach().clone()
+        if opt is not None:
+            opt.step()
+        else:                                                    # Adamax by hand, touched rows only
+            b1, b2, eps = f32(0.9), f32(0.999), f32(1e-7)
+            lr_t = f32(lr) / (1.0 - b1 ** (s + 1))
+            with torch.no_grad():
+                for n, ids in (("R", row), ("C", col), ("br", row), ("bc", col)):
+                    g = P[n].grad.numpy()
+                    m, v = state[n]
+                    u = np.unique(ids)
+                    m[u] = b1 * m[u] + (1 - b1) * g[u]
+                    v[u] = np.maximum(b2 * v[u], np.abs(g[u]))
+                    P[n][torch.from_numpy(u)] -= torch.from_numpy(lr_t * m[u] / (v[u] + eps))
+                dg = P["g"].grad.item()
+                mg = b1 * mg + (1 - b1) * dg
+                vg = max(b2 * vg, abs(dg))
+                P["g"] -= lr_t * mg / (vg + eps)
+        want_loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+        np.testing.assert_allclose(loss.item(), want_loss, rtol=1e-12)
+        assert torch.equal(P["R"].detach()[3], before[3])       # the untouched row
+        for n in ("R", "C", "br", "bc"):
+            np.testing.assert_allclose(P[n].detach().numpy(), getattr(t, n), rtol=1e-9, atol=1e-13, err_msg="%s after step %d" % (n, s + 1))
+        np.testing.assert_allclose(P["g"].item(), t.g, rtol=1e-9, atol=1e-13)
