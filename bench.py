@@ -561,7 +561,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
             stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
         stepper.prepare(plans)
 
-    if mode == "single" and step_form in (0, 5) and not adam and plans[0].r_crec is not None:
+    if mode == "single" and step_form in (0, 5) and plans[0].r_crec is not None:
         tables.maybe_enable_tags(B)         # small batches on small tables: the tagged step (as Stepper does)
     if mode == "single" and step_form == 0 and not adam and plans[0].r_crec is not None and \
             (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES:
@@ -608,6 +608,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                     # as the trainer's static mode issues them (Stepper.step_many): one host call; on step-tagged tables the
                     # library chains consecutive small batches, one launch per step
                     hip.steps_adagrad([plans[i % nb] for i in range(spg)], tables, hyper, loss_out, ws=ws)
+                elif stepper is None:
+                    hip.steps_adam([plans[i % nb] for i in range(spg)], tables, hyper, G, loss_out, ws=ws)
                 else:
                     for i in range(spg):
                         step(i)

@@ -300,6 +300,8 @@ struct SideOut {
     int heavy_chunks, cap_heavy;
     int2 *chunk_aux[2];                                   // per chunk (or nullptr): {position of its id among the side's ids, first chunk
                                                           // of its id << 31 | chunks of the id behind it}: words 2, 3 of its record header
+    uint32_t *mark[2];                                    // per side (or nullptr): bitmap of the batch's ids — zeroed by side_tiles, set by side_emit
+    int mark_words[2];
 };
 
 // flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
@@ -444,6 +446,7 @@ struct SideDev {
     SortedWs ws;
     int64_t B;
     int ntiles;
+    int32_t V;
 };
 __device__ inline SideOne pick(const SideDev &a)
 {
@@ -459,7 +462,8 @@ __device__ inline SideOne pick(const SideDev &a)
     o.ex = TileExtra{tile_re, pl.counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     o.out = SideOut{{pl.r_chunk_id, pl.c_chunk_id}, {pl.r_chunk_start, pl.c_chunk_start}, {pl.r_uniq_slot, pl.c_uniq_slot},
                     pl.counts, {pl.r_uniq_rec, pl.c_uniq_rec}, tile_re, pl.heavy, pl.heavy_chunks, pl.cap_heavy,
-                    {pl.r_crec ? aux0 : nullptr, pl.r_crec ? aux1 : nullptr}};
+                    {pl.r_crec ? aux0 : nullptr, pl.r_crec ? aux1 : nullptr},
+                    {pl.r_mark, pl.c_mark}, {((pl.V_row > 0 ? pl.V_row : a.V) + 31) / 32, (a.V + 31) / 32}};
     o.cp = SideCopy{{a.src.partner[0] + at, a.src.partner[1] + at}, {a.src.w[0] + at, a.src.w[1] + at}, {a.src.y[0] + at, a.src.y[1] + at},
                     {pl.r_partner, pl.c_partner}, {pl.r_w, pl.c_w}, {pl.r_y, pl.c_y}};
     return o;
@@ -478,6 +482,12 @@ __global__ __launch_bounds__(kTileThreads) void side_tiles(Args args, int64_t B,
     const int side = blockIdx.y, t = blockIdx.x;
     const int32_t *keys = SIDE(sk.keys);
     const int64_t begin = (int64_t)t * kTile;
+    if (SIDE(one.out.mark)) {
+        // this tile's share of the side's id bitmap starts at zero (side_emit, the next launch, sets the bits)
+        uint32_t *mk = SIDE(one.out.mark);
+        const int words = SIDE(one.out.mark_words);
+        for (int i = t * kTileThreads + (int)threadIdx.x; i < words; i += ntiles * kTileThreads) mk[i] = 0u;
+    }
     if (SIDE(one.cp.p_dst)) {
         // the batch arrived sorted and its plan keeps the pair fields itself (no chunk records): coalesced copy, a wave's
         // lanes on consecutive positions
@@ -640,6 +650,7 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
         }
         if (!(flag[i] & 2u)) continue;
         reinterpret_cast<int4 *>(SIDE(out.uniq_rec))[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
+        if (SIDE(out.mark)) atomicOr(SIDE(out.mark) + (keys[k] >> 5), 1u << (keys[k] & 31));
         if (chunks > out.heavy_chunks) {
             const int slot = atomicAdd(out.counts + 4, 1);  // zeroed by side_tiles, the launch before this one
             if (slot < out.cap_heavy) out.heavy[slot] = (side << 30) | open_ui[i];
@@ -873,6 +884,8 @@ static PlanWs carve_plan_ws(void *ws, int64_t B)
     return p;
 }
 
+static inline int32_t Vr_of(const glove_plan *plan, int32_t V) { return plan->V_row > 0 ? plan->V_row : V; }
+
 static int ceil_log2(int32_t v)
 {
     int b = 1;
@@ -966,7 +979,8 @@ static int build_tiled_set(const int32_t *row, const int32_t *col, const float *
         ss.b[j].out = SideOut{{plan->r_chunk_id, plan->c_chunk_id}, {plan->r_chunk_start, plan->c_chunk_start},
                             {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
                             (const int64_t *)pw[j].tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
-                            {plan->r_crec ? pw[j].chunk_aux[0] : nullptr, plan->r_crec ? pw[j].chunk_aux[1] : nullptr}};
+                            {plan->r_crec ? pw[j].chunk_aux[0] : nullptr, plan->r_crec ? pw[j].chunk_aux[1] : nullptr},
+                            {plan->r_mark, plan->c_mark}, {(Vr_of(plan, V) + 31) / 32, (V + 31) / 32}};
         ss.b[j].cp = SideCopy{};
         ss.b[j].ex = TileExtra{pw[j].tile_re, plan->counts, (const int32_t *)pw[j].mapped, 2 * pw[j].sort_tiles,
                              (const int32_t *)pw[j].c_orig, (const int32_t *)pw[j].rpos, plan->c_perm, plan->r_to_c};
@@ -1030,6 +1044,7 @@ static int check_plan_for_build(const glove_plan *plan, int64_t B, int32_t V)
     if (plan->cap_chunks < B || plan->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
     if ((plan->r_to_c == nullptr) != (plan->c_perm == nullptr)) return GLOVE_E_BADARG;     // the links come as a pair or not at all
+    if ((plan->r_mark == nullptr) != (plan->c_mark == nullptr)) return GLOVE_E_BADARG;     // so do the id bitmaps
     return 0;
 }
 
@@ -1154,6 +1169,7 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
         if (own && (!p->r_partner || !p->r_w || !p->r_y || !p->c_partner || !p->c_w || !p->c_y)) return GLOVE_E_BADARG;
         if (!own && !p->r_crec) return GLOVE_E_BADARG;
         if (p->c_perm || p->r_to_c) return GLOVE_E_BADARG;              // the links between the orders are not computed here
+        if ((p->r_mark == nullptr) != (p->c_mark == nullptr)) return GLOVE_E_BADARG;
         if (!p->heavy || p->heavy_chunks < 1 || p->cap_heavy < 2 * B / ((int64_t)p->heavy_chunks * p->chunk_cap) + 2) return GLOVE_E_WORKSPACE;
         if (p->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
         if (p->cap_chunks < glove_plan_chunk_bound(B, p->cap_uniq, p->chunk_cap)) return GLOVE_E_WORKSPACE;
@@ -1167,6 +1183,7 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
                        {row_side->w + first_pair, col_side->w + first_pair}, {row_side->y + first_pair, col_side->y + first_pair}};
     sd.ws = carve_sorted_ws(ws, B, &sd.ntiles);
     sd.B = B;
+    sd.V = V;
     if (sd.ws.per_batch * (size_t)n_batches > ws_bytes) return GLOVE_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int32_t cap = plans[0].chunk_cap;

@@ -123,6 +123,7 @@ __device__ inline void block_sort_pairs(const Team &tm, uint32_t (&key)[E], int3
 }
 
 struct SmallSideOut {
+    uint32_t *mark;             // bitmap of the side's ids (or nullptr)
     int32_t *chunk_id, *chunk_start, *uniq_slot, *uniq_rec;
     int32_t *crec;              // per-chunk records (or nullptr): words 2, 3 of every record header are written here
     int rec_dwords;             // int32 per record in memory
@@ -211,7 +212,10 @@ __device__ inline void small_side(const Team &tm, const int32_t *ids, int B, int
         open_ui[e] = ui;
         open_ci[e] = ci;
         if (k >= B) continue;
-        if (uniq >> e & 1) o.uniq_slot[ui++] = ci;
+        if (uniq >> e & 1) {
+            o.uniq_slot[ui++] = ci;
+            if (o.mark) atomicOr(o.mark + (id[e + 1] >> 5), 1u << (id[e + 1] & 31));
+        }
         if (chunk >> e & 1) { o.chunk_id[ci] = id[e + 1]; o.chunk_start[ci] = k; ++ci; }
         if (k == B - 1) {                                                   // closing entries and totals
             o.chunk_start[ci] = B;
@@ -299,8 +303,8 @@ __device__ inline void build_side(int team, const Team &tm, uint32_t *kbuf, int3
         }
     }
     const int rd = 4 * rec_stride_q(rec_cap(plan.chunk_cap));
-    const SmallSideOut so = team == 0 ? SmallSideOut{plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec, plan.r_crec, rd}
-                                      : SmallSideOut{plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec, plan.c_crec, rd};
+    const SmallSideOut so = team == 0 ? SmallSideOut{plan.r_mark, plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec, plan.r_crec, rd}
+                                      : SmallSideOut{plan.c_mark, plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec, plan.c_crec, rd};
     small_side<TT, E>(tm, reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, team, L,
                       so, plan.counts, plan.heavy);
     SMALL_STAMP(4);                                                      // side numbered and stored
@@ -336,6 +340,11 @@ __global__ __launch_bounds__(T) void plan_small_kernel(
     SmallLds *L = reinterpret_cast<SmallLds *>(sy + np);                 // [NT]
     // every word of `counts` is written by this kernel: [4] (heavy ids) before anybody appends behind it, the rest at the end
     if (threadIdx.x == 0) plan.counts[4] = 0;
+    if (plan.r_mark) {                                                   // the id bitmaps start at zero (small_side sets the bits behind the barriers below)
+        const int wr = ((plan.V_row > 0 ? plan.V_row : V) + 31) / 32, wc = (V + 31) / 32;
+        for (int i = threadIdx.x; i < wr; i += T) plan.r_mark[i] = 0u;
+        for (int i = threadIdx.x; i < wc; i += T) plan.c_mark[i] = 0u;
+    }
     SMALL_STAMP(0);
     // ---- the batch into LDS (coalesced; both sides sort and gather from there); ids outside their table count as id 0 (the
     // reference's unknown-token id, estimator.py:26-28; see glove_plan.hip)

@@ -1528,6 +1528,341 @@ __global__ __launch_bounds__(kBlock) void tagged_flush_kernel(float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Keras-legacy Adam in ONE launch per step (the reference's default optimizer at its default batch: configs/app.ini:39-53),
+// on twinned tables.  The legacy optimizer's sparse path rewrites EVERY row every step (m *= b1, v *= b2, var -= lr_t
+// m / (sqrt(v) + eps) over the whole table, a11), so the twin needs no tags: a step reads copy c of both tables and writes
+// copy 1 - c of both, all rows — the batch's rows by the lane group that holds the first chunk of the id (gradient, then
+// Adam, as in the tagged Adagrad step), every other row by a sweep that finds the batch's ids in the plan's bitmaps
+// (glove_plan.r_mark / c_mark) and leaves them alone.  scalars[3] says which copy is current between chains.  The global bias
+// travels through chain records like the tagged Adagrad step's ([0] bias, [1] m, [2] v as the step began).
+// ------------------------------------------------------------------------------------------
+constexpr int kSweepRows = 2;       // table rows a sweep lane group keeps in flight
+
+struct AdamSide {
+    const int32_t *crec;
+    float *own, *own_bias;              // this side's table and bias vector, twinned
+    const float *other, *other_bias;    // the partner table, twinned
+    float *S1, *S1b, *S2, *S2b;         // m and v (never twinned: only the row's owner or sweeper touches them)
+    const uint32_t *mark;               // bitmap of the batch's ids of this side
+    int own_twin, other_twin;           // rows between the two copies = rows of the table
+    int n_host, count_index, capP, cap_chunks;
+};
+
+template <int LPR, int NV, bool FULL>
+__global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_adam_kernel(
+    const int32_t *__restrict__ counts, AdamSide rowside, AdamSide colside, int row_blocks, int chunk_blocks,
+    const float *__restrict__ scalars, const int64_t *__restrict__ step, int d4, float inv_batch, int head, float neg_factor,
+    StepConsts kc, float b1, float b2, double ln_beta1, double ln_beta2, const float *__restrict__ prev, int prev_blocks,
+    float *__restrict__ mine, int chain_i)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const uint32_t cur = (scalars[3] != 0.f ? 1u : 0u) ^ (uint32_t)(chain_i & 1);     // the copy this step reads (scalars[3]: as the chain began)
+    const int64_t t = *step + chain_i + 1;                                            // global_step stands still during a chain
+    const float lr_t = adam_lr_t(kc.lr, ln_beta1, ln_beta2, t);
+    if ((int)blockIdx.x >= chunk_blocks) {
+        // ---- sweep: a lane group per table row (R's rows first, then C's), kSweepRows rows in flight; the batch's rows belong
+        // to the chunk groups
+        const int sb0 = blockIdx.x - chunk_blocks, nsb = gridDim.x - chunk_blocks;
+        const int Vr = rowside.own_twin, Vc = colside.own_twin;
+        const int total = Vr + Vc, stride = nsb * GPB;
+        for (int v0 = sb0 * GPB + grp; v0 < total; v0 += kSweepRows * stride) {
+            f4 Wv[kSweepRows][NV], M[kSweepRows][NV], Vv[kSweepRows][NV];
+            float bval[kSweepRows], Mb[kSweepRows], Vb[kSweepRows];
+            uint32_t mk[kSweepRows];
+#pragma unroll
+            for (int r = 0; r < kSweepRows; ++r) {
+                const int v = v0 + r * stride;
+                const bool live = v < total, is_row = v < Vr;
+                const int id = live ? (is_row ? v : v - Vr) : 0;
+                const AdamSide &sd = is_row ? rowside : colside;
+                mk[r] = live ? (sd.mark[id >> 5] >> (id & 31)) & 1u : 1u;
+                const int at = id + (cur ? sd.own_twin : 0);
+                load_row<LPR, NV>(Wv[r], sd.own, at, d4, lg);
+                load_row<LPR, NV>(M[r], sd.S1, id, d4, lg);
+                load_row<LPR, NV>(Vv[r], sd.S2, id, d4, lg);
+                bval[r] = Mb[r] = Vb[r] = 0.f;
+                if (lg == 0) { bval[r] = sd.own_bias[at]; Mb[r] = sd.S1b[id]; Vb[r] = sd.S2b[id]; }
+            }
+#pragma unroll
+            for (int r = 0; r < kSweepRows; ++r) {
+                const int v = v0 + r * stride;
+                if (v >= total || mk[r]) continue;
+                const bool is_row = v < Vr;
+                const int id = is_row ? v : v - Vr;
+                const AdamSide &sd = is_row ? rowside : colside;
+                const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < NV; ++kk) adam_vec(Wv[r][kk], M[r][kk], Vv[r][kk], zero, lr_t, b1, b2, kc.eps);
+                const int to = id + (cur ? 0 : sd.own_twin);
+                store_row<LPR, NV>(sd.S1, (size_t)id, d4, lg, M[r]);
+                store_row<LPR, NV>(sd.S2, (size_t)id, d4, lg, Vv[r]);
+                store_row<LPR, NV>(sd.own, (size_t)to, d4, lg, Wv[r]);
+                if (lg == 0) {
+                    adam_elem(bval[r], Mb[r], Vb[r], 0.f, lr_t, b1, b2, kc.eps);
+                    sd.S1b[id] = Mb[r];
+                    sd.S2b[id] = Vb[r];
+                    sd.own_bias[to] = bval[r];
+                }
+            }
+        }
+        return;
+    }
+    constexpr int U = PassUnroll<NV>::value;
+    constexpr int kRecStride = 4 + 3 * kChunkMax + 4;
+    __shared__ __attribute__((aligned(16))) uint32_t fld_raw[GPB * kRecStride];
+    uint32_t *rec = fld_raw + (threadIdx.x / LPR) * kRecStride;
+    const bool is_row = (int)blockIdx.x < row_blocks;
+    const AdamSide &sd = is_row ? rowside : colside;
+    const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
+    const int nblk = is_row ? row_blocks : chunk_blocks - row_blocks;
+    // the group's first record is requested before anything else (as in tagged_step_kernel)
+    constexpr int kPre = (1 + 3 * kChunkMax / 4 + LPR - 1) / LPR;
+    uint4 pre[kPre];
+    {
+        const int jf = bid * GPB + grp;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)(jf < sd.cap_chunks ? jf : sd.cap_chunks - 1) * rec_stride_q(sd.capP);
+        const int rq0 = 1 + 3 * sd.capP / 4;
+#pragma unroll
+        for (int x = 0; x < kPre; ++x) {
+            const int f = lg + x * LPR;
+            pre[x] = rp[rec_gq(f < rq0 ? f : 0)];
+        }
+    }
+    const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
+    float part[kPartials] = {0.f, 0.f, 0.f, 0.f};
+    const int capP = sd.capP;
+    const int rq = 1 + 3 * capP / 4;
+    const int sq = rec_stride_q(capP);
+    // ---- the global bias of THIS step: derived by every workgroup from the record the step before left (tagged_step_kernel)
+    __shared__ float s_g[3];
+    if (prev) {
+        float tot[kPartials];
+        sum_blockpart(prev + kChainHead, prev_blocks, tot);
+        if (threadIdx.x == 0) {
+            const float g0 = prev[0];
+            const float dg = tot[3] + 2.0f * kc.m * kc.l2 * g0;
+            float gn = g0, Mg = prev[1], Vg = prev[2];
+            adam_elem(gn, Mg, Vg, dg, adam_lr_t(kc.lr, ln_beta1, ln_beta2, t - 1), b1, b2, kc.eps);
+            s_g[0] = gn; s_g[1] = Mg; s_g[2] = Vg;
+        }
+    } else if (threadIdx.x == 0) {
+        s_g[0] = scalars[0]; s_g[1] = scalars[1]; s_g[2] = scalars[2];
+    }
+    __syncthreads();
+    const float g = s_g[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mine[0] = g; mine[1] = s_g[1]; mine[2] = s_g[2]; }
+    float *blockpart = mine + kChainHead;
+    const uint32_t other_add = cur ? (uint32_t)sd.other_twin : 0u;
+
+    for (int j0 = bid * GPB + grp; j0 < n_chunks; j0 += nblk * GPB) {
+        {
+            uint4 *lrec = reinterpret_cast<uint4 *>(rec);
+            if (j0 == bid * GPB + grp) {
+#pragma unroll
+                for (int x = 0; x < kPre; ++x) {
+                    const int f = lg + x * LPR;
+                    if (f < rq) lrec[f] = pre[x];
+                }
+            } else {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j0 * sq;
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[rec_gq(f)];
+            }
+        }
+        uint4 hdr = *reinterpret_cast<const uint4 *>(rec);
+        if (!(hdr.w >> 31)) continue;                           // the group that holds the id's first chunk does the whole id
+        const int32_t u = (int32_t)hdr.x;
+        const int chunks = 1 + (int)(hdr.w & 0x7fffffffu);
+        const int32_t own_at = u + (cur ? sd.own_twin : 0);
+        f4 r[NV], M[NV], Vv[NV], G[NV];
+        load_row<LPR, NV>(r, sd.own, own_at, d4, lg);
+        const float own_b = sd.own_bias[own_at];
+        load_row<LPR, NV>(M, sd.S1, u, d4, lg);
+        load_row<LPR, NV>(Vv, sd.S2, u, d4, lg);
+        float Mb = sd.S1b[u], Vb = sd.S2b[u];
+        const float bg = own_b + g;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) G[k] = f4{0.f, 0.f, 0.f, 0.f};
+        float Gb = 0.f;
+        int pairs = 0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int j = j0 + ch;
+            if (ch > 0) {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j * sq;
+                uint4 *lrec = reinterpret_cast<uint4 *>(rec);
+                for (int f = lg; f < rq; f += LPR) lrec[f] = rp[rec_gq(f)];
+                hdr = *reinterpret_cast<const uint4 *>(rec);
+            }
+            const int n = (int)hdr.y;
+            pairs += n;
+            f4 acc[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+            float se_c = 0.f, cc_sum = 0.f, bsq = 0.f, ed = 0.f;
+            for (int q0 = 0; q0 < n; q0 += U) {
+                int32_t col[U];
+                float w2[U], yq[U];
+#pragma unroll
+                for (int a4 = 0; a4 < U; a4 += 4) {
+                    const int rp0 = rec_pair(q0 + a4);
+                    const uint4 pc = *reinterpret_cast<const uint4 *>(&rec[rp0]);
+                    const uint4 pw = *reinterpret_cast<const uint4 *>(&rec[rp0 + kRecPad]);
+                    const uint4 py = *reinterpret_cast<const uint4 *>(&rec[rp0 + 2 * kRecPad]);
+                    col[a4] = (int32_t)(pc.x + other_add); col[a4 + 1] = (int32_t)(pc.y + other_add);
+                    col[a4 + 2] = (int32_t)(pc.z + other_add); col[a4 + 3] = (int32_t)(pc.w + other_add);
+                    const float sc2 = 2.0f * inv_batch;
+                    w2[a4] = sc2 * __uint_as_float(pw.x); w2[a4 + 1] = sc2 * __uint_as_float(pw.y);
+                    w2[a4 + 2] = sc2 * __uint_as_float(pw.z); w2[a4 + 3] = sc2 * __uint_as_float(pw.w);
+                    yq[a4] = __uint_as_float(py.x); yq[a4 + 1] = __uint_as_float(py.y);
+                    yq[a4 + 2] = __uint_as_float(py.z); yq[a4 + 3] = __uint_as_float(py.w);
+                }
+                f4 c[U][NV];
+                float bcv[U];
+#pragma unroll
+                for (int a = 0; a < U; ++a) {
+                    load_row_fast<LPR, NV, FULL>(c[a], sd.other, col[a], d4, lg);
+                    bcv[a] = 0.f;
+                    if (lg == 0) bcv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sd.other_bias) + (uint32_t)col[a] * 4u);
+                }
+                float dp[U], cc[U];
+#pragma unroll
+                for (int a = 0; a < U; ++a) {
+                    dp[a] = 0.f; cc[a] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) { dp[a] += dot4(r[k], c[a][k]); cc[a] += dot4(c[a][k], c[a][k]); }
+                    dp[a] += bcv[a];
+                }
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0xB1>(dp[a]);
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x4E>(dp[a]);
+#pragma unroll
+                for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x141>(dp[a]);
+                if (LPR >= 16) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] = dpp_add<0x140>(dp[a]);
+                }
+                if (LPR >= 32) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 16, 64);
+                }
+                if (LPR >= 64) {
+#pragma unroll
+                    for (int a = 0; a < U; ++a) dp[a] += __shfl_xor(dp[a], 32, 64);
+                }
+#pragma unroll
+                for (int a = 0; a < U; ++a) {
+                    const float valid = (q0 + a < n) ? 1.0f : 0.f;
+                    float e;
+                    if (head == GLOVE_HEAD_REGRESSION) {
+                        const float diff = (dp[a] + bg) - yq[a];
+                        e = w2[a] * diff;
+                        ed += e * diff;
+                    } else {
+                        const float p = dp[a] + bg;
+                        const float en = expf(-fabsf(p));
+                        const float s = (p >= 0.f ? 1.0f : en) / (1.0f + en);
+                        const float lse = log1pf(en);
+                        const float wn = 2.0f * inv_batch * neg_factor * valid * yq[a];
+                        e = 0.5f * (w2[a] * (s - 1.0f) + wn * s);
+                        ed += w2[a] * (fmaxf(-p, 0.f) + lse) + wn * (fmaxf(p, 0.f) + lse);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) acc[k] += e * c[a][k];
+                    se_c += e;
+                    cc_sum += valid * cc[a];
+                    bsq += valid * bcv[a] * bcv[a];
+                }
+            }
+            if (is_row) {
+                float rr = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) rr += dot4(r[k], r[k]);
+                part[1] += cc_sum + (float)n * rr;
+                if (lg == 0) {
+                    part[0] += ed;
+                    part[2] += bsq + (float)n * own_b * own_b;
+                    part[3] += se_c;
+                }
+            }
+            if (ch == 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) G[k] = acc[k];
+                Gb = se_c;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) G[k] += acc[k];
+                Gb += se_c;
+            }
+        }
+        {
+            float bval = own_b;
+            const float cnt = (float)pairs;
+            const float kcn = kc.kappa * cnt;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) G[k] += kcn * r[k];
+            Gb += kc.kappa_b * cnt * bval;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) adam_vec(r[k], M[k], Vv[k], G[k], lr_t, b1, b2, kc.eps);
+            store_row<LPR, NV>(sd.S1, (size_t)u, d4, lg, M);
+            store_row<LPR, NV>(sd.S2, (size_t)u, d4, lg, Vv);
+            const int32_t new_at = u + (cur ? 0 : sd.own_twin);
+            store_row<LPR, NV>(sd.own, (size_t)new_at, d4, lg, r);
+            if (lg == 0) {
+                adam_elem(bval, Mb, Vb, Gb, lr_t, b1, b2, kc.eps);
+                sd.S1b[u] = Mb;
+                sd.S2b[u] = Vb;
+                sd.own_bias[new_at] = bval;
+            }
+        }
+    }
+    if (is_row) {
+        part[0] *= 0.5f / inv_batch;
+        block_partials_store(part, blockpart);
+    }
+}
+
+// The end of a chain of n one-launch Adam steps: loss, the global bias the next step begins with, which copy is current, global_step
+__global__ __launch_bounds__(kBlock) void tagged_adam_flush_kernel(float *__restrict__ scalars, int64_t *__restrict__ step,
+                                                                   const float *__restrict__ last, int nblocks, int n, StepConsts k,
+                                                                   float b1, float b2, double ln_beta1, double ln_beta2,
+                                                                   float *__restrict__ loss_out)
+{
+    float tot[kPartials];
+    sum_blockpart(last + kChainHead, nblocks, tot);
+    if (threadIdx.x == 0) {
+        const float g = last[0];
+        float loss, L, reg;
+        loss_from_partials(tot, k, g, loss, L, reg);
+        const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
+        float gn = g, Mg = last[1], Vg = last[2];
+        adam_elem(gn, Mg, Vg, dg, adam_lr_t(k.lr, ln_beta1, ln_beta2, *step + n), b1, b2, k.eps);
+        scalars[0] = gn; scalars[1] = Mg; scalars[2] = Vg;
+        if (n & 1) scalars[3] = scalars[3] != 0.f ? 0.f : 1.0f;
+        if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
+        *step += n;
+    }
+}
+
+// Twinned tables whose second copies are current as a whole (the one-launch Adam step, scalars[3] != 0): every row home
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void twin_home_kernel(float *__restrict__ W, float *__restrict__ bias, const float *__restrict__ scalars,
+                                                           int V, int d4)
+{
+    if (scalars[3] == 0.f) return;
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int u = blockIdx.x * GPB + grp; u < V; u += gridDim.x * GPB) {
+        f4 v[NV];
+        load_row<LPR, NV>(v, W, u + V, d4, lg);
+        store_row<LPR, NV>(W, (size_t)u, d4, lg, v);
+        if (lg == 0) bias[u] = bias[u + V];
+    }
+}
+
+__global__ void twin_home_done_kernel(float *scalars) { if (threadIdx.x == 0 && blockIdx.x == 0) scalars[3] = 0.f; }
+
 // Step-tagged twinned tables back to the plain form: rows whose current copy is the second one are copied home, tags cleared
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void untag_kernel(float *__restrict__ W, float *__restrict__ bias, uint64_t *__restrict__ tag,
@@ -1827,8 +2162,6 @@ struct AdamApply {
         }
     }
 };
-
-constexpr int kSweepRows = 2;
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void adam_fused_kernel(
@@ -2703,6 +3036,15 @@ int glove_canonicalize_f32(const glove_tables *t, void *stream)
         hipLaunchKernelGGL((untag_kernel<LPR, NV>), dim3(nbc), dim3(kBlock), 0, st, t->C, t->bc, t->C_tag, (int)t->V, d4)
         GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
+        // the one-launch Adam step flips the tables as a whole (scalars[3]) instead of tagging rows
+        if (t->scalars) {
+#define CALL(LPR, NV)                                                                                                  \
+            hipLaunchKernelGGL((twin_home_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, t->R, t->br, (const float *)t->scalars, Vr, d4);  \
+            hipLaunchKernelGGL((twin_home_kernel<LPR, NV>), dim3(nbc), dim3(kBlock), 0, st, t->C, t->bc, (const float *)t->scalars, (int)t->V, d4)
+            GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+            hipLaunchKernelGGL(twin_home_done_kernel, dim3(1), dim3(64), 0, st, t->scalars);
+        }
         return (int)hipGetLastError();
     }
 #define CALL(LPR, NV) hipLaunchKernelGGL((canonicalize_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, t->R, t->br, t->R_ver, Vr, d4)
@@ -2765,9 +3107,86 @@ static int step_adam_fused(const glove_plan *p, const glove_tables *t, const glo
     return (int)hipGetLastError();
 }
 
+// Whether an Adam step takes the one-launch form (tagged_adam_kernel): twinned tables (glove_tables.R_tag / C_tag are the
+// sign; the tags themselves stay zero), a plan with chunk records and id bitmaps, a small batch that touches a minority of the rows
+static bool adam_one_launch(const glove_plan *p, const glove_tables *t, const glove_hyper *h)
+{
+    if (!p || !t || !h || sides_of(h) != 3) return false;
+    if (!t->R_tag || !t->C_tag || !p->r_crec || !p->c_crec || !p->r_mark || !p->c_mark) return false;
+    if (h->step_form != GLOVE_STEP_AUTO && h->step_form != GLOVE_STEP_TAGGED) return false;
+    return p->B <= 2048 && 2 * p->B <= (int64_t)v_row(t) + t->V;
+}
+
+// n consecutive one-launch Adam steps: chain records in the workspace as launch_tagged_chain keeps them, one epilogue per chain
+static int launch_adam_chain(const glove_plan *const *plans, int n, const glove_tables *t, const glove_hyper *h, void *ws,
+                             size_t ws_bytes, float *loss_out, void *stream)
+{
+    if (!plans || n < 1 || !t || !h || !ws) return GLOVE_E_BADARG;
+    const int d4 = t->d / 4;
+    int most_blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        const glove_plan *p = plans[i];
+        if (int rc = check_common(p, t, h, ws)) return rc;
+        if (!adam_one_launch(p, t, h)) return GLOVE_E_BADARG;
+        const int rb = rowpass_blocks(p, pass_shape(d4).lpr);
+        most_blocks = rb > most_blocks ? rb : most_blocks;
+    }
+    if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc || !t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc) return GLOVE_E_BADARG;
+    if (!(h->beta1 > 0.0 && h->beta1 < 1.0 && h->beta2 > 0.0 && h->beta2 < 1.0)) return GLOVE_E_BADARG;
+    const size_t rec_floats = (size_t)kChainHead + (size_t)kPartials * most_blocks;
+    const size_t fit = ws_bytes / (rec_floats * sizeof(float));
+    if (fit < 1) return GLOVE_E_WORKSPACE;
+    const RowShape shape = pass_shape(d4);
+    const int Vr = v_row(t);
+    const StepConsts kc = make_consts(t, h);
+    const float b1 = (float)h->beta1, b2 = (float)h->beta2;
+    const double ln_b1 = log((double)b1), ln_b2 = log((double)b2);
+    hipStream_t st = (hipStream_t)stream;
+    float *recs = (float *)ws;
+    // the sweep's part of the grid: as adam_fused_kernel's; a multiple of 8 workgroups in front of it, so that every step's sweep
+    // finds the rows it wrote last step in the same L2s
+    const int sweep_blocks = blocks_for(((int64_t)Vr + t->V + kSweepRows - 1) / kSweepRows, kBlock / shape.lpr);
+    for (int i0 = 0; i0 < n; i0 += (int)fit) {
+        const int m = n - i0 < (int)fit ? n - i0 : (int)fit;
+        int prev_blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            const glove_plan *p = plans[i0 + i];
+            const int row_blocks = rowpass_blocks(p, shape.lpr), chunk_blocks = (2 * row_blocks + 7) & ~7;
+            const int nb = chunk_blocks + sweep_blocks;
+            AdamSide rs, cs;
+            rs.crec = p->r_crec; rs.own = t->R; rs.own_bias = t->br; rs.other = t->C; rs.other_bias = t->bc;
+            rs.S1 = t->s1_R; rs.S1b = t->s1_br; rs.S2 = t->s2_R; rs.S2b = t->s2_br; rs.mark = p->r_mark; rs.own_twin = Vr; rs.other_twin = t->V;
+            rs.n_host = p->host_counts[0]; rs.count_index = 0; rs.capP = rec_cap(p->chunk_cap);
+            cs.crec = p->c_crec; cs.own = t->C; cs.own_bias = t->bc; cs.other = t->R; cs.other_bias = t->br;
+            cs.S1 = t->s1_C; cs.S1b = t->s1_bc; cs.S2 = t->s2_C; cs.S2b = t->s2_bc; cs.mark = p->c_mark; cs.own_twin = t->V; cs.other_twin = Vr;
+            cs.n_host = p->host_counts[2]; cs.count_index = 2; cs.capP = rs.capP;
+            rs.cap_chunks = cs.cap_chunks = p->cap_chunks > 0 ? p->cap_chunks : 1;
+            const float *prev = i > 0 ? recs + (size_t)(i - 1) * rec_floats : nullptr;
+            float *mine = recs + (size_t)i * rec_floats;
+#define CALL(LPR, NV)                                                                                                           \
+            if (LPR * NV == d4)                                                                                                 \
+                hipLaunchKernelGGL((tagged_adam_kernel<LPR, NV, true>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, row_blocks, \
+                                   chunk_blocks, (const float *)t->scalars, (const int64_t *)t->step, d4, h->inv_batch, (int)h->head, \
+                                   h->neg_factor, kc, b1, b2, ln_b1, ln_b2, prev, prev_blocks, mine, i);                        \
+            else                                                                                                                \
+                hipLaunchKernelGGL((tagged_adam_kernel<LPR, NV, false>), dim3(nb), dim3(kBlock), 0, st, p->counts, rs, cs, row_blocks, \
+                                   chunk_blocks, (const float *)t->scalars, (const int64_t *)t->step, d4, h->inv_batch, (int)h->head, \
+                                   h->neg_factor, kc, b1, b2, ln_b1, ln_b2, prev, prev_blocks, mine, i)
+            GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
+#undef CALL
+            prev_blocks = row_blocks;
+        }
+        hipLaunchKernelGGL(tagged_adam_flush_kernel, dim3(1), dim3(kBlock), 0, st, t->scalars, t->step,
+                           (const float *)(recs + (size_t)(m - 1) * rec_floats), prev_blocks, m, kc, b1, b2, ln_b1, ln_b2,
+                           i0 + m == n ? loss_out : nullptr);
+    }
+    return (int)hipGetLastError();
+}
+
 int glove_step_adam_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                         float *G_flat, float *loss_out, void *stream)
 {
+    if (adam_one_launch(p, t, h)) return launch_adam_chain(&p, 1, t, h, ws, ws_bytes, loss_out, stream);
     // a batch that touches a minority of the rows (the reference's 1,024 pairs): two launches, no gradient buffer
     // traffic; a batch that touches most rows: the dense form, whose sweep then wastes nothing
     if (int rc = plain_table(t, stream)) return rc;
@@ -2829,9 +3248,18 @@ int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_
                          void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream)
 {
     if (!plans || n < 0) return GLOVE_E_BADARG;
-    for (int32_t i = 0; i < n; ++i)
-        if (int rc = glove_step_adam_f32(plans[i], t, h, ws, ws_bytes, G_flat, i == n - 1 ? loss_out : nullptr, stream))
-            return rc;
+    // runs of consecutive steps that take the one-launch form go out as chains
+    for (int32_t i = 0; i < n;) {
+        int32_t k = i;
+        while (k < n && adam_one_launch(plans[k], t, h)) ++k;
+        if (k > i) {
+            if (int rc = launch_adam_chain(plans + i, k - i, t, h, ws, ws_bytes, k == n ? loss_out : nullptr, stream)) return rc;
+            i = k;
+            continue;
+        }
+        if (int rc = glove_step_adam_f32(plans[i], t, h, ws, ws_bytes, G_flat, i == n - 1 ? loss_out : nullptr, stream)) return rc;
+        ++i;
+    }
     return 0;
 }
 

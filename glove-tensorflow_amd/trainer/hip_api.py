@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 10
+GLOVE_ABI_VERSION = 11
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4}      # glove_hyper.optimizer (GLOVE_OPT_*)
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
@@ -83,7 +83,7 @@ class GlovePlan(C.Structure):
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp),
-                ("r_crec", _fp), ("c_crec", _fp)]
+                ("r_crec", _fp), ("c_crec", _fp), ("r_mark", _fp), ("c_mark", _fp)]
 
 
 class GlovePairs(C.Structure):
@@ -330,8 +330,8 @@ class DeviceTables:
         """Second copies of BOTH tables + a step tag per row (glove_tables.R_tag / C_tag): what the tagged step
         (GLOVE_STEP_TAGGED) needs to read pre-step rows while it updates rows in the same launch.  For the latency-bound
         regime — small tables: costs (V_row + V) x d x 4 B of HBM."""
-        if self.R_tag is not None or self.optimizer != "Adagrad" or self.R_ver is not None:
-            return
+        if self.R_tag is not None or self.optimizer not in ("Adagrad", "Adam") or self.R_ver is not None:
+            return                               # (Adam: the twins flip as a whole every step — scalars[3] —, the tags stay zero)
         if self.V_col != self.V or 2 * max(self.V_row, self.V) * self.d * 4 >= 1 << 32:
             return                               # a sharded col table goes through views; 32-bit row offsets
         for name in ("_R", "_br", "_C", "_bc"):
@@ -346,7 +346,8 @@ class DeviceTables:
     def maybe_enable_tags(self, batch_size: int):
         """The policy: batches the library steps in the tagged form (at most TAGGED_STEP_MAX_BATCH pairs) on tables small enough
         that the step is a latency chain (both tables within the caches: 64 MB)."""
-        if self.optimizer == "Adagrad" and batch_size <= TAGGED_STEP_MAX_BATCH and (self.V_row + self.V) * self.d * 4 <= (64 << 20):
+        small = batch_size <= TAGGED_STEP_MAX_BATCH and (self.V_row + self.V) * self.d * 4 <= (64 << 20)
+        if small and (self.optimizer == "Adagrad" or (self.optimizer == "Adam" and 2 * batch_size <= self.V_row + self.V)):
             self.enable_tags()
 
     def enable_twin(self):
@@ -416,6 +417,7 @@ class DeviceTables:
             dst.copy_(src)
 
     def state_dict(self) -> dict:
+        self.canonicalize()             # (also settles scalars[3], the current copy of tables the one-launch Adam step flips)
         out = {"V": self.V, "d": self.d_model, "V_row": self.V_row, "optimizer": self.optimizer,
                "scalars": self.scalars.cpu(), "global_step": self.step.cpu()}
         for n in self.NAMES:
@@ -429,6 +431,7 @@ class DeviceTables:
         if (sd["V"], sd["d"], sd["optimizer"], sd.get("V_row", sd["V"])) != (self.V, self.d_model, self.optimizer, self.V_row):
             raise ValueError("checkpoint is for V=%s d=%s %s, model is V=%d d=%d %s" % (
                 sd["V"], sd["d"], sd["optimizer"], self.V, self.d_model, self.optimizer))
+        self.canonicalize()
         self.scalars.copy_(sd["scalars"])
         self.step.copy_(sd["global_step"])
         for n in self.NAMES:
@@ -544,6 +547,12 @@ class Plan:
         self.r_chunk_start, self.c_chunk_start = (torch.zeros(self.cap_chunks + 1, **i32) for _ in range(2))
         self.r_uniq_slot, self.c_uniq_slot = (torch.zeros(self.cap_uniq + 1, **i32) for _ in range(2))
         self.r_uniq_rec, self.c_uniq_rec = (torch.zeros(4 * max(self.cap_uniq, 1), **i32) for _ in range(2))
+        # bitmaps of the batch's ids (glove_plan.r_mark / c_mark): small batches carry them — the one-launch Adam step's sweep
+        # over all rows leaves the batch's rows alone by them
+        self.r_mark = self.c_mark = None
+        if 0 < self.B <= TAGGED_STEP_MAX_BATCH:
+            self.r_mark = torch.zeros(((max(self.V_row, 0) or self.V) + 31) // 32, **i32)
+            self.c_mark = torch.zeros((self.V + 31) // 32, **i32)
         self._struct = None
 
     @property
@@ -564,6 +573,7 @@ class Plan:
         if self._struct is None:
             s = GlovePlan()
             s.r_crec, s.c_crec = _ptr(self.r_crec), _ptr(self.c_crec)
+            s.r_mark, s.c_mark = _ptr(getattr(self, "r_mark", None)), _ptr(getattr(self, "c_mark", None))
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
             s.heavy_chunks, s.cap_heavy, s.V_row = self.heavy_chunks, self.cap_heavy, getattr(self, "V_row", 0)
             s.counts = _ptr(self.counts)
@@ -606,6 +616,7 @@ class Plan:
         out.r_uniq_rec = self.r_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out.c_uniq_rec = self.c_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out._struct = None
+        out.r_mark, out.c_mark = self.r_mark, self.c_mark
         out.r_crec = out.c_crec = None
         # records pad every chunk to the cap: worth it for the latency they save unless the chunks are nearly
         # empty (V = 400 k, B = 1 M: 2.6 pairs per 16-slot chunk -> 7 % more traffic, measured slower)
@@ -621,7 +632,7 @@ class Plan:
         return out
 
     def nbytes(self) -> int:
-        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts") if getattr(self, f) is not None)
+        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts", "r_mark", "c_mark") if getattr(self, f, None) is not None)
         return n + sum(t.numel() * 4 for t in (self.r_crec, self.c_crec) if t is not None)
 
 
@@ -722,9 +733,10 @@ def _step_struct(tables, plans, hyper):
     as possibly twinned when one of the plans can take the twin form (the rule of glove_step.hip pick_step_form), so
     that the next reader of R / br brings them home first."""
     if getattr(tables, "R_tag", None) is not None:
-        # step-tagged tables: the tagged step leaves rows in their second copies (the rule of glove_step.hip pick_step_form)
+        # step-tagged tables: the tagged step leaves rows in their second copies (the rule of glove_step.hip pick_step_form;
+        # Adam: adam_one_launch)
         form = hyper.step_form
-        if form == STEP_TAGGED or (form == STEP_AUTO and any(p.r_crec is not None and p.B <= TAGGED_STEP_MAX_BATCH for p in plans)):
+        if form in (STEP_TAGGED, STEP_AUTO) and any(p.r_crec is not None and p.B <= TAGGED_STEP_MAX_BATCH for p in plans):
             tables._twin_dirty = True
         return tables.struct(twin_ok=True)
     if getattr(tables, "R_ver", None) is None:
@@ -1015,7 +1027,7 @@ class GloveHip:
 
     def step_adam(self, plan, tables, hyper, G_flat, loss_out=None, ws=None):
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
-        _check(self.lib.glove_step_adam_f32(C.byref(plan.struct()), C.byref(tables.struct()), C.byref(hyper),
+        _check(self.lib.glove_step_adam_f32(C.byref(plan.struct()), C.byref(_step_struct(tables, (plan,), hyper)), C.byref(hyper),
                                             _ptr(ws), ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_step_adam_f32")
 
@@ -1024,18 +1036,20 @@ class GloveHip:
         Adam go to their own entry points).  G_flat: the dense gradient buffer RMSprop and Adam need."""
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
         hyper.optimizer = OPTIMIZER_CODES[tables.optimizer]
-        struct = _step_struct(tables, (plan,), hyper) if tables.optimizer == "Adagrad" else tables.struct()
+        struct = _step_struct(tables, (plan,), hyper) if tables.optimizer in ("Adagrad", "Adam") else tables.struct()
         _check(self.lib.glove_step_sparse_f32(C.byref(plan.struct()), C.byref(struct), C.byref(hyper), _ptr(ws), ws.numel(),
                                               _ptr(G_flat), _ptr(loss_out), _stream()), "glove_step_sparse_f32")
 
-    def steps_adam(self, plans, tables, hyper, G_flat, loss_out=None):
-        """len(plans) consecutive Adam steps from one host call."""
+    def steps_adam(self, plans, tables, hyper, G_flat, loss_out=None, ws=None):
+        """len(plans) consecutive Adam steps from one host call (on twinned tables consecutive small batches go out as a chain:
+        ONE launch per step, glove_steps_adam_f32)."""
         if not plans:
             return
-        big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
-        ws = self.step_workspace(big, tables.d)
+        if ws is None:
+            big = max(plans, key=lambda p: self.lib.glove_step_workspace_bytes(p.B, p.cap_chunks, tables.d))
+            ws = self.step_workspace(big, tables.d)
         arr = (C.POINTER(GlovePlan) * len(plans))(*[C.pointer(p.struct()) for p in plans])
-        _check(self.lib.glove_steps_adam_f32(arr, len(plans), C.byref(tables.struct()), C.byref(hyper), _ptr(ws),
+        _check(self.lib.glove_steps_adam_f32(arr, len(plans), C.byref(_step_struct(tables, plans, hyper)), C.byref(hyper), _ptr(ws),
                                              ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_steps_adam_f32")
 

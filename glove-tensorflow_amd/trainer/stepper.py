@@ -330,6 +330,8 @@ class Stepper(GraphedSteps):
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
             tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
+        elif not self._multi and tables.optimizer == "Adam" and hasattr(tables, "maybe_enable_tags"):
+            tables.maybe_enable_tags(batch_size)   # small batches on small tables: Adam's one-launch step on twinned tables
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
         self.exchange, self.rows, self.bufs = exchange, False, None
         self.payload_floats = int(self.G.numel()) if self.G is not None else 0
@@ -760,7 +762,7 @@ class ReshufflingRunner:
         if fused and form == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
         self.records = records
-        if single and records and tables.optimizer == "Adagrad" and form in (0, 5) and hasattr(tables, "maybe_enable_tags"):
+        if single and records and tables.optimizer in ("Adagrad", "Adam") and form in (0, 5) and hasattr(tables, "maybe_enable_tags"):
             tables.maybe_enable_tags(B)     # small batches on small tables: the tagged step (one launch for all the row work)
         stream.main_reads_epochs = False        # from here on only the side stream's builds read the epoch buffers
         first = hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records)
@@ -880,6 +882,8 @@ class ReshufflingRunner:
         step, the global bias handed on through the workspace)."""
         if self.stepper is None and self.tables.optimizer == "Adagrad":
             self.hip.steps_adagrad(plans, self.tables, self.hyper, self.loss_out, ws=self.step_ws)
+        elif self.stepper is None and self.tables.optimizer == "Adam":
+            self.hip.steps_adam(plans, self.tables, self.hyper, self.G, self.loss_out, ws=self.step_ws)
         else:
             for plan in plans:
                 self._step(plan)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 10   /* 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 11   /* 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -211,6 +211,12 @@ typedef struct glove_plan {
      * rec_dwords = 32 * ceil((8 + 6 * (capP / 8 - 1)) / 8) int32 each (128 for chunk_cap 32). */
     int32_t *r_crec;
     int32_t *c_crec;
+    /* Optional bitmaps of the batch's distinct ids (NULL = not computed): bit u of r_mark (ceil(V_row / 32) words; V when the row
+     * table is whole) is set iff row id u occurs in the batch, c_mark (ceil(V / 32) words) likewise for col ids.  Every word is
+     * written by every build.  The one-launch Keras-legacy Adam step reads them: its sweep over ALL rows (the legacy optimizer's
+     * sparse path decays every row of the table every step, a11) leaves the batch's rows to the lane groups that apply them. */
+    uint32_t *r_mark;
+    uint32_t *c_mark;
 } glove_plan;
 
 int glove_abi_version(void);

@@ -98,7 +98,7 @@ PLAN_ARRAYS = ("r_partner", "r_w", "r_y", "r_to_c", "r_chunk_id", "r_chunk_start
 def _poison(plan, ws):
     """0xFF into every array of a plan and into the build workspace: -1 as an id or position, NaN as a float — whatever a
     build leaves unwritten, or expects zeroed from allocation time, shows."""
-    for n in PLAN_ARRAYS + ("r_crec", "c_crec"):
+    for n in PLAN_ARRAYS + ("r_crec", "c_crec", "r_mark", "c_mark"):
         t = getattr(plan, n)
         if t is not None:
             t.view(torch.uint8).fill_(0xFF)
@@ -117,6 +117,11 @@ def _assert_plan_equals_oracle(plan, want, B, w, y):
                          ("c_uniq_slot", want["c_uniq_slot"], nu_c + 1)):
         if getattr(plan, name) is not None:                     # (c_perm / r_to_c are optional: Plan(links=False))
             np.testing.assert_array_equal(getattr(plan, name).cpu().numpy()[:n], exp, err_msg=name)
+    for side in ("r", "c"):                                     # the id bitmaps (small batches): exactly the side's distinct ids
+        mark = getattr(plan, side + "_mark", None)
+        if mark is not None:
+            bits = np.unpackbits(mark.cpu().numpy().view(np.uint8), bitorder="little")
+            np.testing.assert_array_equal(np.flatnonzero(bits), np.unique(want[side + "_uniq_rec"][:, 0]), err_msg=side + "_mark")
     np.testing.assert_array_equal(plan.r_uniq_rec.cpu().numpy()[:4 * nu_r].reshape(-1, 4), want["r_uniq_rec"])
     np.testing.assert_array_equal(plan.c_uniq_rec.cpu().numpy()[:4 * nu_c].reshape(-1, 4), want["c_uniq_rec"])
     if plan.r_w is not None:                                    # (a plan of a dealt epoch may keep its pair fields in its records only)
