@@ -648,8 +648,15 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         calls = {}
         if adam:
             adam_fused = 2 * B <= V_row + V          # glove_step_adam_f32's own rule (include/glove_hip.h)
-            calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)
-            if adam_fused:
+            one_launch = adam_fused and tables.R_tag is not None and B <= 2048 and plans[0].r_mark is not None and form in (0, 5)
+            if one_launch:
+                # twinned tables, plans with id bitmaps: the whole step is ONE kernel (+ a one-workgroup epilogue)
+                calls["step_adam_one_launch"] = lambda p: hip.step_adam(p, tables, hyper, G, loss_out, ws)
+            else:
+                calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)
+            if one_launch:
+                pass
+            elif adam_fused:
                 # passes (+ id marks) and ONE fused apply/decay kernel; the second kernel has no entry point of its own,
                 # so it is timed as the whole step minus the passes
                 calls["step_adam"] = lambda p: hip.step_adam(p, tables, hyper, G, loss_out, ws)

@@ -736,7 +736,7 @@ def _step_struct(tables, plans, hyper):
         # step-tagged tables: the tagged step leaves rows in their second copies (the rule of glove_step.hip pick_step_form;
         # Adam: adam_one_launch)
         form = hyper.step_form
-        if form in (STEP_TAGGED, STEP_AUTO) and any(p.r_crec is not None and p.B <= TAGGED_STEP_MAX_BATCH for p in plans):
+        if form == STEP_TAGGED or (form == STEP_AUTO and any(p.r_crec is not None and p.B <= TAGGED_STEP_MAX_BATCH for p in plans)):
             tables._twin_dirty = True
         return tables.struct(twin_ok=True)
     if getattr(tables, "R_ver", None) is None:
