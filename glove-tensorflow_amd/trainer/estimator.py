@@ -19,7 +19,7 @@ import torch
 
 from trainer.config_utils import parse_args
 from trainer.data_utils import NonzeroStream, file_lines, get_id_string_table, load_interaction_csv
-from trainer.model_utils import MatrixFactorisation, get_predictions, summary_histograms, summary_values
+from trainer.model_utils import MatrixFactorisation, get_predictions, logged_biases, summary_histograms, summary_values
 from trainer.stepper import HipBackend, Stepper
 from trainer.train_utils import CheckpointManager, get_optimizer
 
@@ -195,41 +195,127 @@ class Estimator:
                     obj.release_graphs()
 
     def _train_loop(self, stepper, stream, step, max_steps, log_every, t_last, s_last):
+        """Steps up to the next logging point go out in one call (launch loop in C or replayed graphs, no Python per step).  A
+        logging point does not drain the GPU: the loss scalars and the bias vectors are copied to pinned host memory behind
+        the point's last step, the next run of steps is issued, and only then the host waits for THAT copy, checks the loss
+        (NanTensorHook) and hands the record to the writer thread (histograms, event file, JSON line)."""
         p = self.params
-        while step < max_steps:
-            # steps up to the next logging point go out in one call (launch loop in C, no Python per step)
-            if self.reshuffling:
-                # up to the next logging point; a call ends early at the epoch's end and at a burst's (the runner replays
-                # graphs of 2^k steps): the loop simply asks again
-                done = stepper.run(min(max_steps, (step // log_every + 1) * log_every) - step)
-                step += done
-                at_log_point = step % log_every == 0 or step == max_steps
+        self._clock = (t_last, s_last)
+        pending = None
+        try:
+            while step < max_steps:
+                upto = min(max_steps, (step // log_every + 1) * log_every)
+                if self.reshuffling:
+                    # a call ends early at the epoch's end and at a burst's (the runner replays graphs of 2^k steps): the loop
+                    # simply asks again
+                    step += stepper.run(upto - step)
+                else:
+                    stepper.step_many([stream.next_plan() for _ in range(upto - step)])
+                    step = upto
+                if pending is not None:
+                    self._finish_log_point(pending)
+                    pending = None
+                if step % log_every == 0 or step == max_steps:
+                    pending = self._start_log_point(stepper, step)
+                due = self.ckpt.due() or step == max_steps
+                if self.world > 1:               # the eval pass below is collective: rank 0's clock decides for all
+                    flag = torch.tensor([1 if due else 0], device=self.device)
+                    self.dist.broadcast(flag, src=0)
+                    due = bool(flag.item())
+                if due:
+                    if pending is not None:
+                        self._finish_log_point(pending)
+                        pending = None
+                    self._drain_logs()
+                    self._save_checkpoint()
+                    if not p.get("skip_eval"):
+                        self.evaluate()
+            if pending is not None:
+                self._finish_log_point(pending)
+        finally:
+            self._drain_logs()
+
+    # ---- logging points
+    HOST_BIASES_MAX = 1 << 18       # bias vectors up to this length are logged from a host copy (one 1 MB copy at most)
+
+    def _start_log_point(self, stepper, step):
+        """Behind the last step issued: the loss scalars, the global bias and (small vocabularies) the bias vectors on their
+        way to pinned host memory; an event marks the copies' end."""
+        tables = self.model.tables
+        br, bc = tables.br, tables.bc                      # (brings twinned tables home, in stream order)
+        src = {"loss": stepper.loss_out, "scalars": tables.scalars}
+        if max(br.numel(), bc.numel()) <= self.HOST_BIASES_MAX:
+            src.update(br=br, bc=bc)
+        if self.device.type != "cuda":
+            return {"step": step, "host": {k: v.clone() for k, v in src.items()}, "event": None, "dev": None}
+        bufs = getattr(self, "_log_bufs", None)
+        if bufs is None or any(bufs[k].shape != v.shape for k, v in src.items()) or set(bufs) != set(src):
+            bufs = self._log_bufs = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in src.items()}
+        for k, v in src.items():
+            bufs[k].copy_(v, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        dev = None if "br" in src else (br, bc)            # big vocabularies: statistics and histograms on the device, at the finish
+        return {"step": step, "host": bufs, "event": ev, "dev": dev}
+
+    def _finish_log_point(self, pt):
+        if pt["event"] is not None:
+            pt["event"].synchronize()                      # the copies of THIS point; later steps keep running
+        host, step = pt["host"], pt["step"]
+        loss, L, reg, _ = host["loss"].tolist()
+        if not math.isfinite(loss):
+            raise FloatingPointError("loss is %r at global_step %d" % (loss, step))   # NanTensorHook
+        now = time.perf_counter()
+        t_last, s_last = self._clock
+        rate = (step - s_last) / max(now - t_last, 1e-9)
+        self._clock = (now, step)
+        if pt["dev"] is not None:
+            biases = pt["dev"]                             # (read as they are NOW: a big table's log point waits for the stream)
+        else:
+            biases = (host["br"].clone(), host["bc"].clone())
+        rec = {"loss": loss, "weighted_mse": L, "regularization_loss": reg, "global_step": step, "steps_per_sec": rate,
+               "nonzeros_per_sec": rate * self.params["batch_size"] * self.world}
+        rec.update(summary_values(self.model, biases, global_bias=float(host["scalars"][0])))
+        logger.info("global_step %d: loss = %.6f (%.1f steps/s)", step, loss, rate)
+        # a row-sharded run logs the histogram of rank 0's row-bias shard (every world-th row)
+        if self.rank == 0:
+            if pt["dev"] is not None:
+                self._log("train_log.jsonl", rec, summary_histograms(self.model, biases))
             else:
-                burst = min(max_steps, (step // log_every + 1) * log_every) - step
-                stepper.step_many([stream.next_plan() for _ in range(burst)])
-                step += burst
-                at_log_point = step % log_every == 0 or step == max_steps
-            if at_log_point:
-                rec = stepper.read_loss()                      # device sync
-                if not math.isfinite(rec["loss"]):
-                    raise FloatingPointError("loss is %r at global_step %d" % (rec["loss"], step))   # NanTensorHook
-                now = time.perf_counter()
-                rate = (step - s_last) / max(now - t_last, 1e-9)
-                rec.update(global_step=step, steps_per_sec=rate,
-                           nonzeros_per_sec=rate * p["batch_size"] * self.world, **summary_values(self.model))
-                # a row-sharded run logs the histogram of rank 0's row-bias shard (every world-th row)
-                self._log("train_log.jsonl", rec, summary_histograms(self.model) if self.rank == 0 else None)
-                logger.info("global_step %d: loss = %.6f (%.1f steps/s)", step, rec["loss"], rate)
-                t_last, s_last = now, step
-            due = self.ckpt.due() or step == max_steps
-            if self.world > 1:               # the eval pass below is collective: rank 0's clock decides for all
-                flag = torch.tensor([1 if due else 0], device=self.device)
-                self.dist.broadcast(flag, src=0)
-                due = bool(flag.item())
-            if due:
-                self._save_checkpoint()
-                if not p.get("skip_eval"):
-                    self.evaluate()
+                self._log_later("train_log.jsonl", rec, biases)
+
+    def _log_later(self, name, rec, biases):
+        """The record's histograms, its event and its JSON line, on the writer thread (started at the first record)."""
+        import queue
+        import threading
+        if getattr(self, "_log_queue", None) is None:
+            self._log_queue, self._log_error = queue.Queue(), None
+
+            def work():
+                while True:
+                    item = self._log_queue.get()
+                    try:
+                        if item is None:
+                            return
+                        if self._log_error is None:
+                            self._log(item[0], item[1], summary_histograms(self.model, item[2]))
+                    except BaseException as exc:           # surfaces at the next drain
+                        self._log_error = exc
+                    finally:
+                        self._log_queue.task_done()
+            self._log_thread = threading.Thread(target=work, name="glove-log-writer", daemon=True)
+            self._log_thread.start()
+        self._log_queue.put((name, rec, biases))
+
+    def _drain_logs(self):
+        """Everything handed to the writer thread is on disk when this returns (before a checkpoint, an eval pass, the end)."""
+        q = getattr(self, "_log_queue", None)
+        if q is None:
+            return
+        q.join()
+        if self._log_error is not None:
+            err, self._log_error = self._log_error, None
+            raise err
 
     def _save_checkpoint(self):
         """Rank 0 writes; a row-sharded run first gathers the whole model (collective: every rank calls this)."""

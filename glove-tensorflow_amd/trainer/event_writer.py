@@ -73,28 +73,42 @@ def default_bucket_limits() -> list:
     return _LIMITS
 
 
+_LIMITS_NP = None
+
+
+def _limits_np():
+    global _LIMITS_NP
+    if _LIMITS_NP is None:
+        import numpy as np
+        _LIMITS_NP = np.asarray(default_bucket_limits(), dtype=np.float64)
+    return _LIMITS_NP
+
+
 def histogram_of(values) -> dict:
     """HistogramProto fields of a 1-D tensor or array (any device): bucket i counts limit[i-1] <= x < limit[i]
-    (TF: upper_bound over the limits)."""
+    (TF: upper_bound over the limits).  Host data goes through NumPy, device tensors stay on their device."""
+    import numpy as np
     import torch
-    x = torch.as_tensor(values).detach().double().flatten()
     limits = default_bucket_limits()
-    lim = torch.tensor(limits, dtype=torch.float64, device=x.device)
-    counts = torch.bincount(torch.bucketize(x, lim, right=True).clamp_(max=len(limits) - 1), minlength=len(limits)).tolist()
-    out_limits, out_counts = [], []
-    i = 0
-    while i < len(counts):                       # Histogram::EncodeToProto: a run of empty buckets becomes one entry
-        c, end = counts[i], limits[i]
-        i += 1
-        if c <= 0:
-            while i < len(counts) and counts[i] <= 0:
-                end = limits[i]
-                i += 1
-        out_limits.append(end)
-        out_counts.append(float(c))
-    n = x.numel()
-    return {"min": float(x.min()) if n else 0.0, "max": float(x.max()) if n else 0.0, "num": float(n),
-            "sum": float(x.sum()), "sum_squares": float((x * x).sum()), "bucket_limit": out_limits, "bucket": out_counts}
+    if isinstance(values, torch.Tensor) and values.is_cuda:
+        x = values.detach().double().flatten()
+        lim = torch.tensor(limits, dtype=torch.float64, device=x.device)
+        counts = torch.bincount(torch.bucketize(x, lim, right=True).clamp_(max=len(limits) - 1), minlength=len(limits)).tolist()
+        n = x.numel()
+        stats = [float(v) for v in torch.stack([x.min(), x.max(), x.sum(), (x * x).sum()]).tolist()] if n else [0.0] * 4
+    else:
+        x = np.asarray(values.detach().numpy() if isinstance(values, torch.Tensor) else values, dtype=np.float64).ravel()
+        counts = np.bincount(np.minimum(np.searchsorted(_limits_np(), x, side="right"), len(limits) - 1), minlength=len(limits))
+        n = x.size
+        stats = [float(x.min()), float(x.max()), float(x.sum()), float((x * x).sum())] if n else [0.0] * 4
+    # Histogram::EncodeToProto: a run of empty buckets becomes one entry (its last limit, count 0)
+    c = np.asarray(counts, dtype=np.int64)
+    empty = c <= 0
+    keep = ~empty | np.append(~empty[1:], True)            # every non-empty bucket, and the LAST bucket of every empty run
+    lim_np = _limits_np()
+    out_limits, out_counts = lim_np[keep].tolist(), c[keep].astype(np.float64).tolist()
+    return {"min": stats[0], "max": stats[1], "num": float(n), "sum": stats[2], "sum_squares": stats[3],
+            "bucket_limit": out_limits, "bucket": out_counts}
 
 
 def _histo(h: dict) -> bytes:

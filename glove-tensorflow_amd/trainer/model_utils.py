@@ -48,17 +48,31 @@ def get_predictions(hip, model: MatrixFactorisation, input_ids: torch.Tensor, id
     }
 
 
-def summary_values(model: MatrixFactorisation) -> dict:
+def logged_biases(model: MatrixFactorisation):
+    """The two bias vectors as a log point reads them: vocabularies up to 2^18 come to the host in one copy each (a handful
+    of tiny device reductions, each with its own sync, costs more than the 40 KB copy), bigger ones stay on the device."""
+    t = model.tables
+    br, bc = t.br, t.bc
+    if br.is_cuda and max(br.numel(), bc.numel()) <= 1 << 18:
+        br, bc = br.cpu(), bc.cpu()
+    return br, bc
+
+
+def summary_values(model: MatrixFactorisation, biases=None, global_bias=None) -> dict:
     """What add_summary logs (reference model_utils.py:113-118): global bias scalar and, for the log line, the
     min/mean/max/std of the two bias vectors (their histograms go to the event file: summary_histograms)."""
-    t = model.tables
-    stat = lambda x: {"min": float(x.min()), "mean": float(x.mean()), "max": float(x.max()), "std": float(x.std())}
-    return {"mf/global_bias": t.global_bias, "mf/row_biases": stat(t.br), "mf/col_biases": stat(t.bc)}
+    br, bc = biases if biases is not None else logged_biases(model)
+
+    def stat(x):
+        x = x.double()
+        return {"min": float(x.min()), "mean": float(x.mean()), "max": float(x.max()), "std": float(x.std()) if x.numel() > 1 else 0.0}
+    return {"mf/global_bias": model.tables.global_bias if global_bias is None else global_bias,
+            "mf/row_biases": stat(br), "mf/col_biases": stat(bc)}
 
 
-def summary_histograms(model: MatrixFactorisation) -> dict:
+def summary_histograms(model: MatrixFactorisation, biases=None) -> dict:
     """`summary.histogram("row_biases" / "col_biases")` of add_summary (reference model_utils.py:116-117) as
     HistogramProto fields over TensorFlow's default buckets."""
     from trainer.event_writer import histogram_of
-    t = model.tables
-    return {"mf/row_biases": histogram_of(t.br), "mf/col_biases": histogram_of(t.bc)}
+    br, bc = biases if biases is not None else logged_biases(model)
+    return {"mf/row_biases": histogram_of(br), "mf/col_biases": histogram_of(bc)}
