@@ -1997,7 +1997,8 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
 // epilogues on the same traversal as AdagradApply.  Semantics: include/glove_hip.h glove_hyper.optimizer; restated in
 // oracle/glove_ref.py (_sgd, _rmsprop_dense_decay, _adamax).
 // ------------------------------------------------------------------------------------------
-struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; };
+struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; float rho; };
+template <int OPT> struct OptSlots { static constexpr bool two = OPT == GLOVE_OPT_ADAMAX || OPT == GLOVE_OPT_ADADELTA || OPT == GLOVE_OPT_FTRL; };
 
 template <int LPR, int NV, int OPT>
 struct SparseOptApply {
@@ -2012,10 +2013,35 @@ struct SparseOptApply {
         if (OPT == GLOVE_OPT_SGD && o.momentum == 0.f) return;
         load_row<LPR, NV>(st.A, sb.S1, id, d4, lg);
         st.Ab = sb.S1b[id];
-        if (OPT == GLOVE_OPT_ADAMAX) {
+        if (OptSlots<OPT>::two) {
             load_row<LPR, NV>(st.B, is_row ? S2_R : S2_C, id, d4, lg);
             st.Bb = (is_row ? S2_br : S2_bc)[id];
         }
+    }
+    // Adadelta (kernel SparseApplyAdadelta): a = accum_grad, u = accum_var
+    __device__ static void adadelta(float &w, float &a, float &u, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        a = a * o.rho + g * g * (1.0f - o.rho);
+        const float upd = sqrtf(u + o.eps) / sqrtf(a + o.eps) * g;
+        w -= upd * o.lr;
+        u = u * o.rho + upd * upd * (1.0f - o.rho);
+    }
+    // Ftrl at its Keras defaults (kernel FtrlCompute; lr_power -0.5, l1 = l2 = 0): a = accumulator, z = linear
+    __device__ static void ftrl(float &w, float &a, float &z, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        const float na = a + g * g;
+        z += g - (sqrtf(na) - sqrtf(a)) / o.lr * w;
+        w = fabsf(z) > 0.f ? -z / (sqrtf(na) / o.lr) : 0.f;
+        a = na;
+    }
+    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o)
+    {
+        if (OPT == GLOVE_OPT_SGD) sgd(w, a, g, o);
+        else if (OPT == GLOVE_OPT_ADAMAX) adamax(w, a, b, g, o);
+        else if (OPT == GLOVE_OPT_ADADELTA) adadelta(w, a, b, g, o);
+        else ftrl(w, a, b, g, o);
     }
     __device__ static void sgd(float &w, float &a, float g, const OptConsts &o)
     {
@@ -2041,22 +2067,18 @@ struct SparseOptApply {
             float b[4] = {st.B[kk].x, st.B[kk].y, st.B[kk].z, st.B[kk].w};
             const float g[4] = {G[kk].x, G[kk].y, G[kk].z, G[kk].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (OPT == GLOVE_OPT_SGD) sgd(w[i], a[i], g[i], o);
-                else adamax(w[i], a[i], b[i], g[i], o);
-            }
+            for (int i = 0; i < 4; ++i) one(w[i], a[i], b[i], g[i], o);
             Wv[kk] = f4{w[0], w[1], w[2], w[3]};
             st.A[kk] = f4{a[0], a[1], a[2], a[3]};
             st.B[kk] = f4{b[0], b[1], b[2], b[3]};
         }
         if (slots) store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, st.A);
-        if (OPT == GLOVE_OPT_ADAMAX) store_row<LPR, NV>(is_row ? S2_R : S2_C, (size_t)id, d4, lg, st.B);
+        if (OptSlots<OPT>::two) store_row<LPR, NV>(is_row ? S2_R : S2_C, (size_t)id, d4, lg, st.B);
         store_row<LPR, NV>(sb.W, (size_t)wid, d4, lg, Wv);
         if (lg == 0) {
-            if (OPT == GLOVE_OPT_SGD) sgd(bval, st.Ab, Gb, o);
-            else adamax(bval, st.Ab, st.Bb, Gb, o);
+            one(bval, st.Ab, st.Bb, Gb, o);
             if (slots) sb.S1b[id] = st.Ab;
-            if (OPT == GLOVE_OPT_ADAMAX) (is_row ? S2_br : S2_bc)[id] = st.Bb;
+            if (OptSlots<OPT>::two) (is_row ? S2_br : S2_bc)[id] = st.Bb;
             sb.bias[wid] = bval;
         }
     }
@@ -2081,8 +2103,7 @@ __global__ __launch_bounds__(kBlock) void apply_sparse_opt_kernel(
             loss_from_partials(tot, k, g, loss, L, reg);
             const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
             float gn = g, a = scalars[1], b = scalars[2];
-            if (OPT == GLOVE_OPT_SGD) SparseOptApply<LPR, NV, OPT>::sgd(gn, a, dg, o);
-            else SparseOptApply<LPR, NV, OPT>::adamax(gn, a, b, dg, o);
+            SparseOptApply<LPR, NV, OPT>::one(gn, a, b, dg, o);
             scalars[0] = gn; scalars[1] = a; scalars[2] = b;
             if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
         }
@@ -2162,6 +2183,149 @@ struct AdamApply {
         }
     }
 };
+
+// Keras-legacy Nadam on the same two-part kernel (the legacy optimizer's sparse path decays m and v over the whole variable like
+// its Adam, but only the touched rows move: optimizer_v2/nadam.py `_resource_apply_sparse`; restated in oracle/glove_ref.py _nadam).
+// The momentum cache — the running product of the schedule u_i = beta1 (1 - 0.5 0.96^(0.004 i)) — lives in scalars[4 + parity]:
+// step t reads slot (t - 1) & 1 and its scalar epilogue writes slot t & 1, so no workgroup of step t sees the new value.
+struct NadamConsts { float lr, eps, b1, b2, one_minus_u_t, u_t1, om_new, om_next, v_den, sched_new; };
+__device__ inline NadamConsts nadam_consts(float lr, float eps, float b1, float b2, double ln_beta2, int64_t t, const float *scalars)
+{
+#pragma clang fp contract(off)
+    const double ln096 = -0.040821994520255166;                 // ln 0.96
+    const float u_t = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)t * ln096)));
+    const float u_t1 = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)(t + 1) * ln096)));
+    const float cache = scalars[4 + (int)((t - 1) & 1)];
+    NadamConsts k;
+    k.lr = lr; k.eps = eps; k.b1 = b1; k.b2 = b2;
+    k.sched_new = cache * u_t;
+    k.one_minus_u_t = 1.0f - u_t;
+    k.u_t1 = u_t1;
+    k.om_new = 1.0f - k.sched_new;
+    k.om_next = 1.0f - k.sched_new * u_t1;
+    k.v_den = -expm1f((float)((double)t * ln_beta2));
+    return k;
+}
+__device__ inline void nadam_elem(float &w, float &m, float &v, float g, const NadamConsts &k)
+{
+#pragma clang fp contract(off)
+    m = m * k.b1 + (1.0f - k.b1) * g;
+    v = v * k.b2 + (1.0f - k.b2) * g * g;
+    const float m_bar = k.one_minus_u_t * (g / k.om_new) + k.u_t1 * (m / k.om_next);
+    w -= k.lr * m_bar / (sqrtf(v / k.v_den) + k.eps);
+}
+
+template <int LPR, int NV>
+struct NadamApply {
+    SideBufs rs, cs;
+    float *S2_R, *S2_C, *S2_br, *S2_bc;
+    int d4, lg;
+    NadamConsts k;
+    struct State { f4 M[NV], V[NV]; float Mb, Vb; };
+    __device__ void prefetch(bool is_row, int32_t id, State &st) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+        load_row<LPR, NV>(st.M, sb.S1, id, d4, lg);
+        load_row<LPR, NV>(st.V, is_row ? S2_R : S2_C, id, d4, lg);
+        st.Mb = sb.S1b[id];
+        st.Vb = (is_row ? S2_br : S2_bc)[id];
+    }
+    __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
+    {
+        const SideBufs &sb = is_row ? rs : cs;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            float w[4] = {Wv[kk].x, Wv[kk].y, Wv[kk].z, Wv[kk].w}, m[4] = {st.M[kk].x, st.M[kk].y, st.M[kk].z, st.M[kk].w};
+            float v[4] = {st.V[kk].x, st.V[kk].y, st.V[kk].z, st.V[kk].w};
+            const float g[4] = {G[kk].x, G[kk].y, G[kk].z, G[kk].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nadam_elem(w[i], m[i], v[i], g[i], k);
+            Wv[kk] = f4{w[0], w[1], w[2], w[3]};
+            st.M[kk] = f4{m[0], m[1], m[2], m[3]};
+            st.V[kk] = f4{v[0], v[1], v[2], v[3]};
+        }
+        store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, st.M);
+        store_row<LPR, NV>(is_row ? S2_R : S2_C, (size_t)id, d4, lg, st.V);
+        store_row<LPR, NV>(sb.W, (size_t)id, d4, lg, Wv);
+        if (lg == 0) {
+            nadam_elem(bval, st.Mb, st.Vb, Gb, k);
+            sb.S1b[id] = st.Mb;
+            (is_row ? S2_br : S2_bc)[id] = st.Vb;
+            sb.bias[id] = bval;
+        }
+    }
+};
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void nadam_fused_kernel(
+    IdWork wk, SideBufs rs, SideBufs cs, float *S2_R, float *S2_C, float *S2_br, float *S2_bc, int d4, StepConsts k,
+    float b1, float b2, double ln_beta2, const int64_t *__restrict__ step,
+    float *__restrict__ scalars, const float *__restrict__ blockpart, int nblocks_rowpass,
+    float *__restrict__ mark_rows, float *__restrict__ mark_cols, int V_row, int V, int apply_blocks,
+    float *__restrict__ loss_out)
+{
+#pragma clang fp contract(off)
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR;
+    const NadamConsts nk = nadam_consts(k.lr, k.eps, b1, b2, ln_beta2, *step, scalars);
+    if ((int)blockIdx.x >= apply_blocks) {
+        // ---- sweep (as adam_fused_kernel's): an unmarked row's m and v decay, the row itself stays; a marked row belongs to the apply part
+        const int grp = threadIdx.x / LPR;
+        const int sb0 = blockIdx.x - apply_blocks, nsb = gridDim.x - apply_blocks;
+        const int total = V_row + V, stride = nsb * GPB;
+        for (int v0 = sb0 * GPB + grp; v0 < total; v0 += kSweepRows * stride) {
+            f4 M[kSweepRows][NV], Vv[kSweepRows][NV];
+            float mk[kSweepRows], Mb[kSweepRows], Vb[kSweepRows];
+#pragma unroll
+            for (int r = 0; r < kSweepRows; ++r) {
+                const int v = v0 + r * stride;
+                const bool live = v < total;
+                const bool is_row = v < V_row;
+                const int id = live ? (is_row ? v : v - V_row) : 0;
+                const SideBufs &sb = is_row ? rs : cs;
+                mk[r] = live ? (is_row ? mark_rows : mark_cols)[id] : 1.0f;
+                load_row<LPR, NV>(M[r], sb.S1, id, d4, lg);
+                load_row<LPR, NV>(Vv[r], is_row ? S2_R : S2_C, id, d4, lg);
+                Mb[r] = Vb[r] = 0.f;
+                if (lg == 0) { Mb[r] = sb.S1b[id]; Vb[r] = (is_row ? S2_br : S2_bc)[id]; }
+            }
+#pragma unroll
+            for (int r = 0; r < kSweepRows; ++r) {
+                const int v = v0 + r * stride;
+                if (v >= total) continue;
+                const bool is_row = v < V_row;
+                const int id = is_row ? v : v - V_row;
+                const SideBufs &sb = is_row ? rs : cs;
+                float *S2 = is_row ? S2_R : S2_C, *S2b = is_row ? S2_br : S2_bc;
+                if (mk[r] != 0.f) {
+                    if (lg == 0) (is_row ? mark_rows : mark_cols)[id] = 0.f;
+                    continue;
+                }
+#pragma unroll
+                for (int kk = 0; kk < NV; ++kk) { M[r][kk] = b1 * M[r][kk]; Vv[r][kk] = b2 * Vv[r][kk]; }
+                store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, M[r]);
+                store_row<LPR, NV>(S2, (size_t)id, d4, lg, Vv[r]);
+                if (lg == 0) { sb.S1b[id] = b1 * Mb[r]; S2b[id] = b2 * Vb[r]; }
+            }
+        }
+        return;
+    }
+    const bool scalar_duty = for_each_id<LPR, NV>(wk, rs, cs, d4, k, NadamApply<LPR, NV>{rs, cs, S2_R, S2_C, S2_br, S2_bc, d4, lg, nk},
+                                                  apply_blocks);
+    if (scalar_duty) {
+        float tot[kPartials];
+        sum_blockpart(blockpart, nblocks_rowpass, tot);
+        if (threadIdx.x == 0) {
+            const float g = scalars[0];
+            float loss, L, reg;
+            loss_from_partials(tot, k, g, loss, L, reg);
+            const float dg = tot[3] + 2.0f * k.m * k.l2 * g;
+            nadam_elem(scalars[0], scalars[1], scalars[2], dg, nk);
+            scalars[4 + (int)(*step & 1)] = nk.sched_new;
+            if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = tot[3]; }
+        }
+    }
+}
 
 template <int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void adam_fused_kernel(
@@ -3074,7 +3238,7 @@ int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glo
 
 // passes (marking the batch's ids) + adam_fused_kernel: see the kernel's header
 static int step_adam_fused(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
-                           float *G_flat, float *loss_out, void *stream)
+                           float *G_flat, float *loss_out, void *stream, bool nadam = false)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!G_flat || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc || !t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)
@@ -3098,10 +3262,16 @@ static int step_adam_fused(const glove_plan *p, const glove_tables *t, const glo
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
     hipStream_t st = (hipStream_t)stream;
 #define CALL(LPR, NV)                                                                                          \
-    hipLaunchKernelGGL((adam_fused_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
-                       t->s2_br, t->s2_bc, d4, k, (float)h->beta1, (float)h->beta2, log((double)(float)h->beta1), log((double)(float)h->beta2),  \
-                       t->step, t->scalars, w.blockpart, nb_row, mark_rows, mark_cols, (int)Vr, (int)t->V,     \
-                       apply_blocks, loss_out)
+    if (nadam)                                                                                                 \
+        hipLaunchKernelGGL((nadam_fused_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
+                           t->s2_br, t->s2_bc, d4, k, (float)h->beta1, (float)h->beta2, log((double)(float)h->beta2), \
+                           t->step, t->scalars, w.blockpart, nb_row, mark_rows, mark_cols, (int)Vr, (int)t->V, \
+                           apply_blocks, loss_out);                                                            \
+    else                                                                                                       \
+        hipLaunchKernelGGL((adam_fused_kernel<LPR, NV>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
+                           t->s2_br, t->s2_bc, d4, k, (float)h->beta1, (float)h->beta2, log((double)(float)h->beta1), log((double)(float)h->beta2),  \
+                           t->step, t->scalars, w.blockpart, nb_row, mark_rows, mark_cols, (int)Vr, (int)t->V, \
+                           apply_blocks, loss_out)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
     return (int)hipGetLastError();
@@ -3206,6 +3376,8 @@ int glove_step_sparse_f32(const glove_plan *p, const glove_tables *t, const glov
     if (int rc = plain_table(t, stream)) return rc;
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (sides_of(h) != 3 || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_NADAM)        // passes (marking the batch's ids) + one kernel: apply for the ids, decay of m and v for all other rows
+        return step_adam_fused(p, t, h, ws, ws_bytes, G_flat, loss_out, stream, true);
     hipStream_t st = (hipStream_t)stream;
     const StepConsts k = make_consts(t, h);
     if (h->optimizer == GLOVE_OPT_RMSPROP) {
@@ -3217,10 +3389,12 @@ int glove_step_sparse_f32(const glove_plan *p, const glove_tables *t, const glov
         hipLaunchKernelGGL(dense_rmsprop_kernel, dim3(nbx, 4), dim3(kBlock), 0, st, segs, k, h->rho, t->scalars, tail, loss_out, 1);
         return (int)hipGetLastError();
     }
-    if (h->optimizer != GLOVE_OPT_SGD && h->optimizer != GLOVE_OPT_ADAMAX) return GLOVE_E_BADARG;
-    if (h->optimizer == GLOVE_OPT_ADAMAX && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc || !(h->beta1 > 0.0 && h->beta1 < 1.0) ||
-                                             !(h->beta2 > 0.0 && h->beta2 < 1.0)))
-        return GLOVE_E_BADARG;
+    const bool two_slots = h->optimizer == GLOVE_OPT_ADAMAX || h->optimizer == GLOVE_OPT_ADADELTA || h->optimizer == GLOVE_OPT_FTRL;
+    if (h->optimizer != GLOVE_OPT_SGD && !two_slots) return GLOVE_E_BADARG;
+    if (two_slots && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_ADAMAX && (!(h->beta1 > 0.0 && h->beta1 < 1.0) || !(h->beta2 > 0.0 && h->beta2 < 1.0))) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_ADADELTA && !(h->rho > 0.f && h->rho < 1.f)) return GLOVE_E_BADARG;
+    if (h->optimizer == GLOVE_OPT_FTRL && !(h->learning_rate > 0.f)) return GLOVE_E_BADARG;
     if (h->optimizer == GLOVE_OPT_SGD && !(h->momentum >= 0.f && h->momentum < 1.f)) return GLOVE_E_BADARG;
     if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3)) return rc;
     const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
@@ -3230,17 +3404,19 @@ int glove_step_sparse_f32(const glove_plan *p, const glove_tables *t, const glov
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
     const int nb_row = rowpass_blocks(p, pass_shape(d4).lpr);
     const SideBufs rs = side_bufs(p, w, t, true), cs = side_bufs(p, w, t, false);
-    const OptConsts o = {h->learning_rate, h->epsilon, h->momentum, 0.f, (float)h->beta1, (float)h->beta2, h->nesterov ? 1 : 0};
+    const OptConsts o = {h->learning_rate, h->epsilon, h->momentum, 0.f, (float)h->beta1, (float)h->beta2, h->nesterov ? 1 : 0, h->rho};
     const double ln_b1 = h->optimizer == GLOVE_OPT_ADAMAX ? log((double)(float)h->beta1) : 0.0;
-#define CALL(LPR, NV)                                                                                                       \
-    if (h->optimizer == GLOVE_OPT_SGD)                                                                                      \
-        hipLaunchKernelGGL((apply_sparse_opt_kernel<LPR, NV, GLOVE_OPT_SGD>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
-                           t->s2_br, t->s2_bc, d4, k, o, ln_b1, (const int64_t *)t->step, t->scalars, (const float *)w.blockpart, nb_row, loss_out); \
-    else                                                                                                                    \
-        hipLaunchKernelGGL((apply_sparse_opt_kernel<LPR, NV, GLOVE_OPT_ADAMAX>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
+#define LAUNCH_OPT(LPR, NV, OPT)                                                                                           \
+        hipLaunchKernelGGL((apply_sparse_opt_kernel<LPR, NV, OPT>), dim3(nb), dim3(kBlock), 0, st, wk, rs, cs, t->s2_R, t->s2_C, \
                            t->s2_br, t->s2_bc, d4, k, o, ln_b1, (const int64_t *)t->step, t->scalars, (const float *)w.blockpart, nb_row, loss_out)
+#define CALL(LPR, NV)                                                                                                       \
+    if (h->optimizer == GLOVE_OPT_SGD) LAUNCH_OPT(LPR, NV, GLOVE_OPT_SGD);                                                  \
+    else if (h->optimizer == GLOVE_OPT_ADAMAX) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADAMAX);                                       \
+    else if (h->optimizer == GLOVE_OPT_ADADELTA) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADADELTA);                                   \
+    else LAUNCH_OPT(LPR, NV, GLOVE_OPT_FTRL)
     GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef CALL
+#undef LAUNCH_OPT
     return (int)hipGetLastError();
 }
 

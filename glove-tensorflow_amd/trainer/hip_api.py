@@ -20,7 +20,7 @@ LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
 GLOVE_ABI_VERSION = 11
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
-OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4}      # glove_hyper.optimizer (GLOVE_OPT_*)
+OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4, "Adadelta": 5, "Ftrl": 6, "Nadam": 7}      # glove_hyper.optimizer (GLOVE_OPT_*)
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
 TAGGED_STEP_MAX_BATCH = 2048      # GLOVE_STEP_AUTO takes the tagged step up to this batch size on step-tagged tables
 DEFAULT_CHUNK_CAP = 32
@@ -270,14 +270,16 @@ class DeviceTables:
         self.s1, self.s2 = {}, {}
         for n in self.NAMES:
             w = getattr(self, n)
-            if optimizer == "Adagrad":
-                self.s1[n] = torch.full_like(w, 0.1)   # initial_accumulator_value
-            else:                                      # Adam m / v, Adamax m / v; SGD momentum accumulator, RMSprop rms: zeros
+            if optimizer in ("Adagrad", "Ftrl"):
+                self.s1[n] = torch.full_like(w, 0.1)   # initial_accumulator_value (both optimizers' Keras default)
+            else:                                      # Adam m / v, Adamax m / v, Adadelta accum_grad / accum_var; SGD momentum accumulator, RMSprop rms: zeros
                 self.s1[n] = torch.zeros_like(w)
-                if optimizer in ("Adam", "Adamax"):
-                    self.s2[n] = torch.zeros_like(w)
-        if optimizer == "Adagrad":
+            if optimizer in ("Adam", "Adamax", "Adadelta", "Ftrl", "Nadam"):
+                self.s2[n] = torch.zeros_like(w)       # (Ftrl: linear)
+        if optimizer in ("Adagrad", "Ftrl"):
             self.scalars[1] = 0.1
+        if optimizer == "Nadam":
+            self.scalars[4:6] = 1.0                    # the momentum cache (Keras: an optimizer weight initialised to ones)
         self._struct = None
 
     # ---- the row table may be twinned (glove_tables.R_ver): R / br are the plain views [V_row, ...]; reading them
@@ -708,12 +710,14 @@ class PlanBlock:
 
 def make_hyper(l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, epsilon=1e-7, beta1=0.9, beta2=0.999,
                batch_size=None, inv_batch=None, sides=0, head=HEAD_REGRESSION, neg_factor=1.0,
-               step_form=STEP_AUTO, optimizer="Adagrad", momentum=0.0, nesterov=False, rho=0.9) -> GloveHyper:
+               step_form=STEP_AUTO, optimizer="Adagrad", momentum=0.0, nesterov=False, rho=None) -> GloveHyper:
     """`sides`: 0/3 both sides, 1 row side only, 2 col side only; `head`: HEAD_REGRESSION (GloVe) or
     HEAD_LOGISTIC (pos/neg logistic matrix factorisation, with `neg_factor`) — see glove_hyper in the header."""
     h = GloveHyper()
     h.sides, h.head, h.neg_factor, h.step_form = sides, head, neg_factor, step_form
     h.optimizer = OPTIMIZER_CODES[optimizer] if isinstance(optimizer, str) else int(optimizer)     # read by glove_step_sparse_f32 only
+    if rho is None:                     # the optimizer's own Keras default
+        rho = 0.95 if h.optimizer == OPTIMIZER_CODES["Adadelta"] else 0.9
     h.momentum, h.nesterov, h.rho = momentum, int(bool(nesterov)), rho
     h.beta1, h.beta2 = beta1, beta2
     h.l2_reg, h.reg_mult, h.learning_rate, h.epsilon = l2_reg, reg_mult, learning_rate, epsilon
@@ -1032,8 +1036,8 @@ class GloveHip:
                "glove_step_adam_f32")
 
     def step_sparse(self, plan, tables, hyper, G_flat=None, loss_out=None, ws=None):
-        """One step under the Keras optimizer `tables.optimizer` names (glove_step_sparse_f32: SGD, RMSprop, Adamax; Adagrad and
-        Adam go to their own entry points).  G_flat: the dense gradient buffer RMSprop and Adam need."""
+        """One step under the Keras optimizer `tables.optimizer` names (glove_step_sparse_f32: SGD, RMSprop, Adamax, Adadelta, Ftrl, Nadam; Adagrad
+        and Adam go to their own entry points).  G_flat: the dense gradient buffer RMSprop, Nadam and Adam need."""
         ws = self.step_workspace(plan, tables.d) if ws is None else ws
         hyper.optimizer = OPTIMIZER_CODES[tables.optimizer]
         struct = _step_struct(tables, (plan,), hyper) if tables.optimizer in ("Adagrad", "Adam") else tables.struct()

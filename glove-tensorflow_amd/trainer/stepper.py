@@ -48,7 +48,7 @@ class HipBackend:
     def step_sparse_adagrad(self, plan, tables, hyper, loss_out):
         if tables.optimizer == "Adagrad":
             self.hip.step_adagrad(plan, tables, hyper, loss_out)
-        else:                                   # SGD, Adamax: passes + their apply epilogue (glove_step_sparse_f32)
+        else:                                   # the other Keras names: passes + their apply epilogue (glove_step_sparse_f32)
             self.hip.step_sparse(plan, tables, hyper, None, loss_out)
 
     def steps_sparse_adagrad(self, plans, tables, hyper, loss_out):
@@ -326,7 +326,7 @@ class Stepper(GraphedSteps):
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer; RMSprop (whole-slot decay) too,
         # inside its own entry point
         self.dense = self._multi or tables.optimizer == "Adam"
-        self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer == "RMSprop" else None
+        self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer in ("RMSprop", "Nadam") else None
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
             tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
@@ -773,7 +773,7 @@ class ReshufflingRunner:
         self.slots = [PlanBlock(plans[:self.S]), PlanBlock(plans[self.S:])]
         self.sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, self.S), 256), dtype=torch.uint8, device=dev)
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, first.cap_chunks, tables.d), dtype=torch.uint8, device=dev)
-        self.G = hip.dense_grad_buffer(tables) if single and tables.optimizer in ("Adam", "RMSprop") else None
+        self.G = hip.dense_grad_buffer(tables) if single and tables.optimizer in ("Adam", "RMSprop", "Nadam") else None
         # ---- segments: `_g` = the segment the next step belongs to (counted over all epochs), slot = segment % 2
         self._g, self._issued, self._entered = 0, 0, -1
         self._cursor = (stream.epoch, 0)       # (epoch, segment of the epoch) the next build takes
@@ -817,7 +817,7 @@ class ReshufflingRunner:
             self.hip.step_adagrad(plan, self.tables, self.hyper, self.loss_out, self.step_ws)
         elif self.tables.optimizer == "Adam":
             self.hip.step_adam(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
-        else:                                   # SGD, RMSprop, Adamax by their Keras names
+        else:                                   # the other Keras names (glove_step_sparse_f32)
             self.hip.step_sparse(plan, self.tables, self.hyper, self.G, self.loss_out, self.step_ws)
 
     def _segments_per_epoch(self) -> int:

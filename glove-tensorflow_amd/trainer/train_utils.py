@@ -25,6 +25,10 @@ OPTIMIZERS = {
     "SGD": {"momentum": 0.0, "nesterov": False},
     "RMSprop": {"rho": 0.9, "momentum": 0.0, "epsilon": 1e-7, "centered": False},
     "Adamax": {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7},
+    "Nadam": {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7, "schedule_decay": 0.004},
+    "Adadelta": {"rho": 0.95, "epsilon": 1e-7},
+    "Ftrl": {"learning_rate_power": -0.5, "initial_accumulator_value": 0.1, "l1_regularization_strength": 0.0,
+             "l2_regularization_strength": 0.0, "l2_shrinkage_regularization_strength": 0.0, "beta": 0.0},
 }
 
 

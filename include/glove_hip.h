@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 11   /* 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 11   /* 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax, later Adadelta and Ftrl by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -48,7 +48,8 @@ typedef struct glove_tables {
     float *s1_R, *s1_C, *s1_br, *s1_bc;   /* slot 1, same shapes */
     float *s2_R, *s2_C, *s2_br, *s2_bc;   /* slot 2 (Adam only; may be NULL for Adagrad) */
     /* scalars live on the device so that a captured hipGraph replays without host patching:
-     *  [0] global_bias g (model_utils.py:39)  [1] slot1(g)  [2] slot2(g)  [3..7] reserved */
+     *  [0] global_bias g (model_utils.py:39)  [1] slot1(g)  [2] slot2(g)  [3] which copy of twinned tables is current as a
+     *  whole (the one-launch Adam step: 0 / 1)  [4], [5] Nadam's momentum cache (GLOVE_OPT_NADAM)  [6..7] reserved */
     float *scalars;             /* float[8] */
     /* global_step (estimator.py:45), int64[1].  glove_rowpass_f32 advances it by one (it is
      * the first kernel of a step and does not read it); the apply kernels read t = *step. */
@@ -125,11 +126,23 @@ typedef struct glove_hyper {
      *                      optimizer does, like its Adam —, (1 - rho) G^2 is added on the touched rows, which alone move:
      *                      var -= lr G / (sqrt(rms) + epsilon); momentum 0, not centered
      *   GLOVE_OPT_ADAMAX   (slot1 = m, slot2 = v, zeros) lazy: touched rows only: m = beta1 m + (1 - beta1) G;
-     *                      v = max(beta2 v, |G|); var -= lr / (1 - beta1^t) m / (v + epsilon) */
+     *                      v = max(beta2 v, |G|); var -= lr / (1 - beta1^t) m / (v + epsilon)
+     *   GLOVE_OPT_ADADELTA (slot1 = accum_grad, slot2 = accum_var, zeros) touched rows only: a = rho a + (1 - rho) G^2;
+     *                      u = sqrt(accum_var + epsilon) / sqrt(a + epsilon) G; var -= lr u; accum_var = rho accum_var +
+     *                      (1 - rho) u^2   (rho: Keras default 0.95)
+     *   GLOVE_OPT_FTRL     at its Keras defaults (learning_rate_power -0.5, l1 = l2 = l2_shrinkage = beta = 0; slot1 =
+     *                      accumulator, 0.1, slot2 = linear, zeros) touched rows only: n = accumulator + G^2; linear += G -
+     *                      (sqrt(n) - sqrt(accumulator)) / lr var; var = -linear / (sqrt(n) / lr) (0 where linear is 0);
+     *                      accumulator = n
+     *   GLOVE_OPT_NADAM    (slot1 = m, slot2 = v, zeros; scalars[4], scalars[5] = the momentum cache, ones, used alternately by
+     *                      odd and even steps) m and v decay over the WHOLE variable and take (1 - beta) G, G^2 on the touched
+     *                      rows, which alone move: with u_i = beta1 (1 - 0.5 0.96^(0.004 i)) and P_t = u_1 .. u_t,
+     *                      var -= lr ((1 - u_t) G / (1 - P_t) + u_{t+1} m / (1 - P_{t+1})) / (sqrt(v / (1 - beta2^t)) + epsilon).
+     *                      Needs G_flat (its bias segments carry the marks of the batch's ids, as in glove_step_adam_f32) */
     int32_t optimizer;
     float momentum;             /* SGD, Keras default 0 */
     int32_t nesterov;           /* SGD, Keras default 0 */
-    float rho;                  /* RMSprop, Keras default 0.9 */
+    float rho;                  /* RMSprop (Keras default 0.9), Adadelta (0.95) */
 } glove_hyper;
 
 #define GLOVE_OPT_ADAGRAD 0
@@ -137,6 +150,9 @@ typedef struct glove_hyper {
 #define GLOVE_OPT_RMSPROP 2
 #define GLOVE_OPT_ADAMAX 3
 #define GLOVE_OPT_ADAM 4
+#define GLOVE_OPT_ADADELTA 5
+#define GLOVE_OPT_FTRL 6
+#define GLOVE_OPT_NADAM 7
 
 #define GLOVE_HEAD_REGRESSION 0
 #define GLOVE_HEAD_LOGISTIC 1

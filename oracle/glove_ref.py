@@ -45,6 +45,7 @@ ADAGRAD_INIT_ACC = 0.1
 KERAS_EPSILON = 1e-7
 ADAM_BETA1 = 0.9
 ADAM_BETA2 = 0.999
+FTRL_INIT_ACC = 0.1  # Keras-legacy Ftrl(initial_accumulator_value=0.1)
 INIT_RANGE = 0.05  # Keras Embedding default initializer "uniform" = U(-0.05, 0.05)
 
 
@@ -66,7 +67,7 @@ class Hyper:
     # the name and the learning rate only): SGD(momentum=0.0, nesterov=False), RMSprop(rho=0.9, momentum=0.0, centered=False)
     momentum: float = 0.0
     nesterov: bool = False
-    rho: float = 0.9
+    rho: float | None = None       # None: the optimizer's own Keras default (RMSprop 0.9, Adadelta 0.95)
 
 
 class Tables:
@@ -103,8 +104,30 @@ class Tables:
                 setattr(self, "V_" + n, np.zeros_like(getattr(self, n)))
             self.M_g = dtype(0.0)
             self.V_g = dtype(0.0)
+        elif optimizer == "Nadam":
+            # slots m, v (zeros) and the optimizer's scalar weight "momentum_cache" (ones): the running product of the momentum schedule
+            for n in names:
+                setattr(self, "M_" + n, np.zeros_like(getattr(self, n)))
+                setattr(self, "V_" + n, np.zeros_like(getattr(self, n)))
+            self.M_g = dtype(0.0)
+            self.V_g = dtype(0.0)
+            self.m_cache = dtype(1.0)
+        elif optimizer == "Adadelta":
+            # slots "accum_grad" (A_) and "accum_var" (U_), zeros
+            for n in names:
+                setattr(self, "A_" + n, np.zeros_like(getattr(self, n)))
+                setattr(self, "U_" + n, np.zeros_like(getattr(self, n)))
+            self.A_g = dtype(0.0)
+            self.U_g = dtype(0.0)
+        elif optimizer == "Ftrl":
+            # slots "accumulator" (A_, initial_accumulator_value 0.1) and "linear" (Z_, zeros)
+            for n in names:
+                setattr(self, "A_" + n, np.full_like(getattr(self, n), FTRL_INIT_ACC))
+                setattr(self, "Z_" + n, np.zeros_like(getattr(self, n)))
+            self.A_g = dtype(FTRL_INIT_ACC)
+            self.Z_g = dtype(0.0)
         else:
-            raise ValueError("optimizer must be Adagrad, Adam, SGD, RMSprop or Adamax, got %r" % (optimizer,))
+            raise ValueError("optimizer must be Adagrad, Adam, SGD, RMSprop, Adamax, Nadam, Adadelta or Ftrl, got %r" % (optimizer,))
 
     def astype(self, dtype):
         out = Tables.__new__(Tables)
@@ -252,6 +275,60 @@ def _adamax(W, M, Vv, G, touched, lr_t, b1, b2, eps):
     W[touched] -= lr_t * M[touched] / (Vv[touched] + eps)
 
 
+NADAM_SCHEDULE_DECAY = 0.004    # Keras-legacy Nadam(schedule_decay=0.004), base 0.96
+
+
+def nadam_coefficients(step_after, m_cache, lr, b1, b2, dt=np.float64):
+    """Keras-legacy Nadam `_prepare_local` (optimizer_v2/nadam.py) for the step that ends with iterations == step_after:
+    u_t = beta1 (1 - 0.5 0.96^(0.004 t)), u_{t+1} likewise, the momentum cache (product of all u_i) advanced by u_t;
+    the learning rate is NOT decayed (the `decay` the class hands to OptimizerV2 only parameterises this schedule)."""
+    t = dt(step_after)
+    u_t = b1 * (dt(1.0) - dt(0.5) * dt(0.96) ** (dt(NADAM_SCHEDULE_DECAY) * t))
+    u_t1 = b1 * (dt(1.0) - dt(0.5) * dt(0.96) ** (dt(NADAM_SCHEDULE_DECAY) * (t + 1)))
+    sched_new = m_cache * u_t
+    sched_next = sched_new * u_t1
+    return dict(lr=lr, b1=b1, b2=b2, one_minus_u_t=1 - u_t, u_t1=u_t1, om_new=1 - sched_new, om_next=1 - sched_next,
+                v_den=1 - b2 ** t, sched_new=sched_new)
+
+
+def _nadam(W, M, Vv, G, touched, k, eps):
+    """Keras-legacy Nadam `_resource_apply_sparse` (optimizer_v2/nadam.py): m and v decay over the WHOLE variable (like the
+    legacy Adam), the scaled gradient is scatter-added on the touched rows, and ONLY the touched rows move:
+    m_bar = (1 - u_t) g / (1 - prod u_1..t) + u_{t+1} m / (1 - prod u_1..t+1); var -= lr m_bar / (sqrt(v / (1 - beta2^t)) + eps)."""
+    M *= k["b1"]
+    M += (1 - k["b1"]) * G
+    Vv *= k["b2"]
+    Vv += (1 - k["b2"]) * G * G
+    m_bar = k["one_minus_u_t"] * (G[touched] / k["om_new"]) + k["u_t1"] * (M[touched] / k["om_next"])
+    W[touched] -= k["lr"] * m_bar / (np.sqrt(Vv[touched] / k["v_den"]) + eps)
+
+
+def _adadelta(W, A, U, G, touched, lr, rho, eps):
+    """Keras-legacy Adadelta `_resource_apply_sparse` (optimizer_v2/adadelta.py -> ResourceSparseApplyAdadelta, kernel
+    SparseApplyAdadelta of tensorflow/core/kernels/training_ops.cc), touched rows only:
+    accum = rho accum + (1 - rho) g^2; update = sqrt(accum_update + eps) / sqrt(accum + eps) g; var -= lr update;
+    accum_update = rho accum_update + (1 - rho) update^2.  Defaults: rho 0.95, epsilon 1e-7."""
+    g = G[touched]
+    a = rho * A[touched] + (1 - rho) * g * g
+    upd = np.sqrt(U[touched] + eps) / np.sqrt(a + eps) * g
+    A[touched] = a
+    W[touched] -= lr * upd
+    U[touched] = rho * U[touched] + (1 - rho) * upd * upd
+
+
+def _ftrl(W, A, Z, G, touched, lr):
+    """Keras-legacy Ftrl `_resource_apply_sparse` at its defaults (optimizer_v2/ftrl.py: learning_rate_power -0.5, l1 = l2 =
+    l2_shrinkage = beta = 0 -> ResourceSparseApplyFtrl, kernel FtrlCompute of training_ops.cc), touched rows only:
+    new_accum = accum + g^2; linear += g - (sqrt(new_accum) - sqrt(accum)) / lr var;
+    var = -linear / (sqrt(new_accum) / lr) where |linear| > l1 = 0, else 0; accum = new_accum."""
+    g, a, w = G[touched], A[touched], W[touched]
+    na = a + g * g
+    z = Z[touched] + g - (np.sqrt(na) - np.sqrt(a)) / lr * w
+    Z[touched] = z
+    W[touched] = np.where(np.abs(z) > 0, -z / (np.sqrt(na) / lr), 0)
+    A[touched] = na
+
+
 def apply_update(t: Tables, gr, hp: Hyper):
     """Optimizer update of the five variables from summed gradients `gr`; step += 1."""
     dt = t.dtype
@@ -274,11 +351,36 @@ def apply_update(t: Tables, gr, hp: Hyper):
             t.A_g = t.A_g * mom - lr * dg
             t.g = t.g + ((t.A_g * mom - lr * dg) if hp.nesterov else t.A_g)
     elif t.optimizer == "RMSprop":
-        rho = dt(np.float32(hp.rho))
+        rho = dt(np.float32(0.9 if hp.rho is None else hp.rho))
         for n in ("R", "C", "br", "bc"):
             _rmsprop_dense_decay(getattr(t, n), getattr(t, "A_" + n), gr["G_" + n], lr, rho, eps)
         t.A_g = rho * t.A_g + (1 - rho) * dg * dg
         t.g = t.g - lr * dg / (np.sqrt(t.A_g) + eps)
+    elif t.optimizer == "Nadam":
+        b1, b2 = dt(np.float32(hp.beta1)), dt(np.float32(hp.beta2))
+        k = nadam_coefficients(t.step + 1, t.m_cache, lr, b1, b2, dt)
+        for n, side in (("R", "r"), ("C", "c"), ("br", "r"), ("bc", "c")):
+            _nadam(getattr(t, n), getattr(t, "M_" + n), getattr(t, "V_" + n), gr["G_" + n], gr["touched_" + side], k, eps)
+        t.M_g = b1 * t.M_g + (1 - b1) * dg                     # a dense variable: `_resource_apply_dense`, same formulas
+        t.V_g = b2 * t.V_g + (1 - b2) * dg * dg
+        m_bar = k["one_minus_u_t"] * (dg / k["om_new"]) + k["u_t1"] * (t.M_g / k["om_next"])
+        t.g = t.g - lr * m_bar / (np.sqrt(t.V_g / k["v_den"]) + eps)
+        t.m_cache = dt(k["sched_new"])
+    elif t.optimizer == "Adadelta":
+        rho = dt(np.float32(0.95 if hp.rho is None else hp.rho))
+        for n, side in (("R", "r"), ("C", "c"), ("br", "r"), ("bc", "c")):
+            _adadelta(getattr(t, n), getattr(t, "A_" + n), getattr(t, "U_" + n), gr["G_" + n], gr["touched_" + side], lr, rho, eps)
+        t.A_g = rho * t.A_g + (1 - rho) * dg * dg
+        upd = np.sqrt(t.U_g + eps) / np.sqrt(t.A_g + eps) * dg
+        t.g = t.g - lr * upd
+        t.U_g = rho * t.U_g + (1 - rho) * upd * upd
+    elif t.optimizer == "Ftrl":
+        for n, side in (("R", "r"), ("C", "c"), ("br", "r"), ("bc", "c")):
+            _ftrl(getattr(t, n), getattr(t, "A_" + n), getattr(t, "Z_" + n), gr["G_" + n], gr["touched_" + side], lr)
+        na = t.A_g + dg * dg
+        t.Z_g = t.Z_g + dg - (np.sqrt(na) - np.sqrt(t.A_g)) / lr * t.g
+        t.g = dt(-t.Z_g / (np.sqrt(na) / lr)) if abs(t.Z_g) > 0 else dt(0.0)
+        t.A_g = na
     elif t.optimizer == "Adamax":
         b1, b2 = dt(np.float32(hp.beta1)), dt(np.float32(hp.beta2))
         lr_t = dt(float(lr) / (1.0 - float(b1) ** (t.step + 1)))

@@ -1,6 +1,6 @@
 """The Keras optimizers beyond Adagrad / Adam that `tf.keras.optimizers.get(name)` resolves (reference
 src/models/train_utils.py:13-16 hands over the name and the learning rate; everything else keeps its Keras-legacy default):
-SGD (plain, momentum, Nesterov), RMSprop, Adamax through glove_step_sparse_f32 against oracle/glove_ref.py (float64).
+SGD (plain, momentum, Nesterov), RMSprop, Adamax, Adadelta, Ftrl, Nadam (all eight names of Keras 2.11 with Adagrad and Adam) through glove_step_sparse_f32 against oracle/glove_ref.py (float64).
 Tolerances as for the other optimizers: loss rtol 1e-5, parameters and slots rtol 1e-5 / atol 1e-6."""
 import json
 from pathlib import Path
@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 CASES = [("SGD", {}, 0.05), ("SGD", {"momentum": 0.9}, 0.02), ("SGD", {"momentum": 0.9, "nesterov": True}, 0.02),
-         ("RMSprop", {}, 0.001), ("Adamax", {}, 0.002)]
+         ("RMSprop", {}, 0.001), ("Adamax", {}, 0.002), ("Adadelta", {}, 1.0), ("Ftrl", {}, 0.05), ("Nadam", {}, 0.002)]
+SLOTS = {"SGD": ("A_",), "RMSprop": ("A_",), "Adamax": ("M_", "V_"), "Adadelta": ("A_", "U_"), "Ftrl": ("A_", "Z_"), "Nadam": ("M_", "V_")}
 
 
 def _device_tables(t):
@@ -32,12 +33,12 @@ def _device_tables(t):
 
 def _check(dt, t, rtol, atol):
     got = lambda x: (x[:, :dt.d_model] if x.dim() == 2 else x).cpu().numpy()
-    slot1 = "M_" if t.optimizer == "Adamax" else "A_"
+    slots = SLOTS[t.optimizer]
     for n in ("R", "C", "br", "bc"):
         np.testing.assert_allclose(got(getattr(dt, n)), getattr(t, n), rtol=rtol, atol=atol, err_msg=n)
-        np.testing.assert_allclose(got(dt.s1[n]), getattr(t, slot1 + n), rtol=rtol, atol=atol, err_msg=slot1 + n)
-        if t.optimizer == "Adamax":
-            np.testing.assert_allclose(got(dt.s2[n]), getattr(t, "V_" + n), rtol=rtol, atol=atol, err_msg="V_" + n)
+        np.testing.assert_allclose(got(dt.s1[n]), getattr(t, slots[0] + n), rtol=rtol, atol=atol, err_msg=slots[0] + n)
+        if len(slots) > 1:
+            np.testing.assert_allclose(got(dt.s2[n]), getattr(t, slots[1] + n), rtol=rtol, atol=atol, err_msg=slots[1] + n)
     np.testing.assert_allclose(dt.scalars[0].item(), t.g, rtol=rtol, atol=atol)
     assert dt.global_step == t.step
 
@@ -52,7 +53,7 @@ def test_single_step_and_trajectory(hip, optimizer, kw, lr, B, V, d):
     t = oracle_tables(V, d, optimizer)
     dt = _device_tables(t)
     h = make_hyper(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=lr, batch_size=B, optimizer=optimizer, **kw)
-    G = hip.dense_grad_buffer(dt) if optimizer == "RMSprop" else None
+    G = hip.dense_grad_buffer(dt) if optimizer in ("RMSprop", "Nadam") else None
     loss_out = torch.zeros(4, device="cuda:0")
     keep = V - 1                                            # an id no batch contains
     r0 = dt.R[keep].clone()
@@ -66,18 +67,21 @@ def test_single_step_and_trajectory(hip, optimizer, kw, lr, B, V, d):
             _check(dt, t, 1e-5, 1e-6)
     _check(dt, t, 5e-5, 5e-6)
     assert torch.equal(dt.R[keep], r0)
+    if optimizer == "Nadam":
+        np.testing.assert_allclose(dt.scalars[4 + t.step % 2].item(), t.m_cache, rtol=1e-5)     # the momentum cache, from the device
     if G is not None:
         assert float(G.abs().max()) == 0.0                  # the dense buffer is all zero again
 
 
-@pytest.mark.parametrize("name,shuffle", [("sgd", "full"), ("RMSprop", "full"), ("adamax", "static"), ("SGD", "static")])
+@pytest.mark.parametrize("name,shuffle", [("sgd", "full"), ("RMSprop", "full"), ("adamax", "static"), ("SGD", "static"),
+                                          ("adadelta", "full"), ("FTRL", "static"), ("nadam", "full")])
 def test_cli_with_other_keras_optimizers(hip, tmp_path, name, shuffle):
     """`--optimizer` takes the Keras names case-insensitively, as tf.keras.optimizers.get does; both epoch modes train (the
     eval loss over the whole file falls) and checkpoints carry the slots."""
     from trainer import estimator
     csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
     job = tmp_path / "job"
-    lr = {"sgd": "0.5", "rmsprop": "0.01", "adamax": "0.02"}[name.lower()]
+    lr = {"sgd": "0.5", "rmsprop": "0.01", "adamax": "0.02", "adadelta": "5.0", "ftrl": "0.5", "nadam": "0.02"}[name.lower()]
     estimator.main(["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
                     "--embedding-size", "16", "--optimizer", name, "--learning-rate", lr, "--batch-size", "64",
                     "--train-steps", "200", "--log-every", "50", "--seed", "3", "--epoch-shuffle", shuffle,
@@ -85,10 +89,10 @@ def test_cli_with_other_keras_optimizers(hip, tmp_path, name, shuffle):
     ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
     assert ev[-1]["global_step"] == 200 and ev[-1]["average_loss"] < ev[0]["average_loss"]
     blob = torch.load(job / "model.ckpt-200.pt", weights_only=False)["tables"]
-    assert blob["optimizer"].lower() == name.lower() and "slot1_R" in blob and ("slot2_R" in blob) == (name.lower() == "adamax")
+    assert blob["optimizer"].lower() == name.lower() and "slot1_R" in blob and ("slot2_R" in blob) == (name.lower() in ("adamax", "adadelta", "ftrl", "nadam"))
 
 
 def test_unknown_optimizer_is_rejected():
     from trainer.train_utils import get_optimizer
     with pytest.raises(ValueError, match="no HIP kernel"):
-        get_optimizer("Ftrl", learning_rate=0.1)
+        get_optimizer("Lion", learning_rate=0.1)               # not a Keras 2.11 name
