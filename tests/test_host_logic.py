@@ -73,8 +73,11 @@ def test_get_optimizer_by_keras_name():
     assert get_optimizer("adagrad", learning_rate=0.1) == {
         "class_name": "Adagrad", "config": {"initial_accumulator_value": 0.1, "epsilon": 1e-7, "learning_rate": 0.1}}
     assert get_optimizer("Adam")["config"]["beta_2"] == 0.999
+    # every name tf.keras.optimizers.get resolves in Keras 2.11 (reference train_utils.py:13-16 accepts any of them)
+    for name in ("sgd", "rmsprop", "adamax", "nadam", "adadelta", "ftrl"):
+        assert get_optimizer(name)["class_name"].lower() == name
     with pytest.raises(ValueError, match="no HIP kernel"):
-        get_optimizer("Ftrl")
+        get_optimizer("Lion")
 
 
 def test_checkpoint_layout_and_resume(tmp_path):
