@@ -310,6 +310,7 @@ struct DealJob {
     int shift;
     uint32_t mask;
     int bshift;                                 // log2 B when B is a power of two, else -1
+    int nt;                                     // a stream beyond the caches: its one pass per epoch goes by non-temporal loads and stores
     using Item = typename std::conditional<LAST, DealItemLast, DealItemMid>::type;
 
     // (called by the histogram: every position exactly once)
@@ -331,9 +332,16 @@ struct DealJob {
         const DealSide &sd = s[side];
         int32_t batch;
         if (FIRST) {
-            it.id = sd.id[i]; it.partner = sd.partner[i];
-            it.w = __float_as_int(sd.w[i]); it.y = __float_as_int(sd.y[i]);
-            batch = sd.cache[i];
+            if (nt) {
+                // (read once per epoch: non-temporal, so that the deal does not push the step's table rows out of the L2s)
+                it.id = __builtin_nontemporal_load(sd.id + i); it.partner = __builtin_nontemporal_load(sd.partner + i);
+                it.w = __float_as_int(__builtin_nontemporal_load(sd.w + i)); it.y = __float_as_int(__builtin_nontemporal_load(sd.y + i));
+                batch = __builtin_nontemporal_load(sd.cache + i);
+            } else {
+                it.id = sd.id[i]; it.partner = sd.partner[i];
+                it.w = __float_as_int(sd.w[i]); it.y = __float_as_int(sd.y[i]);
+                batch = sd.cache[i];
+            }
         } else {
             const int4 v = sd.tmp_pay[i];
             it.id = v.x; it.partner = v.y; it.w = v.z; it.y = v.w;
@@ -347,8 +355,13 @@ struct DealJob {
     __device__ void store(int side, int64_t dest, const DealItemLast &it) const
     {
         const DealSide &sd = s[side];
-        sd.o_id[dest] = it.id; sd.o_partner[dest] = it.partner;
-        sd.o_w[dest] = __int_as_float(it.w); sd.o_y[dest] = __int_as_float(it.y);
+        if (nt) {
+            __builtin_nontemporal_store(it.id, sd.o_id + dest); __builtin_nontemporal_store(it.partner, sd.o_partner + dest);
+            __builtin_nontemporal_store(__int_as_float(it.w), sd.o_w + dest); __builtin_nontemporal_store(__int_as_float(it.y), sd.o_y + dest);
+        } else {
+            sd.o_id[dest] = it.id; sd.o_partner[dest] = it.partner;
+            sd.o_w[dest] = __int_as_float(it.w); sd.o_y[dest] = __int_as_float(it.y);
+        }
     }
     __device__ void store(int side, int64_t dest, const DealItemMid &it) const
     {
@@ -574,6 +587,9 @@ int glove_epoch_deal(const glove_pairs *row_major, const glove_pairs *col_major,
     if (h < 0) return GLOVE_E_BADARG;
     const uint4 key = make_uint4((uint32_t)key_lo, (uint32_t)(key_lo >> 32), (uint32_t)key_hi, (uint32_t)(key_hi >> 32));
     hipStream_t st = (hipStream_t)stream;
+    // both orders in and out, 64 B per pair: from 128 MB on the stream is beyond the L2s and most of the Infinity Cache
+    // (measured, whole step with the deal beside it: V = 400 k, B = 1 M 683 -> 672 us; text8, 1.2 M pairs: 29.2 -> 29.9, not taken there)
+    const int nt = n * 64 >= (128ll << 20) ? 1 : 0;
     DealSide s[2];
     s[0] = DealSide{row_major->id, row_major->partner, row_major->w, row_major->y, nullptr,
                     row_side->id, row_side->partner, row_side->w, row_side->y, d.cache[0], d.pay[0], d.batch[0]};
@@ -584,12 +600,12 @@ int glove_epoch_deal(const glove_pairs *row_major, const glove_pairs *col_major,
         for (bshift = 0; (1ll << bshift) < B; ++bshift) {}
     if (dp.passes == 1) {
         const int db[2] = {dp.db[0], dp.db[0]};
-        return run_cs_pass(DealJob<true, true>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, 0, (1u << dp.db[0]) - 1u, bshift}, d.cs, n, db, st);
+        return run_cs_pass(DealJob<true, true>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, 0, (1u << dp.db[0]) - 1u, bshift, nt}, d.cs, n, db, st);
     }
     const int db0[2] = {dp.db[0], dp.db[0]}, db1[2] = {dp.db[1], dp.db[1]};
-    if (int rc = run_cs_pass(DealJob<true, false>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, 0, (1u << dp.db[0]) - 1u, bshift}, d.cs, n, db0, st))
+    if (int rc = run_cs_pass(DealJob<true, false>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, 0, (1u << dp.db[0]) - 1u, bshift, nt}, d.cs, n, db0, st))
         return rc;
-    return run_cs_pass(DealJob<false, true>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, dp.db[0], (1u << dp.db[1]) - 1u, bshift}, d.cs, n, db1, st);
+    return run_cs_pass(DealJob<false, true>{{s[0], s[1]}, (uint64_t)n, (uint32_t)B, h, key, dp.db[0], (1u << dp.db[1]) - 1u, bshift, nt}, d.cs, n, db1, st);
 }
 
 }  // extern "C"

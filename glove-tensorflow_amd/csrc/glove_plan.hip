@@ -689,8 +689,10 @@ __device__ inline RecordOne pick(const RecordDev &r)
     return o;
 }
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
 template <class Args>
-__global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
+__global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP, int nt)
 {
     const RecordOne &rone = pick(args);
     const RecordArgs &a = rone.a;
@@ -789,7 +791,10 @@ __global__ __launch_bounds__(kBlock) void fill_records(Args args, int capP)
                 }
                 v = make_int4(o[0], o[1], o[2], o[3]);
             }
-            dst[gq] = v;
+            // (nt: records of a big batch are read a segment of steps later, long after the L2s have turned over: they go
+            // out non-temporal instead of pushing table rows out)
+            if (nt) __builtin_nontemporal_store(v4i_t{v.x, v.y, v.z, v.w}, reinterpret_cast<v4i_t *>(dst + gq));
+            else dst[gq] = v;
         }
     }
 }
@@ -820,8 +825,8 @@ static int launch_fill_records_set(const glove_plan *const *plans, int n, hipStr
     const int64_t per_block = (kBlock / 64) * 32;
     const int64_t nb = (most + per_block - 1) / per_block;
     const dim3 grid((unsigned)(nb < 1 ? 1 : nb), 2, n);
-    if (n == 1) hipLaunchKernelGGL(fill_records<RecordOne>, grid, dim3(kBlock), 0, st, set.b[0], capP);
-    else hipLaunchKernelGGL(fill_records<RecordSet>, grid, dim3(kBlock), 0, st, set, capP);
+    if (n == 1) hipLaunchKernelGGL(fill_records<RecordOne>, grid, dim3(kBlock), 0, st, set.b[0], capP, 0);
+    else hipLaunchKernelGGL(fill_records<RecordSet>, grid, dim3(kBlock), 0, st, set, capP, 0);
     return (int)hipGetLastError();
 }
 
@@ -1202,7 +1207,7 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
         if (plans[0].r_crec) {
             const int64_t per_block = (kBlock / 64) * 32;
             const int64_t nb = (most + per_block - 1) / per_block;
-            hipLaunchKernelGGL(fill_records<RecordDev>, dim3((unsigned)(nb < 1 ? 1 : nb), 2, nz), dim3(kBlock), 0, st, RecordDev{part}, rec_cap(cap));
+            hipLaunchKernelGGL(fill_records<RecordDev>, dim3((unsigned)(nb < 1 ? 1 : nb), 2, nz), dim3(kBlock), 0, st, RecordDev{part}, rec_cap(cap), B >= 262144 ? 1 : 0);
         }
     }
     return (int)hipGetLastError();
