@@ -34,7 +34,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 } > $out/${tag}_${name}_kernel_stats.txt
 cap=$(grep -o '"chunk_cap": [0-9]*' $raw/stats.log | head -1 | grep -o '[0-9]*$')
 # (the per-step traffic JSON delimits steps by the apply launch: only for the plain single-GPU step forms)
-case "$extra" in *--row-sharded*|*--exchange*|*--force-dense*) ;; *)
+case "$extra" in *--row-sharded*|*--exchange*|*--force-dense*|*--optimizer*) ;; *)
 idx=dealt; case "$extra" in *--static-index*) idx=static;; esac
 python3 tools/pmc_traffic.py $raw/fetch $raw/write $out/${tag}_${name}_traffic.json workload=$wl batch=$batch chunk_cap=$cap index=$idx \
   "command=rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes) -- $B --no-graph --steps $psteps --warmup 5"
