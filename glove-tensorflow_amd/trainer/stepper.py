@@ -327,10 +327,13 @@ class Stepper(GraphedSteps):
         # inside its own entry point
         self.dense = self._multi or tables.optimizer == "Adam"
         self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer in ("RMSprop", "Nadam") else None
+        form = int(hyper_kwargs.get("step_form", 0) or 0)
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
-            tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
-            tables.maybe_enable_twin()          # big tables: the fused step writes new rows beside the old ones
-        elif not self._multi and tables.optimizer == "Adam" and hasattr(tables, "maybe_enable_tags"):
+            if form in (0, 5):
+                tables.maybe_enable_tags(batch_size)   # small batches on small tables: the tagged step
+            if form in (0, 4):
+                tables.maybe_enable_twin()      # big tables: the fused step writes new rows beside the old ones
+        elif not self._multi and tables.optimizer == "Adam" and form in (0, 5) and hasattr(tables, "maybe_enable_tags"):
             tables.maybe_enable_tags(batch_size)   # small batches on small tables: Adam's one-launch step on twinned tables
         self.G = backend.dense_grad_buffer(tables) if self.dense else None
         self.exchange, self.rows, self.bufs = exchange, False, None

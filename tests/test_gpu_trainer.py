@@ -266,6 +266,45 @@ def test_cli_on_a_twinned_row_table_equals_the_three_launch_form(hip, tmp_path):
     assert tensors >= 9 and state["3"] == state["4"]
 
 
+@pytest.mark.parametrize("shuffle", ["full", "static"])
+def test_cli_with_adam_in_one_launch_equals_the_two_launch_form(hip, tmp_path, shuffle):
+    """The reference's default optimizer end to end on twinned tables (AUTO: Keras-legacy Adam in one launch per step, the
+    tables flipping as a whole every step), with logging points, eval, checkpoints, resume and export in between — every
+    reader first brings the tables home — against --step-form 1 (passes + the fused apply / decay kernel on plain tables):
+    same checkpoints within fp32 rounding of a few multi-chunk ids' sums, same exported neighbours."""
+    from trainer import estimator, export_embeddings
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    state = {}
+    for form in (0, 1):
+        job = tmp_path / ("job%d" % form)
+        argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+                "--embedding-size", "50", "--optimizer", "Adam", "--learning-rate", "0.01", "--batch-size", "16",
+                "--epoch-shuffle", shuffle, "--step-form", str(form), "--train-steps", "45", "--log-every", "15", "--seed", "7"]
+        estimator.main(argv)
+        params = json.loads((job / "params.json").read_text())
+        params["train_steps"] = 91
+        est = estimator.Estimator(params)                      # resume from the checkpoint, in process: an odd number of steps more
+        est.train(91)
+        assert (est.model.tables.R_tag is not None) == (form == 0)              # the one-launch form really ran
+        if form == 0:
+            assert est.model.tables._twin_dirty
+        state[form] = torch.load(job / "model.ckpt-91.pt", weights_only=False)
+        assert float(state[form]["tables"]["scalars"][3]) == 0.0                # checkpoints hold the plain form
+        out = tmp_path / ("emb%d.json" % form)
+        export_embeddings.main(job_dir=str(job), embeddings_json=str(out))
+        state[str(form)] = json.loads(out.read_text())
+        ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+        assert ev[-1]["global_step"] == 91 and ev[-1]["average_loss"] < ev[0]["average_loss"]
+    tensors = 0
+    for k, v in state[0]["tables"].items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            np.testing.assert_allclose(v.numpy(), state[1]["tables"][k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+            tensors += 1
+    assert tensors >= 13
+    for token, rec in state["0"].items():
+        np.testing.assert_allclose(rec["item_embedding"], state["1"][token]["item_embedding"], rtol=2e-4, atol=2e-6)
+
+
 def _two_rank_trainer(rank, port, argv, out_dir):
     """One rank of `python -m trainer.estimator` under a launcher, both ranks on the box's one GPU: the HIP
     kernels are the product's, only the transport of the collectives is gloo instead of RCCL."""
