@@ -233,7 +233,7 @@ class Estimator:
             if pending is not None:
                 self._finish_log_point(pending)
         finally:
-            self._drain_logs()
+            self._drain_logs(stop=True)
 
     # ---- logging points
     HOST_BIASES_MAX = 1 << 18       # bias vectors up to this length are logged from a host copy (one 1 MB copy at most)
@@ -307,12 +307,17 @@ class Estimator:
             self._log_thread.start()
         self._log_queue.put((name, rec, biases))
 
-    def _drain_logs(self):
-        """Everything handed to the writer thread is on disk when this returns (before a checkpoint, an eval pass, the end)."""
+    def _drain_logs(self, stop=False):
+        """Everything handed to the writer thread is on disk when this returns (before a checkpoint, an eval pass, the end);
+        `stop`: the thread ends as well (it holds the estimator — tables, stream — alive while it runs)."""
         q = getattr(self, "_log_queue", None)
         if q is None:
             return
         q.join()
+        if stop:
+            q.put(None)
+            self._log_thread.join()
+            self._log_queue = self._log_thread = None
         if self._log_error is not None:
             err, self._log_error = self._log_error, None
             raise err
