@@ -406,7 +406,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
     runner = ReshufflingRunner(hip, stream, tables, hyper, chunk_cap=chunk_cap, burst=64, graphs=False if no_graph else None, segment=segment)
     cap, S, nb = runner.cap, runner.S, runner.nb
     log("  masters in %.1f ms (once, at load); %d batches per epoch, index built %d batches at a time, chunk records: %s" % (
-        masters_ms, nb, S, runner.records))
+        masters_ms, nb, S, "run words instead (pair fields as dealt)" if getattr(runner, "run_words", False) else runner.records))
 
     def run(n_steps):
         done = 0
@@ -449,7 +449,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
                                   stream=stream.side) / nb
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (elapsed / steps) / 1e9
-    fused = runner.records and getattr(tables, "_twin_dirty", False)
+    fused = (runner.records or getattr(runner, "run_words", False)) and getattr(tables, "_twin_dirty", False)
     traffic, traffic_src = measured_traffic(workload, B, cap, fused, "dealt") if not adam else (None, None)
     out = {
         "metric": "co-occurrence nonzeros/sec", "value": steps * B / elapsed, "unit": "nonzeros/s",
@@ -463,7 +463,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
                             "index of %d consecutive batches numbered by 3 launches on a side stream, inside the timed region" % S,
                    "launch": "the trainer's runner: steps replayed from hipGraphs of 2^k steps" if runner.graphs_on else
                              "the trainer's runner: every run of steps issued by one C call (glove_steps_adagrad_f32)",
-                   "parallelism": "single GPU", "chunk_records": bool(runner.records)},
+                   "parallelism": "single GPU", "chunk_records": bool(runner.records), "chunk_run_words": bool(getattr(runner, "run_words", False))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
                      "stream_ceiling": HBM_STREAM_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -530,6 +530,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     backend = HipBackend(dev)
     backend.hip = hip
     backend.row_floats = tables.d
+    backend.exchange = mode != "single"         # the multi-rank forms' packing passes read chunk records
     hyper_kw = dict(learning_rate=lr, step_form=step_form)
 
     # ---- load time (untimed): resident batches + their dedup index
@@ -542,7 +543,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         handles = [stepper.add_batch(*bt, cap) for bt in batches]
         plans = [stepper.batches[h]["plan"] for h in handles]
     else:
-        plans = [hip.build_plan(*bt, V, chunk_cap=cap, compact=True, d=tables.d, V_row=V_row if V_row < V else 0)
+        plans = [hip.build_plan(*bt, V, chunk_cap=cap, compact=True, d=tables.d, V_row=V_row if V_row < V else 0,
+                                run_words=None if mode == "single" else False)
                  for bt in batches]
         handles = plans
     torch.cuda.synchronize()
@@ -563,7 +565,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 
     if mode == "single" and step_form in (0, 5) and plans[0].r_crec is not None:
         tables.maybe_enable_tags(B)         # small batches on small tables: the tagged step (as Stepper does)
-    if mode == "single" and step_form == 0 and not adam and plans[0].r_crec is not None and \
+    if mode == "single" and step_form == 0 and not adam and plans[0].fusable and \
             (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES:
         tables.maybe_enable_twin()          # the library will take a fused form: give it the twinned row table (as Stepper does)
     hyper = make_hyper(batch_size=B * world, **hyper_kw)
@@ -664,10 +666,10 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                 calls["dense_grad"] = lambda p: hip.dense_grad(p, tables, hyper, G, ws)
                 calls["dense_adam"] = lambda p: hip.dense_adam(tables, hyper, G, loss_out)
         else:
-            fused_auto = plans[0].r_crec is not None and (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES
+            fused_auto = plans[0].fusable and (u_row + u_col) * tables.d * 16 >= FUSED_STEP_BYTES
             if form == 0:
                 form = 5 if tables.R_tag is not None and B <= 2048 else (4 if tables.R_ver is not None else 3) if fused_auto else 1
-            if form == 1 or plans[0].r_crec is None:
+            if form == 1 or not plans[0].fusable:
                 calls["passes"] = lambda p: hip.passes(p, tables, hyper, ws)      # row side + col side, one launch
                 calls["apply_adagrad"] = lambda p: hip.apply_adagrad(p, tables, hyper, loss_out, ws)
             else:

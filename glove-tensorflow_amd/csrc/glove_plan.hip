@@ -302,6 +302,7 @@ struct SideOut {
                                                           // of its id << 31 | chunks of the id behind it}: words 2, 3 of its record header
     uint32_t *mark[2];                                    // per side (or nullptr): bitmap of the batch's ids — zeroed by side_tiles, set by side_emit
     int mark_words[2];
+    uint32_t *chunk_hw[2];                                // per side (or nullptr): per chunk, word 3 of its record header on its own (glove_plan.r_chunk_hw)
 };
 
 // flags of this thread's kTilePer positions: bit 0 = opens a chunk, bit 1 = opens an id; nu / nc = their counts.
@@ -463,7 +464,8 @@ __device__ inline SideOne pick(const SideDev &a)
     o.out = SideOut{{pl.r_chunk_id, pl.c_chunk_id}, {pl.r_chunk_start, pl.c_chunk_start}, {pl.r_uniq_slot, pl.c_uniq_slot},
                     pl.counts, {pl.r_uniq_rec, pl.c_uniq_rec}, tile_re, pl.heavy, pl.heavy_chunks, pl.cap_heavy,
                     {pl.r_crec ? aux0 : nullptr, pl.r_crec ? aux1 : nullptr},
-                    {pl.r_mark, pl.c_mark}, {((pl.V_row > 0 ? pl.V_row : a.V) + 31) / 32, (a.V + 31) / 32}};
+                    {pl.r_mark, pl.c_mark}, {((pl.V_row > 0 ? pl.V_row : a.V) + 31) / 32, (a.V + 31) / 32},
+                    {pl.r_chunk_hw, pl.c_chunk_hw}};
     o.cp = SideCopy{{a.src.partner[0] + at, a.src.partner[1] + at}, {a.src.w[0] + at, a.src.w[1] + at}, {a.src.y[0] + at, a.src.y[1] + at},
                     {pl.r_partner, pl.c_partner}, {pl.r_w, pl.c_w}, {pl.r_y, pl.c_y}};
     return o;
@@ -643,10 +645,12 @@ __global__ __launch_bounds__(kTileThreads) void side_emit(Args args, int64_t B, 
         if (!(flag[i] & 1u)) continue;                     // (a position that opens an id opens a chunk)
         const int64_t k = k0 + i;
         const int pairs = (int)(next_open - k), chunks = (pairs + chunk_cap - 1) / chunk_cap;   // from k to the end of its id
-        if (aux) {
+        if (aux || SIDE(out.chunk_hw)) {
             // words 2 and 3 of the chunk's record header are at hand here (fill_records would bisect uniq_slot for them)
             const bool opens = (flag[i] & 2u) != 0;
-            aux[open_ci[i]] = make_int2(opens ? open_ui[i] : open_ui[i] - 1, (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
+            const uint32_t hw = (uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u);
+            if (aux) aux[open_ci[i]] = make_int2(opens ? open_ui[i] : open_ui[i] - 1, (int)hw);
+            if (SIDE(out.chunk_hw)) SIDE(out.chunk_hw)[open_ci[i]] = hw;
         }
         if (!(flag[i] & 2u)) continue;
         reinterpret_cast<int4 *>(SIDE(out.uniq_rec))[open_ui[i]] = make_int4(keys[k], open_ci[i], chunks, pairs);
@@ -985,7 +989,8 @@ static int build_tiled_set(const int32_t *row, const int32_t *col, const float *
                             {plan->r_uniq_slot, plan->c_uniq_slot}, plan->counts, {plan->r_uniq_rec, plan->c_uniq_rec},
                             (const int64_t *)pw[j].tile_re, plan->heavy, plan->heavy_chunks, plan->cap_heavy,
                             {plan->r_crec ? pw[j].chunk_aux[0] : nullptr, plan->r_crec ? pw[j].chunk_aux[1] : nullptr},
-                            {plan->r_mark, plan->c_mark}, {(Vr_of(plan, V) + 31) / 32, (V + 31) / 32}};
+                            {plan->r_mark, plan->c_mark}, {(Vr_of(plan, V) + 31) / 32, (V + 31) / 32},
+                            {plan->r_chunk_hw, plan->c_chunk_hw}};
         ss.b[j].cp = SideCopy{};
         ss.b[j].ex = TileExtra{pw[j].tile_re, plan->counts, (const int32_t *)pw[j].mapped, 2 * pw[j].sort_tiles,
                              (const int32_t *)pw[j].c_orig, (const int32_t *)pw[j].rpos, plan->c_perm, plan->r_to_c};
@@ -1050,6 +1055,7 @@ static int check_plan_for_build(const glove_plan *plan, int64_t B, int32_t V)
     if ((plan->r_crec == nullptr) != (plan->c_crec == nullptr)) return GLOVE_E_BADARG;
     if ((plan->r_to_c == nullptr) != (plan->c_perm == nullptr)) return GLOVE_E_BADARG;     // the links come as a pair or not at all
     if ((plan->r_mark == nullptr) != (plan->c_mark == nullptr)) return GLOVE_E_BADARG;     // so do the id bitmaps
+    if ((plan->r_chunk_hw == nullptr) != (plan->c_chunk_hw == nullptr)) return GLOVE_E_BADARG; // and the run words
     return 0;
 }
 
@@ -1175,6 +1181,7 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
         if (!own && !p->r_crec) return GLOVE_E_BADARG;
         if (p->c_perm || p->r_to_c) return GLOVE_E_BADARG;              // the links between the orders are not computed here
         if ((p->r_mark == nullptr) != (p->c_mark == nullptr)) return GLOVE_E_BADARG;
+        if ((p->r_chunk_hw == nullptr) != (p->c_chunk_hw == nullptr)) return GLOVE_E_BADARG;
         if (!p->heavy || p->heavy_chunks < 1 || p->cap_heavy < 2 * B / ((int64_t)p->heavy_chunks * p->chunk_cap) + 2) return GLOVE_E_WORKSPACE;
         if (p->cap_uniq < (B < V ? B : V)) return GLOVE_E_WORKSPACE;
         if (p->cap_chunks < glove_plan_chunk_bound(B, p->cap_uniq, p->chunk_cap)) return GLOVE_E_WORKSPACE;

@@ -127,6 +127,7 @@ struct SmallSideOut {
     int32_t *chunk_id, *chunk_start, *uniq_slot, *uniq_rec;
     int32_t *crec;              // per-chunk records (or nullptr): words 2, 3 of every record header are written here
     int rec_dwords;             // int32 per record in memory
+    uint32_t *chunk_hw;         // per chunk (or nullptr): word 3 on its own (glove_plan.r_chunk_hw)
 };
 
 // ids[k] (sorted ids, LDS) -> chunk / id arrays of one side.  Thread t owns positions t E .. t E + E - 1.  Position k opens an
@@ -230,12 +231,13 @@ __device__ inline void small_side(const Team &tm, const int32_t *ids, int B, int
         if (!(chunk >> e & 1)) continue;                                    // (a position that opens an id opens a chunk)
         const int k = k0 + e;
         const int pairs = next_open - k, chunks = (pairs + cap - 1) / cap;  // from k to the end of its id
-        if (o.crec) {
+        if (o.crec || o.chunk_hw) {
             // words 2, 3 of the chunk's record header {position of its id among the side's ids, first chunk of its id << 31 |
             // chunks of the id behind it}: at hand here, fill_records would bisect uniq_slot for them (ten dependent loads)
             const bool opens = (uniq >> e & 1) != 0;
-            *reinterpret_cast<int2 *>(o.crec + (size_t)open_ci[e] * o.rec_dwords + 2) =
-                make_int2(opens ? open_ui[e] : open_ui[e] - 1, (int)((uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u)));
+            const uint32_t hw = (uint32_t)(chunks - 1) | (opens ? 0x80000000u : 0u);
+            if (o.crec) *reinterpret_cast<int2 *>(o.crec + (size_t)open_ci[e] * o.rec_dwords + 2) = make_int2(opens ? open_ui[e] : open_ui[e] - 1, (int)hw);
+            if (o.chunk_hw) o.chunk_hw[open_ci[e]] = hw;
         }
         if (!(uniq >> e & 1)) continue;
         reinterpret_cast<int4 *>(o.uniq_rec)[open_ui[e]] = make_int4(id[e + 1], open_ci[e], chunks, pairs);
@@ -303,8 +305,8 @@ __device__ inline void build_side(int team, const Team &tm, uint32_t *kbuf, int3
         }
     }
     const int rd = 4 * rec_stride_q(rec_cap(plan.chunk_cap));
-    const SmallSideOut so = team == 0 ? SmallSideOut{plan.r_mark, plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec, plan.r_crec, rd}
-                                      : SmallSideOut{plan.c_mark, plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec, plan.c_crec, rd};
+    const SmallSideOut so = team == 0 ? SmallSideOut{plan.r_mark, plan.r_chunk_id, plan.r_chunk_start, plan.r_uniq_slot, plan.r_uniq_rec, plan.r_crec, rd, plan.r_chunk_hw}
+                                      : SmallSideOut{plan.c_mark, plan.c_chunk_id, plan.c_chunk_start, plan.c_uniq_slot, plan.c_uniq_rec, plan.c_crec, rd, plan.c_chunk_hw};
     small_side<TT, E>(tm, reinterpret_cast<const int32_t *>(kbuf), B, plan.chunk_cap, plan.heavy_chunks, plan.cap_heavy, team, L,
                       so, plan.counts, plan.heavy);
     SMALL_STAMP(4);                                                      // side numbered and stored

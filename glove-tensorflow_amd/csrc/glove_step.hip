@@ -167,6 +167,7 @@ struct PassSide {
     int count_index;               // counts[0] (row) or counts[2] (col)
     float *mark;                   // if not null: mark[id] = 1 for every id of this side (fused Adam step)
     const int32_t *crec;           // per-chunk records {id, n, first pair, only chunk of its id | partner | w | y} or nullptr
+    const uint32_t *chunk_hw;      // without records: per chunk, (first chunk of its id) << 31 | chunks of the id behind it, or nullptr
     int capP;                      // chunk_cap rounded up to a multiple of 8 (record field length)
     // fused Adagrad apply (FUSE kernels): a chunk that is its id's ONLY chunk holds the id's whole gradient in
     // registers, next to the id's own row, so the update is formed here instead of travelling through a partial
@@ -256,6 +257,41 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
     int j = FUSE ? (bid * GPB + grp) * per : bid * GPB + grp;
     const int j_end = FUSE ? (j + per < n_chunks ? j + per : n_chunks) : n_chunks;
     const int j_step = FUSE ? 1 : nblk * GPB;
+    // A plan without records (FUSE, run words): the descriptors of ALL the group's chunks — start, id, run word: 12 B each from
+    // three arrays — arrive in one round trip up front and wait in LDS; a chunk then costs what a record costs: one trip for its
+    // pair fields, then its partner rows.  (Fetched chunk by chunk they were a third dependent trip: 599 against 584 us per C4 step.)
+    constexpr bool kDesc = FUSE == 1 && !REC;
+    constexpr int kDescSlots = 16;
+    __shared__ int32_t desc_raw[kDesc ? GPB * 3 * kDescSlots : 1];
+    int32_t *desc = desc_raw + (kDesc ? grp * 3 * kDescSlots : 0);
+    const bool use_desc = kDesc && sd.chunk_hw != nullptr && per < kDescSlots;
+    const int j_first = j;
+    // ... and the pair fields of all its chunks are ONE contiguous range of the side's arrays (a few dozen pairs for the short
+    // chunks of a big batch): when they fit the group's stage they come in a second trip, coalesced, and the chunks take them
+    // from LDS — no memory trip per chunk but its partner rows.  A longer range (the full chunks of the Zipf head) is read
+    // chunk by chunk.
+    constexpr int kStagePairs = 4 * LPR;        // 12 KB of LDS per workgroup at every shape
+    __shared__ uint32_t stage_raw[kDesc ? GPB * 3 * kStagePairs : 1];
+    uint32_t *stage = stage_raw + (kDesc ? grp * 3 * kStagePairs : 0);
+    int stage_first = 0;
+    bool staged = false;
+    if (use_desc && j < j_end) {
+        if (lg <= j_end - j && lg < kDescSlots) desc[lg] = sd.chunk_start[j + lg];
+        if (lg < j_end - j && lg < kDescSlots) {
+            desc[kDescSlots + lg] = sd.chunk_id[j + lg];
+            desc[2 * kDescSlots + lg] = (int32_t)sd.chunk_hw[j + lg];
+        }
+        stage_first = desc[0];
+        const int span = desc[j_end - j] - stage_first;
+        staged = span <= kStagePairs;
+        if (staged) {
+            for (int i = lg; i < span; i += LPR) {
+                stage[i] = (uint32_t)sd.partner[stage_first + i];
+                stage[kStagePairs + i] = __float_as_uint(sd.w[stage_first + i]);
+                stage[2 * kStagePairs + i] = __float_as_uint(sd.y[stage_first + i]);
+            }
+        }
+    }
     int32_t cur_u = -1, own_at = 0;
     int run_first = 0, run_pairs = 0, run_q = 0;
     bool run_whole = false;
@@ -300,17 +336,35 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
             hw = hdr.w;
             GLOVE_DRAIN(); GLOVE_STAMP(1);
         } else {
-            u = sd.chunk_id[j];
-            s = sd.chunk_start[j];
-            n = sd.chunk_start[j + 1] - s;
+            if (use_desc) {                     // (same wave wrote them: LDS ops of one wave complete in order)
+                const int x = j - j_first;
+                s = desc[x];
+                n = desc[x + 1] - s;
+                u = desc[kDescSlots + x];
+                hw = (uint32_t)desc[2 * kDescSlots + x];
+            } else {
+                u = sd.chunk_id[j];
+                s = sd.chunk_start[j];
+                n = sd.chunk_start[j + 1] - s;
+                if (FUSE && sd.chunk_hw) hw = sd.chunk_hw[j];       // (a plan without records that carries its run words: glove_plan.r_chunk_hw)
+            }
             GLOVE_DRAIN(); GLOVE_STAMP(1);      // descriptor arrived
 #pragma unroll
             for (int sl = 0; sl < SL; ++sl) {
                 const int t = lg + sl * LPR;
-                const int k = s + (t < n ? t : 0);
-                const int32_t pv = sd.partner[k];
-                const float wv = sd.w[k];
-                const float yv = sd.y[k];
+                int32_t pv;
+                float wv, yv;
+                if (kDesc && staged) {              // (the group's stage: same wave wrote it)
+                    const int k = s - stage_first + (t < n ? t : 0);
+                    pv = (int32_t)stage[k];
+                    wv = __uint_as_float(stage[kStagePairs + k]);
+                    yv = __uint_as_float(stage[2 * kStagePairs + k]);
+                } else {
+                    const int k = s + (t < n ? t : 0);
+                    pv = sd.partner[k];
+                    wv = sd.w[k];
+                    yv = sd.y[k];
+                }
                 if (t < kChunkMax) {
                     fld[grp][0][t] = (uint32_t)pv;
                     fld[grp][1][t] = __float_as_uint(t < n ? wv : 0.f);     // tail slots weigh 0
@@ -2505,8 +2559,9 @@ static int fuse_per(const glove_plan *p, int lpr)
     int per = (int)((side + 16383) / 16384);              // <= 2,048 workgroups up to 196 k chunks a side
     per = per < 1 ? 1 : per > 12 ? 12 : per;
     const int64_t groups = (int64_t)kMaxPassBlocks * (kBlock / lpr);
-    const int64_t most = p->host_counts[0] >= 0 && p->host_counts[2] >= 0 ? (int64_t)p->cap_chunks : side;
-    const int need = (int)((most + groups - 1) / groups);
+    // (`side` is the chunk count itself when the host knows it — also for a staging plan whose counts were read back: its
+    // capacity is the worst case, V = 2 M at B = 1 M ran 16 chunks per group instead of 12 for nothing, 530 against 511 us)
+    const int need = (int)((side + groups - 1) / groups);
     return need > per ? need : per;
 }
 static inline int fusepass_blocks(const glove_plan *p, int lpr, int per, bool row)
@@ -2583,6 +2638,7 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
     sd.n_host = p->host_counts[row ? 0 : 2];
     sd.count_index = row ? 0 : 2;
     sd.crec = row ? p->r_crec : p->c_crec;
+    sd.chunk_hw = row ? p->r_chunk_hw : p->c_chunk_hw;
     sd.capP = rec_cap(p->chunk_cap);
     sd.fuse = fuse;
     sd.own_out = row ? t->R : t->C;
@@ -3052,10 +3108,14 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
 {
     if (!p || !t || !h) return GLOVE_STEP_TWO_LAUNCH;
     if (sides_of(h) != 3) return GLOVE_STEP_TWO_LAUNCH;
-    if (!p->r_crec || !p->c_crec) return GLOVE_STEP_TWO_LAUNCH;      // the fused forms read the id layout from the chunk records
+    // the fused forms read the id layout from the chunk records, or from the run words of a plan that keeps pair arrays instead
+    const bool records = p->r_crec && p->c_crec;
+    const bool run_words = p->r_chunk_hw && p->c_chunk_hw && p->r_partner && p->r_w && p->r_y && p->c_partner && p->c_w && p->c_y;
+    if (!records && !run_words) return GLOVE_STEP_TWO_LAUNCH;
+    if (!records && h->step_form == GLOVE_STEP_TAGGED) return GLOVE_STEP_TWO_LAUNCH;        // (the one-launch form walks records)
     if (h->step_form != GLOVE_STEP_AUTO) return h->step_form;
     // the latency-bound regime on step-tagged tables: everything in one launch
-    if (t->R_tag && t->C_tag && p->B <= 2048) return GLOVE_STEP_TAGGED;     // (measured against the two-launch form, 64 staging plans: 512 / 1,024 / 2,048 pairs -16 / -16 / -13 %, 4,096 +12 %)
+    if (t->R_tag && t->C_tag && p->B <= 2048 && records) return GLOVE_STEP_TAGGED;     // (measured against the two-launch form, 64 staging plans: 512 / 1,024 / 2,048 pairs -16 / -16 / -13 %, 4,096 +12 %)
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are known on the host for a plan whose build has been synchronised (a resident plan)
     // (a plan refilled on the device every step — a reshuffled epoch — is judged by the most ids its batch can hold)

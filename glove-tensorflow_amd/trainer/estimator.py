@@ -65,6 +65,8 @@ class Estimator:
                                          seed=None if seed is None else seed + 1)
         if hasattr(self.backend, "row_floats"):
             self.backend.row_floats = self.model.tables.d
+        if hasattr(self.backend, "exchange"):
+            self.backend.exchange = self.world > 1
         if self.world > 1:      # identical replicas: rank 0's init wins
             t = self.model.tables
             for buf in (t.R, t.C, t.br, t.bc):

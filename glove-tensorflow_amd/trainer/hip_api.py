@@ -18,7 +18,7 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 11
+GLOVE_ABI_VERSION = 12
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4, "Adadelta": 5, "Ftrl": 6, "Nadam": 7}      # glove_hyper.optimizer (GLOVE_OPT_*)
 STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
@@ -28,6 +28,7 @@ RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk record
 HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whole workgroup
 
 
+RUN_WORDS_MIN_CHUNKS = 98304    # chunks of a side from which a resident plan of the fused regime keeps run words instead of records (6 chunks per lane group)
 FUSED_STEP_BYTES = 192 << 20    # glove_fused_step_bytes(): touched ids x row bytes x 4 beyond which the fused step pays (re-read from the library at load)
 
 
@@ -83,7 +84,8 @@ class GlovePlan(C.Structure):
                 ("r_chunk_id", _fp), ("r_chunk_start", _fp), ("r_uniq_slot", _fp), ("r_uniq_rec", _fp),
                 ("c_partner", _fp), ("c_perm", _fp), ("c_w", _fp), ("c_y", _fp),
                 ("c_chunk_id", _fp), ("c_chunk_start", _fp), ("c_uniq_slot", _fp), ("c_uniq_rec", _fp), ("heavy", _fp),
-                ("r_crec", _fp), ("c_crec", _fp), ("r_mark", _fp), ("c_mark", _fp)]
+                ("r_crec", _fp), ("c_crec", _fp), ("r_mark", _fp), ("c_mark", _fp),
+                ("r_chunk_hw", _fp), ("c_chunk_hw", _fp)]
 
 
 class GlovePairs(C.Structure):
@@ -517,7 +519,7 @@ class Plan:
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
                  cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None, links: bool = True,
-                 own_pairs: bool = True):
+                 own_pairs: bool = True, run_words: bool = False):
         """`own_pairs=False` (a plan with chunk records that glove_plan_build_sorted refills from a dealt epoch): no pair
         arrays of its own — the records carry partner / w / y, the step functions read nothing else."""
         self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
@@ -551,11 +553,20 @@ class Plan:
         self.r_uniq_rec, self.c_uniq_rec = (torch.zeros(4 * max(self.cap_uniq, 1), **i32) for _ in range(2))
         # bitmaps of the batch's ids (glove_plan.r_mark / c_mark): small batches carry them — the one-launch Adam step's sweep
         # over all rows leaves the batch's rows alone by them
+        # per-chunk run words (glove_plan.r_chunk_hw): the fused step forms on a plan that keeps pair arrays instead of records
+        self.r_chunk_hw = self.c_chunk_hw = None
+        if run_words:
+            self.r_chunk_hw, self.c_chunk_hw = (torch.zeros(max(self.cap_chunks, 1), **i32) for _ in range(2))
         self.r_mark = self.c_mark = None
         if 0 < self.B <= TAGGED_STEP_MAX_BATCH:
             self.r_mark = torch.zeros(((max(self.V_row, 0) or self.V) + 31) // 32, **i32)
             self.c_mark = torch.zeros((self.V + 31) // 32, **i32)
         self._struct = None
+
+    @property
+    def fusable(self) -> bool:
+        """The plan carries what the fused step forms read the id layout from: chunk records, or run words beside pair arrays."""
+        return self.r_crec is not None or (getattr(self, "r_chunk_hw", None) is not None and self.r_partner is not None)
 
     @property
     def rec_dwords(self) -> int:
@@ -576,6 +587,7 @@ class Plan:
             s = GlovePlan()
             s.r_crec, s.c_crec = _ptr(self.r_crec), _ptr(self.c_crec)
             s.r_mark, s.c_mark = _ptr(getattr(self, "r_mark", None)), _ptr(getattr(self, "c_mark", None))
+            s.r_chunk_hw, s.c_chunk_hw = _ptr(getattr(self, "r_chunk_hw", None)), _ptr(getattr(self, "c_chunk_hw", None))
             s.B, s.chunk_cap, s.cap_chunks, s.cap_uniq = self.B, self.chunk_cap, self.cap_chunks, self.cap_uniq
             s.heavy_chunks, s.cap_heavy, s.V_row = self.heavy_chunks, self.cap_heavy, getattr(self, "V_row", 0)
             s.counts = _ptr(self.counts)
@@ -619,13 +631,24 @@ class Plan:
         out.c_uniq_rec = self.c_uniq_rec[:4 * max(out.cap_uniq, 1)].clone()
         out._struct = None
         out.r_mark, out.c_mark = self.r_mark, self.c_mark
+        out.r_chunk_hw = None if self.r_chunk_hw is None else self.r_chunk_hw[:max(out.cap_chunks, 1)].clone()
+        out.c_chunk_hw = None if self.c_chunk_hw is None else self.c_chunk_hw[:max(out.cap_chunks, 1)].clone()
         out.r_crec = out.c_crec = None
         # records pad every chunk to the cap: worth it for the latency they save unless the chunks are nearly
         # empty (V = 400 k, B = 1 M: 2.6 pairs per 16-slot chunk -> 7 % more traffic, measured slower)
         fused = d is not None and (nu_r + nu_c) * d * 16 >= FUSED_STEP_BYTES
         if records is None:
             # (small batches always: the tagged step of the latency-bound regime reads nothing but the records)
-            records = fused or out.B <= TAGGED_STEP_MAX_BATCH or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)
+            records = out.B <= TAGGED_STEP_MAX_BATCH or 4 * out.B >= out.chunk_cap * max(nc_r, nc_c)
+            # a fused step reads the id layout from the records or from the run words; with the words it takes the pair fields
+            # from the plan's arrays, a group's chunks at a time (V = 400 k, d = 300: 579 against 586 us per step; V = 2 M,
+            # d = 128: 509 against 525), and the plan costs 40 instead of 190 B per nonzero
+            # (that pays when a lane group owns many chunks — 12 at these sizes — so that the two trips up front are shared; at
+            # V = 50 k, d = 300, B = 131,072 a group owns 2 and the records win, 98 against 104 us)
+            if fused:
+                records = out.r_chunk_hw is None or max(nc_r, nc_c) < RUN_WORDS_MIN_CHUNKS
+        if not fused or records:
+            out.r_chunk_hw = out.c_chunk_hw = None
         if lib is not None and out.B > 0 and records:
             n = max(out.cap_chunks, 1) * out.rec_dwords
             out.r_crec = torch.empty(n, dtype=torch.int32, device=self.counts.device)
@@ -634,7 +657,7 @@ class Plan:
         return out
 
     def nbytes(self) -> int:
-        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts", "r_mark", "c_mark") if getattr(self, f, None) is not None)
+        n = sum(getattr(self, f).numel() * 4 for f in self.INT_FIELDS + ("r_w", "r_y", "c_w", "c_y", "counts", "r_mark", "c_mark", "r_chunk_hw", "c_chunk_hw") if getattr(self, f, None) is not None)
         return n + sum(t.numel() * 4 for t in (self.r_crec, self.c_crec) if t is not None)
 
 
@@ -749,7 +772,7 @@ def _step_struct(tables, plans, hyper):
     for plan in plans:
         hc = plan.host_counts
         ids = hc[1] + hc[3] if hc[1] >= 0 and hc[3] >= 0 else min(tables.V_row + tables.V, 2 * plan.B)
-        fused = plan.r_crec is not None and ids * tables.d * 16 >= FUSED_STEP_BYTES
+        fused = plan.fusable and ids * tables.d * 16 >= FUSED_STEP_BYTES
         if form == STEP_FUSED_TWIN or (form == STEP_AUTO and fused):
             tables._twin_dirty = True
             break
@@ -781,9 +804,10 @@ class GloveHip:
     # ---- index build
     def build_plan(self, row, col, w, y, V: int, chunk_cap: int | None = DEFAULT_CHUNK_CAP, compact=False,
                    into: Plan | None = None, ws: torch.Tensor | None = None, d: int | None = None,
-                   V_row: int = 0, records: bool | None = None, links: bool = True) -> Plan:
+                   V_row: int = 0, records: bool | None = None, links: bool = True, run_words: bool | None = None) -> Plan:
         """Builds the dedup index of one batch on the device.  `V_row`: rows of this rank's row-table shard when the
-        row ids are shard-local (ids outside it count as id 0, like col ids outside [0, V)).  `into`: a full-capacity Plan of the same
+        row ids are shard-local (ids outside it count as id 0, like col ids outside [0, V)).  `run_words`: the per-chunk run words a
+        fused step needs of a plan without records (default: when `d` says the batch can reach the fused regime).  `into`: a full-capacity Plan of the same
         (B, V, chunk_cap) to refill — a caller that indexes a fresh batch every step avoids ~20 tensor
         allocations per step this way.  `ws`: scratch of glove_plan_workspace_bytes(B, V) bytes (default: one
         shared buffer, fine for builds issued on one stream).  `records`: see Plan (default: small batches only)."""
@@ -797,7 +821,9 @@ class GloveHip:
                 raise ValueError("`into` must be an uncompacted plan of the same batch size, vocabulary and chunk cap")
             plan = into
         else:
-            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row, records=records, links=links)
+            if run_words is None:
+                run_words = d is not None and min((V_row or V) + V, 2 * B) * ((d + 3) // 4 * 4) * 16 >= FUSED_STEP_BYTES
+            plan = Plan(B, V, chunk_cap, row.device, V_row=V_row, records=records, links=links, run_words=bool(run_words))
         if ws is None:      # builds that run concurrently on different streams each bring their own scratch
             ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V))
         _check(self.lib.glove_plan_build(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, V, C.byref(plan.struct()),
@@ -852,13 +878,14 @@ class GloveHip:
                                          C.byref(row_side.struct()), C.byref(col_side.struct()), _ptr(ws), ws.numel(), _stream()),
                "glove_epoch_deal")
 
-    def staging_plan(self, B: int, V: int, chunk_cap: int, device, V_row: int = 0, records: bool = True) -> Plan:
+    def staging_plan(self, B: int, V: int, chunk_cap: int, device, V_row: int = 0, records: bool = True, run_words: bool = False) -> Plan:
         """A plan for glove_plan_build_sorted to refill: capacity for any batch of B pairs (an id of p pairs has at most
-        p / chunk_cap + 1 chunks), chunk records carrying the pair fields, or pair arrays of its own without records."""
+        p / chunk_cap + 1 chunks), chunk records carrying the pair fields, or pair arrays of its own without records
+        (`run_words`: with the per-chunk run words the fused step forms need in that case)."""
         cap_uniq = min(B, max(V, V_row or 0))
         cap_chunks = int(self.lib.glove_plan_chunk_bound(B, cap_uniq, chunk_cap))
         return Plan(B, V, chunk_cap, device, cap_chunks=cap_chunks, cap_uniq=cap_uniq, V_row=V_row, records=bool(records),
-                    links=False, own_pairs=not records)
+                    links=False, own_pairs=not records, run_words=run_words and not records)
 
     def build_plans_sorted(self, row_side: Pairs, col_side: Pairs, first_batch: int, block: PlanBlock, n: int,
                            V: int, ws: torch.Tensor) -> None:

@@ -33,10 +33,12 @@ class HipBackend:
         self.device = torch.device(device)
         self.row_floats = None      # floats per table row, once the tables exist: lets resident plans carry what the fused step needs
         self.shard_rows = 0         # rows of this rank's row-table shard when the row ids handed in are shard-local (else 0)
+        self.exchange = False       # the plans feed a multi-rank step: its packing passes read chunk records, not run words
 
     def build_plan(self, row, col, w, y, V, chunk_cap):
         return self.hip.build_plan(row.contiguous(), col.contiguous(), w.contiguous(), y.contiguous(), V,
-                                   chunk_cap=chunk_cap, compact=True, d=self.row_floats, V_row=self.shard_rows)
+                                   chunk_cap=chunk_cap, compact=True, d=self.row_floats, V_row=self.shard_rows,
+                                   run_words=False if self.exchange else None)
 
     def make_hyper(self, **kw):
         from trainer.hip_api import make_hyper
@@ -313,6 +315,8 @@ class Stepper(GraphedSteps):
         """collectives: go through the transport even with one rank (tests: RCCL is really called on a one-GPU box)."""
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
         self._multi = self.world > 1 or bool(collectives)
+        if self._multi and hasattr(backend, "exchange"):
+            backend.exchange = True         # plans built from here on keep chunk records (the packing passes read them)
         if self._multi and dist is None:
             raise ValueError("world > 1 needs an initialised torch.distributed module")
         if exchange not in ("auto", "dense", "rows"):
@@ -454,6 +458,8 @@ class RowShardedStepper(GraphedSteps):
             raise ValueError("exchange must be auto, dense or rows")
         self.backend, self.tables, self.world, self.dist = backend, tables, int(world), dist
         self._multi = self.world > 1 or bool(collectives)      # collectives: the transport even with one rank (tests)
+        if self._multi and hasattr(backend, "exchange"):
+            backend.exchange = True         # plans built from here on keep chunk records (the packing passes read them)
         gb = batch_size * self.world
         self.hyper = backend.make_hyper(batch_size=gb, **hyper_kwargs)
         self.hyper_rows = backend.make_hyper(batch_size=gb, sides=1, **hyper_kwargs)
@@ -557,7 +563,11 @@ class ShardedStepper(GraphedSteps):
             raise ValueError("the sharded step is implemented for Adagrad (Keras Adam has no sparse form)")
         self.backend, self.tables, self.world, self.rank, self.dist = backend, tables, int(world), int(rank), dist
         self._multi = self.world > 1 or bool(collectives)      # collectives: the transport even with one rank (tests)
+        if self._multi and hasattr(backend, "exchange"):
+            backend.exchange = True         # plans built from here on keep chunk records (the packing passes read them)
         self.local_only = self.world == 1 and not exercise_exchange
+        if hasattr(backend, "exchange"):
+            backend.exchange = not self.local_only      # (alone in the world the step is the plain one: run words will do)
         if self.local_only and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()
         gb = batch_size * self.world
@@ -764,15 +774,21 @@ class ReshufflingRunner:
         records = fused or B <= RECORDS_AT_BUILD_MAX or 4 * B >= self.cap * max(counts[0], counts[2], 1)
         if fused and form == 0 and hasattr(tables, "maybe_enable_twin"):
             tables.maybe_enable_twin()      # as Stepper does: the fused step writes new rows beside the old ones
+        # a fused step on a batch indexed every step: no records at all — their 128-byte lines would be written once and read
+        # once — but the pair fields as they were dealt (12 B per pair) + a run word per chunk (glove_plan.r_chunk_hw)
+        self.run_words = bool(fused) and form != 2
+        if self.run_words:
+            records = False
         self.records = records
         if single and records and tables.optimizer in ("Adagrad", "Adam") and form in (0, 5) and hasattr(tables, "maybe_enable_tags"):
             tables.maybe_enable_tags(B)     # small batches on small tables: the tagged step (one launch for all the row work)
         stream.main_reads_epochs = False        # from here on only the side stream's builds read the epoch buffers
-        first = hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records)
+        staging = lambda: hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records, run_words=self.run_words)
+        first = staging()
         per_plan = max(first.nbytes(), 1)
         self.S = int(segment) if segment else max(1, min(64, self.nb, int(slot_bytes) // per_plan))
         self.S = max(1, min(self.S, self.nb))
-        plans = [first] + [hip.staging_plan(B, V, self.cap, dev, V_row=shard_rows, records=records) for _ in range(2 * self.S - 1)]
+        plans = [first] + [staging() for _ in range(2 * self.S - 1)]
         self.slots = [PlanBlock(plans[:self.S]), PlanBlock(plans[self.S:])]
         self.sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, self.S), 256), dtype=torch.uint8, device=dev)
         self.step_ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, first.cap_chunks, tables.d), dtype=torch.uint8, device=dev)

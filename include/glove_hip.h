@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 11   /* 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax, later Adadelta and Ftrl by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 12   /* 12: glove_plan.r_chunk_hw / c_chunk_hw (the fused step forms on plans without records); 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax, later Adadelta and Ftrl by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -233,6 +233,12 @@ typedef struct glove_plan {
      * sparse path decays every row of the table every step, a11) leaves the batch's rows to the lane groups that apply them. */
     uint32_t *r_mark;
     uint32_t *c_mark;
+    /* Optional per-chunk run words (NULL = not computed; [cap_chunks] each): (first chunk of its id) << 31 | chunks of the
+     * same id behind this one — word 3 of the chunk's record header on its own.  With them the fused step forms run on a plan
+     * WITHOUT records (its pair fields in r_partner / r_w / r_y ..., 12 B per pair, instead of a 128-byte line per chunk): the
+     * form for batches indexed every step, whose records would be written once and read once.  Written by every builder. */
+    uint32_t *r_chunk_hw;
+    uint32_t *c_chunk_hw;
 } glove_plan;
 
 int glove_abi_version(void);

@@ -98,7 +98,7 @@ PLAN_ARRAYS = ("r_partner", "r_w", "r_y", "r_to_c", "r_chunk_id", "r_chunk_start
 def _poison(plan, ws):
     """0xFF into every array of a plan and into the build workspace: -1 as an id or position, NaN as a float — whatever a
     build leaves unwritten, or expects zeroed from allocation time, shows."""
-    for n in PLAN_ARRAYS + ("r_crec", "c_crec", "r_mark", "c_mark"):
+    for n in PLAN_ARRAYS + ("r_crec", "c_crec", "r_mark", "c_mark", "r_chunk_hw", "c_chunk_hw"):
         t = getattr(plan, n)
         if t is not None:
             t.view(torch.uint8).fill_(0xFF)
@@ -127,6 +127,15 @@ def _assert_plan_equals_oracle(plan, want, B, w, y):
     if plan.r_w is not None:                                    # (a plan of a dealt epoch may keep its pair fields in its records only)
         np.testing.assert_array_equal(plan.r_w.cpu().numpy()[:B], w[want["perm_r"]])
         np.testing.assert_array_equal(plan.c_y.cpu().numpy()[:B], y[want["perm_r"]][want["c_perm"]])
+    for side, nc in (("r", nc_r), ("c", nc_c)):                 # the run words (glove_plan.r_chunk_hw): word 3 of a record header on its own
+        hw = getattr(plan, side + "_chunk_hw", None)
+        if hw is not None:
+            ids = np.asarray(want[side + "_chunk_id"])
+            first = np.r_[True, ids[1:] != ids[:-1]]
+            run_id = np.cumsum(first) - 1
+            run_end = np.r_[np.flatnonzero(first)[1:], nc] - 1
+            np.testing.assert_array_equal(hw.cpu().numpy()[:nc].view(np.uint32), (run_end[run_id] - np.arange(nc)).astype(np.uint32) | (first.astype(np.uint32) << 31),
+                                          err_msg=side + "_chunk_hw")
     if plan.r_crec is None:
         return
     # per-chunk records: every header, every pair slot, and the padding of the blocks a reader touches (weight 0, valid id)

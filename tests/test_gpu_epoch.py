@@ -90,7 +90,8 @@ def test_sorted_build_equals_the_oracle_index(hip, plan_checker, n, V, B, cap, r
     rs, cs = _epoch_buffers(m)
     hip.deal_epoch(m, B, KEY, rs, cs, hip.deal_workspace(n, B, "cuda:0"))
     nb = n // B
-    block = PlanBlock([hip.staging_plan(B, V, cap, "cuda:0", records=records) for _ in range(nb)])
+    block = PlanBlock([hip.staging_plan(B, V, cap, "cuda:0", records=records, run_words=not records) for _ in range(nb)])
+    assert (block.plans[0].r_chunk_hw is not None) == (not records)        # (arrays-only plans carry the run words the fused forms need)
     ws = torch.empty(hip.lib.glove_plan_sorted_workspace_bytes(B, nb), dtype=torch.uint8, device="cuda:0")
     errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     for first, count in ((0, nb), (nb // 2, nb - nb // 2)):          # the whole epoch, then a run from the middle into plans 0 ..
@@ -124,10 +125,18 @@ def test_sorted_build_equals_the_oracle_index(hip, plan_checker, n, V, B, cap, r
 
 
 @pytest.mark.parametrize("V,d,B,cap,records,form", [(300, 64, 1024, 16, True, 0), (10000, 64, 16384, 16, False, 0), (3000, 300, 8192, 32, True, 3),
-                                                     (3000, 128, 8192, 32, True, 4)])
+                                                     (3000, 128, 8192, 32, True, 4),
+                                                     # arrays + run words (the staging plans of big batches) against RECORDS on the other side:
+                                                     # the fused forms read the same pairs in the same order either way
+                                                     (3000, 300, 8192, 32, "words", 3), (3000, 128, 8192, 32, "words", 4), (500, 64, 8192, 16, "words", 3),
+                                                     (2000, 16, 4096, 4, "words", 2), (40, 1024, 3000, 7, "words", 4), (60000, 32, 65536, 2, "words", 3)])
 def test_steps_on_dealt_batches_equal_steps_on_sorted_batches(hip, V, d, B, cap, records, form):
     """Training on the staging plans of a dealt epoch == training on plans glove_plan_build makes of the same batches in
-    the same (row-major) arrival order, bit for bit, over a few steps — records only (no pair arrays) and arrays only."""
+    the same (row-major) arrival order, bit for bit, over a few steps — records only (no pair arrays), arrays only, and
+    arrays + run words (a fused step without records: the descriptors and pair fields of a lane group's chunks staged in
+    LDS, ranges too long for the stage read chunk by chunk) against plans WITH records."""
+    words = records == "words"
+    records = False if words else records
     from trainer.hip_api import DeviceTables, PlanBlock, make_hyper
     n = 5 * B + 77
     row, col, w, y = _stream(V + d, n, V)
@@ -135,9 +144,10 @@ def test_steps_on_dealt_batches_equal_steps_on_sorted_batches(hip, V, d, B, cap,
     rs, cs = _epoch_buffers(m)
     hip.deal_epoch(m, B, KEY, rs, cs, hip.deal_workspace(n, B, "cuda:0"))
     nb = n // B
-    block = PlanBlock([hip.staging_plan(B, V, cap, "cuda:0", records=records) for _ in range(nb)])
+    block = PlanBlock([hip.staging_plan(B, V, cap, "cuda:0", records=records, run_words=words) for _ in range(nb)])
     ws = torch.empty(hip.lib.glove_plan_sorted_workspace_bytes(B, nb), dtype=torch.uint8, device="cuda:0")
     hip.build_plans_sorted(rs, cs, 0, block, nb, V, ws)
+    assert block.plans[0].fusable == (records or words)
     a, b = DeviceTables(V, d, "Adagrad", seed=3), DeviceTables(V, d, "Adagrad", seed=3)
     if form == 4:
         a.enable_twin(); b.enable_twin()
@@ -145,7 +155,9 @@ def test_steps_on_dealt_batches_equal_steps_on_sorted_batches(hip, V, d, B, cap,
     la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
     for k in range(nb):
         hip.step_adagrad(block.plans[k], a, h, la)
-        other = hip.build_plan(*(t.contiguous() for t in rs.arrays(k * B, (k + 1) * B)), V, chunk_cap=cap, records=records or None, links=False)
+        other = hip.build_plan(*(t.contiguous() for t in rs.arrays(k * B, (k + 1) * B)), V, chunk_cap=cap, records=True if words else (records or None),
+                               links=False, run_words=False)
+        assert (other.r_crec is not None) == bool(words or records) and other.r_chunk_hw is None
         hip.step_adagrad(other, b, h, lb)
         assert torch.equal(la, lb), (k, la.tolist(), lb.tolist())
     for name in ("R", "C", "br", "bc"):

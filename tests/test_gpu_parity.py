@@ -153,7 +153,7 @@ def test_consecutive_builds_into_a_poisoned_staging_plan(hip, plan_checker, B, V
     allocation only, leftovers of the previous batch).  Bit-exact against the oracle both times, and the device-side
     range check (every partner / perm / record slot a step kernel may read) finds nothing."""
     from trainer.hip_api import Plan
-    staging = Plan(B, V, cap, "cuda:0", records=True)   # records filled by the build as well (small batches; big batches on big tables)
+    staging = Plan(B, V, cap, "cuda:0", records=True, run_words=True)   # records filled by the build as well (small batches; big batches on big tables); run words beside them
     ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V), dtype=torch.uint8, device="cuda:0")
     errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     for k in range(2):
@@ -1462,6 +1462,20 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
                     assert torch.equal(getattr(c, n), getattr(a, n)), (form, n)
             assert int(c.R_ver.sum()) == 0                     # reading R brought the table home
             del c
+    # (1d) the same batch as a resident plan of the fused regime keeps it: run words + pair arrays instead of records (the
+    # trainer's plans at these sizes, static and dealt): the fused forms read the same pairs in the same order, bit for bit
+    plan_w = hip.build_plan(row, col, w, y, V, chunk_cap=plan.chunk_cap, compact=True, d=a.d, run_words=True)
+    if plan.r_crec is not None and plan_w.r_chunk_hw is not None:
+        assert plan_w.r_crec is None and plan_w.fusable
+        for form in (3, 4):
+            c = DeviceTables(V, d, "Adagrad", seed=5)
+            if form == 4:
+                c.enable_twin()
+            hip.step_adagrad(plan_w, c, make_hyper(learning_rate=lr, batch_size=B, step_form=form))
+            for n in ("R", "C", "br", "bc"):
+                assert torch.equal(getattr(c, n), prev[n]), ("run words", form, n)
+            del c
+    del plan_w
     touched = torch.zeros(V, dtype=torch.bool, device="cuda:0")
     touched[row.long()] = True
     assert torch.equal(a.R[~touched], R0[~touched])                               # (2)

@@ -560,7 +560,8 @@ def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, graphs):
         if mode == "runner":
             tables.enable_twin()      # (the policy twins row tables of 128 MB and more; this one has 73 MB: asked for here)
             runner = ReshufflingRunner(hip, stream, tables, hyper, burst=4, graphs=graphs, segment=2)
-            assert tables.R_ver is not None and runner.slots[0].plans[0].r_crec is not None and runner.slots[0].plans[0].r_partner is None
+            p0 = runner.slots[0].plans[0]       # a fused step on batches indexed every step: run words + the pair fields as dealt, no records
+            assert tables.R_ver is not None and p0.r_crec is None and p0.r_chunk_hw is not None and p0.r_partner is not None and p0.fusable
             done = 0
             while done < steps:
                 done += runner.run(steps - done)

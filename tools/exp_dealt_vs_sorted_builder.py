@@ -25,15 +25,15 @@ stream.reshuffle_in_place()
 torch.cuda.synchronize()
 rs, cs = stream.epoch_sides()
 kinds = {}
-for records in (True, False):
-    blk = PlanBlock([hip.staging_plan(B, V, cap, dev, records=records) for _ in range(nb)])
+for records, words in ((True, False), (False, False), (False, True)):
+    blk = PlanBlock([hip.staging_plan(B, V, cap, dev, records=records, run_words=words) for _ in range(nb)])
     ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, nb), 256), dtype=torch.uint8, device=dev)
     hip.build_plans_sorted(rs, cs, 0, blk, nb, V, ws)
     blk.fetch_counts()
     torch.cuda.synchronize()
     blk.adopt_counts(nb)
-    kinds["build_sorted, %s" % ("records only" if records else "own pair arrays, no records")] = blk.plans
-    kinds["_keep%d" % records] = [blk, ws]
+    kinds["build_sorted, %s" % ("records only" if records else "own pair arrays + run words" if words else "own pair arrays, no records")] = blk.plans
+    kinds["_keep%d%d" % (records, words)] = [blk, ws]
 batches = [tuple(t.contiguous() for t in stream.batch(b)) for b in range(nb)]
 kinds["sorting builder, compact"] = [hip.build_plan(*bt, V, chunk_cap=cap, compact=True, d=d) for bt in batches]
 kinds["sorting builder, staging + records"] = [hip.build_plan(*bt, V, chunk_cap=cap, records=True) for bt in batches]
