@@ -1178,7 +1178,9 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
         // a plan without chunk records keeps the pair fields itself (the step kernels read them): all six or none
         const bool own = p->r_partner || p->r_w || p->r_y || p->c_partner || p->c_w || p->c_y;
         if (own && (!p->r_partner || !p->r_w || !p->r_y || !p->c_partner || !p->c_w || !p->c_y)) return GLOVE_E_BADARG;
-        if (!own && !p->r_crec) return GLOVE_E_BADARG;
+        // neither records nor arrays: a plan with run words that BORROWS its pair fields — the batch lies sorted in the epoch's
+        // arrays already; the caller points r_partner .. c_y of the struct it steps with at them (nothing is copied)
+        if (!own && !p->r_crec && !p->r_chunk_hw) return GLOVE_E_BADARG;
         if (p->c_perm || p->r_to_c) return GLOVE_E_BADARG;              // the links between the orders are not computed here
         if ((p->r_mark == nullptr) != (p->c_mark == nullptr)) return GLOVE_E_BADARG;
         if ((p->r_chunk_hw == nullptr) != (p->c_chunk_hw == nullptr)) return GLOVE_E_BADARG;

@@ -519,7 +519,7 @@ class Plan:
 
     def __init__(self, B: int, V: int, chunk_cap: int, device, cap_chunks: int | None = None,
                  cap_uniq: int | None = None, V_row: int = 0, records: bool | None = None, links: bool = True,
-                 own_pairs: bool = True, run_words: bool = False):
+                 own_pairs: bool = True, run_words: bool = False, _no_pairs_ok: bool = False):
         """`own_pairs=False` (a plan with chunk records that glove_plan_build_sorted refills from a dealt epoch): no pair
         arrays of its own — the records carry partner / w / y, the step functions read nothing else."""
         self.B, self.V, self.chunk_cap, self.V_row = int(B), int(V), int(chunk_cap), int(V_row or 0)
@@ -539,7 +539,7 @@ class Plan:
         self.r_crec = self.c_crec = None
         if self.B > 0 and (self.B <= RECORDS_AT_BUILD_MAX if records is None else records):
             self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
-        if not own_pairs and self.r_crec is None:
+        if not own_pairs and self.r_crec is None and not _no_pairs_ok:
             raise ValueError("a plan without pair arrays of its own needs chunk records")
         self.r_partner, self.c_partner = (torch.empty(n, **i32), torch.empty(n, **i32)) if own_pairs else (None, None)
         # c_perm / r_to_c link the two sorted orders; no kernel reads them: `links=False` (the per-step plans of a
@@ -566,7 +566,8 @@ class Plan:
     @property
     def fusable(self) -> bool:
         """The plan carries what the fused step forms read the id layout from: chunk records, or run words beside pair arrays."""
-        return self.r_crec is not None or (getattr(self, "r_chunk_hw", None) is not None and self.r_partner is not None)
+        return self.r_crec is not None or (getattr(self, "r_chunk_hw", None) is not None and
+                                           (self.r_partner is not None or getattr(self, "borrows", False)))
 
     @property
     def rec_dwords(self) -> int:
@@ -878,14 +879,20 @@ class GloveHip:
                                          C.byref(row_side.struct()), C.byref(col_side.struct()), _ptr(ws), ws.numel(), _stream()),
                "glove_epoch_deal")
 
-    def staging_plan(self, B: int, V: int, chunk_cap: int, device, V_row: int = 0, records: bool = True, run_words: bool = False) -> Plan:
+    def staging_plan(self, B: int, V: int, chunk_cap: int, device, V_row: int = 0, records: bool = True, run_words: bool = False,
+                     borrow: bool = False) -> Plan:
         """A plan for glove_plan_build_sorted to refill: capacity for any batch of B pairs (an id of p pairs has at most
         p / chunk_cap + 1 chunks), chunk records carrying the pair fields, or pair arrays of its own without records
-        (`run_words`: with the per-chunk run words the fused step forms need in that case)."""
+        (`run_words`: with the per-chunk run words the fused step forms need in that case; `borrow`: no pair arrays either —
+        build_plans_sorted points the plan at the batch's positions in the epoch's arrays, which must outlive its steps)."""
         cap_uniq = min(B, max(V, V_row or 0))
         cap_chunks = int(self.lib.glove_plan_chunk_bound(B, cap_uniq, chunk_cap))
-        return Plan(B, V, chunk_cap, device, cap_chunks=cap_chunks, cap_uniq=cap_uniq, V_row=V_row, records=bool(records),
-                    links=False, own_pairs=not records, run_words=run_words and not records)
+        words = run_words and not records
+        plan = Plan(B, V, chunk_cap, device, cap_chunks=cap_chunks, cap_uniq=cap_uniq, V_row=V_row, records=bool(records),
+                    links=False, own_pairs=not records and not (borrow and words), run_words=words,
+                    _no_pairs_ok=bool(borrow and words))
+        plan.borrows = bool(borrow and words)
+        return plan
 
     def build_plans_sorted(self, row_side: Pairs, col_side: Pairs, first_batch: int, block: PlanBlock, n: int,
                            V: int, ws: torch.Tensor) -> None:
@@ -896,6 +903,14 @@ class GloveHip:
         _check(self.lib.glove_plan_build_sorted(C.byref(row_side.struct()), C.byref(col_side.struct()), first_batch * B, B, n, V,
                                                 block.host, _ptr(block.dev), _ptr(ws), ws.numel(), _stream()),
                "glove_plan_build_sorted")
+        if getattr(block.plans[0], "borrows", False):
+            # plans that borrow their pair fields: batch j lies sorted at positions [(first_batch + j) B, ...) of the epoch's arrays
+            base = [(t.data_ptr(), t) for t in (row_side.partner, row_side.w, row_side.y, col_side.partner, col_side.w, col_side.y)]
+            for j in range(n):
+                st, off = block.plans[j].struct(), 4 * (first_batch + j) * B
+                st.r_partner, st.r_w, st.r_y = (base[k][0] + off for k in range(3))
+                st.c_partner, st.c_w, st.c_y = (base[k][0] + off for k in range(3, 6))
+                block.plans[j].lent = (row_side, col_side)          # (keeps the epoch's arrays alive as long as the plan points at them)
 
     def shuffle_stream(self, src, dst, key: int) -> None:
         """dst = the four arrays of `src` (row, col, w, y) under the bijection of positions the 128-bit `key` determines."""

@@ -306,7 +306,10 @@ int glove_epoch_deal(const glove_pairs *row_major, const glove_pairs *col_major,
  * launch covers any number of batches and no plan travels in an argument block) indexes the batch at positions
  * [first_pair + j B, first_pair + (j + 1) B) of the two orders.  All plans have the same B, chunk_cap and kind.  A plan
  * with chunk records needs no pair arrays of its own (r_partner .. c_y all NULL: the records carry the pair fields, the
- * step functions read nothing else); a plan without records gets them copied.  c_perm / r_to_c must be NULL.  Capacities:
+ * step functions read nothing else); a plan without records gets them copied — or, when it has run words (r_chunk_hw) and
+ * no pair arrays either, BORROWS them: the batch lies sorted in the epoch's arrays, nothing is copied, and the caller points
+ * r_partner / r_w / r_y at row_side's partner / w / y + first_pair + j B (c_* at col_side's) in the struct it steps with;
+ * the epoch's arrays must then outlive the steps.  c_perm / r_to_c must be NULL.  Capacities:
  * cap_uniq >= min(B, V) and cap_chunks >= glove_plan_chunk_bound(B, cap_uniq, chunk_cap) — an id of p pairs has at most
  * p / chunk_cap + 1 chunks. */
 size_t glove_plan_sorted_workspace_bytes(int64_t B, int32_t n_batches);

@@ -533,8 +533,9 @@ def test_reshuffling_runner_equals_plain_dynamic_stepping(hip, optimizer, lr, B,
 
 @pytest.mark.parametrize("graphs", [False, True])
 def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, graphs):
-    """--epoch-shuffle full at a scale where the step is fused (V = 60 k, d = 300, B = 131,072: the staging plans carry chunk
-    records, the row table is twinned, the library judges a device-refilled plan by the most ids its batch can hold): equal,
+    """--epoch-shuffle full at a scale where the step is fused (V = 60 k, d = 300, B = 131,072: the staging plans carry run
+    words and take their pair fields from the epoch's arrays — borrowed when the steps are issued by C calls, copied when they are
+    replayed from graphs —, the row table is twinned): equal,
     within the fp32 tolerance of summing a heavy id's pairs in another order, to building and stepping batch after batch in
     two launches, across an epoch boundary; the twin form really ran."""
     from trainer import synthetic
@@ -561,7 +562,8 @@ def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, graphs):
             tables.enable_twin()      # (the policy twins row tables of 128 MB and more; this one has 73 MB: asked for here)
             runner = ReshufflingRunner(hip, stream, tables, hyper, burst=4, graphs=graphs, segment=2)
             p0 = runner.slots[0].plans[0]       # a fused step on batches indexed every step: run words + the pair fields as dealt, no records
-            assert tables.R_ver is not None and p0.r_crec is None and p0.r_chunk_hw is not None and p0.r_partner is not None and p0.fusable
+            assert tables.R_ver is not None and p0.r_crec is None and p0.r_chunk_hw is not None and p0.fusable
+            assert p0.borrows == (not graphs) and (p0.r_partner is None) == p0.borrows      # (a captured step cannot follow the epochs' arrays)
             done = 0
             while done < steps:
                 done += runner.run(steps - done)
