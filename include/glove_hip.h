@@ -106,6 +106,10 @@ typedef struct glove_hyper {
      *   GLOVE_STEP_FUSED_TWIN          the three-launch form on a twinned row table (glove_tables.R_ver): the row side
      *                                  writes its new rows into the other copy, the apply launch only flips versions
      *                                  (AUTO picks it whenever R_ver is set and the fused form pays)
+     *                                  The fused forms read the id layout from the plan's chunk records — or, on a plan without
+     *                                  records, from its run words (glove_plan.r_chunk_hw) beside the pair arrays: a lane group
+     *                                  then stages the descriptors and pair fields of all its chunks in LDS in two trips up
+     *                                  front (same pairs, same order: bit-identical).  A plan with neither takes two launches.
      *   GLOVE_STEP_TAGGED              for the latency-bound regime (the reference's default batch of 1,024 pairs: the two-launch
      *                                  form is two ramps, a boundary and four dependent memory round trips, nothing in them is
      *                                  bandwidth): on step-tagged twinned tables (glove_tables.R_tag) ONE launch forms the
@@ -440,7 +444,7 @@ int glove_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const 
 int glove_rowside_step_adagrad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                                    void *ws, size_t ws_bytes, void *stream);
 /* GLOVE_STEP_AUTO takes a fused form when (distinct row ids + distinct col ids of the plan) x d x 16 B — the rows a
- * step reads and writes — reaches this many bytes (and the plan carries chunk records); callers that keep a twinned
+ * step reads and writes — reaches this many bytes (and the plan carries chunk records or run words); callers that keep a twinned
  * table use the same number to know whether a step may have left versions flipped. */
 size_t glove_fused_step_bytes(void);
 /* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
