@@ -460,7 +460,10 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
         "config": {"workload": workload, "V": V, "d": d, "optimizer": optimizer,
                    "batch_size_per_gpu": B, "global_batch": B, "nnz_per_gpu": nnz, "batches_per_epoch": nb, "chunk_cap": cap,
                    "index": "rebuilt every step: epochs dealt from the sorted master orders (one partition pass per epoch), the "
-                            "index of %d consecutive batches numbered by 3 launches on a side stream, inside the timed region" % S,
+                            "index of %d consecutive batches numbered by %d launches on a side stream, inside the timed region%s" % (
+                                S, 3 if runner.records else 2,
+                                "" if runner.records else "; no chunk records: run words, pair fields %s the epoch's arrays" % (
+                                    "borrowed from" if getattr(runner, "borrow", False) else "copied from")),
                    "launch": "the trainer's runner: steps replayed from hipGraphs of 2^k steps" if runner.graphs_on else
                              "the trainer's runner: every run of steps issued by one C call (glove_steps_adagrad_f32)",
                    "parallelism": "single GPU", "chunk_records": bool(runner.records), "chunk_run_words": bool(getattr(runner, "run_words", False))},
