@@ -619,11 +619,21 @@ class ShardedStepper(GraphedSteps):
         if getattr(self, "_graphs", None) is not None:
             self._graphs, self._seen = {}, {}       # graphs of the old batches point at their plans
 
+    def drop_batches(self, handles):
+        """Forgets these prepared batches only (the handles of the others stay valid): an epoch that has been stepped through,
+        while the next one's batches — prepared beside its steps — stay."""
+        for h in handles:
+            self.batches[h] = None
+            if getattr(self, "_graphs", None):
+                self._graphs.pop(h, None)
+                self._seen.pop(h, None)
+
     def _ready(self):
         if not self._dirty:
             return
         self._dirty = False
-        cap, scap = max(b["n"] for b in self.batches), max(b["ns"] for b in self.batches)
+        live = [b for b in self.batches if b is not None]
+        cap, scap = max(b["n"] for b in live), max(b["ns"] for b in live)
         if self.bufs is None or cap > self._caps[0] or scap > self._caps[1]:
             self._caps = (cap, scap)
             if getattr(self, "_graphs", None) is not None:
@@ -739,6 +749,8 @@ class ReshufflingRunner:
         self.graphs, self.max_graphs = {}, int(max_graphs)
         self.position = 0                      # next batch of the current epoch
         self.handles = None                    # both tables sharded: the epoch's prepared batches
+        self._ahead = []                       # ... and those of the next epoch prepared so far (dealt streams)
+        self._prep = torch.cuda.Stream(device=tables.device) if tables.device.type == "cuda" else None
         # batches per epoch: the ranks' shards differ in length (by one pair data parallel, by the ownership of the rows
         # when routed), epochs end together: everybody steps through as many batches as the shortest shard has — the
         # pairs behind them wait for the next permutation, like the `nnz mod B` behind a rank's last full batch
@@ -871,9 +883,38 @@ class ReshufflingRunner:
         self._cursor = (epoch, seg + 1) if seg + 1 < self._segments_per_epoch() else (epoch + 1, 0)
 
     def _prepare_epoch(self):
-        """Both tables sharded: the fetch lists and indexes of all batches of the epoch (collective)."""
-        self.stepper.clear_batches()
-        self.handles = [self.stepper.add_batch(*(t.contiguous() for t in self.stream.batch(b)), self.cap) for b in range(self.nb)]
+        """Both tables sharded: the fetch lists and indexes of all batches of the epoch (collective).  On a dealt stream the
+        next epoch exists while this one trains: its batches are prepared one per step, on a stream of their own, beside the
+        steps (`_prepare_ahead`); what is still missing at the boundary is prepared here."""
+        if getattr(self.stream, "masters", None) is None:
+            self.stepper.clear_batches()
+            self.handles = [self.stepper.add_batch(*(t.contiguous() for t in self.stream.batch(b)), self.cap) for b in range(self.nb)]
+            return
+        old = self.handles or []
+        self.handles, self._ahead = self._ahead, []
+        while len(self.handles) < self.nb:              # (the first epoch; an epoch shorter than the steps that were run in it)
+            self._prepare_one(self.stream.epoch, self.handles)
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._prep)                    # the plans and fetch lists are complete before a step reads them
+        self.stepper.drop_batches(old)
+        # (their memory goes back to the prepare stream's pool: what that stream does from here on — it may reuse the blocks —
+        # waits for the steps of the old epoch that are still running)
+        self._prep.wait_stream(main)
+
+    def _prepare_one(self, epoch: int, into: list):
+        """Batch len(into) of `epoch`: its col ids' fetch lists agreed between the ranks and its index, issued on the prepare
+        stream (its host reads wait for that stream only: the steps on the compute stream keep running)."""
+        b = len(into)
+        rs, _ = self.stream.epoch_sides(epoch)
+        with torch.cuda.stream(self._prep):
+            if b == 0:
+                self._prep.wait_event(self.stream.dealt_event(epoch))
+            into.append(self.stepper.add_batch(*(t.contiguous() for t in rs.arrays(b * self.stream.B, (b + 1) * self.stream.B)), self.cap))
+
+    def _prepare_ahead(self):
+        """One batch of the NEXT epoch per step of this one (every rank the same sequence: the collectives inside line up)."""
+        if getattr(self.stream, "masters", None) is not None and len(self._ahead) < self.nb:
+            self._prepare_one(self.stream.epoch + 1, self._ahead)
 
     def _launch(self, slot: int, off: int, count: int):
         """Steps off .. off + count - 1 of a slot: replayed from the hipGraph of that run (captured the first time it is
@@ -928,6 +969,7 @@ class ReshufflingRunner:
             count = min(n_steps, nb - first, self.burst)
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
+                self._prepare_ahead()
         elif self.hip is None:                     # a test backend: one synchronous build per step
             count = min(n_steps, nb - first, self.burst)
             for b in range(first, first + count):

@@ -588,6 +588,47 @@ def test_reshuffling_runner_on_big_tables_takes_the_fused_step(hip, graphs):
         np.testing.assert_allclose(getattr(a, n_).cpu().numpy(), getattr(b, n_).cpu().numpy(), rtol=5e-5, atol=5e-6, err_msg=n_)
 
 
+def test_sharded_runner_prepares_the_next_epoch_beside_the_steps(hip):
+    """Reshuffled epochs with both tables sharded (one rank, the exchange exercised): the next epoch's batches — fetch lists,
+    indexes — are prepared one per step on a stream of their own while this epoch trains; across four epoch boundaries the
+    result is bit for bit what preparing every epoch at its boundary gives, and within tolerance what the plain runner gives."""
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ReshufflingRunner, ShardedStepper
+    V, d, B, nnz = 3000, 32, 2048, 2048 * 6 + 100
+    rng = np.random.default_rng(8)
+    data = {"row": rng.integers(0, V, nnz).astype(np.int32), "col": rng.integers(0, V, nnz).astype(np.int32),
+            "w": rng.uniform(0.1, 1, nnz).astype(np.float32), "y": rng.normal(0, 1, nnz).astype(np.float32)}
+    dev = torch.device("cuda:0")
+    out = []
+    for mode in ("ahead", "boundary", "plain"):
+        backend = HipBackend(dev)
+        backend.hip = hip
+        tables = DeviceTables(V, d, "Adagrad", device=dev, seed=2)
+        backend.row_floats = tables.d
+        stepper = None if mode == "plain" else ShardedStepper(backend, tables, dict(learning_rate=0.05), B, 1, 0, None, exercise_exchange=True)
+        stream = NonzeroStream(dict(data), B, V, backend, dev, seed=21, static_plans=False)
+        hyper = make_hyper(batch_size=B, learning_rate=0.05)
+        runner = ReshufflingRunner(hip, stream, tables, stepper.hyper if stepper else hyper, stepper=stepper, graphs=False, burst=4)
+        if mode == "boundary":
+            runner._prepare_ahead = lambda: None
+        steps, done = 6 * 4 + 3, 0
+        while done < steps:
+            done += runner.run(min(5, steps - done))
+            if mode == "ahead" and 0 < runner.position < runner.nb:
+                assert 0 < len(runner._ahead) <= runner.nb                  # batches of the next epoch are being prepared
+        torch.cuda.synchronize()
+        out.append((tables, runner.read_loss()["loss"]))
+        if stepper is not None:
+            assert sum(b is not None for b in stepper.batches) <= 2 * runner.nb      # finished epochs are dropped
+    (a, la), (b, lb), (c, lc) = out
+    assert a.global_step == b.global_step == c.global_step == 27 and la == lb
+    np.testing.assert_allclose(la, lc, rtol=1e-4)
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+        np.testing.assert_allclose(getattr(a, n).cpu().numpy(), getattr(c, n).cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+
+
 def test_cli_with_full_epoch_shuffle(hip, tmp_path):
     from trainer import estimator
     csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
