@@ -74,6 +74,9 @@ FLAGS = (
     Flag("row-sharded", None, False, "multi-GPU: shard the row table (and its slots) by row id % ranks and route every "
                                      "nonzero to the rank that owns its row, instead of replicating all tables "
                                      "(BASELINE config 5; Adagrad only)"),
+    Flag("shard-cols", None, False, "with --row-sharded: shard the col table as well (rows and cols on id % ranks; a step fetches "
+                                    "the col rows its batch touches from their owners and returns their gradients: two "
+                                    "all-to-alls whose size follows the batch, not the vocabulary); --epoch-shuffle full only"),
     Flag("step-form", int, 0, "form of the single-GPU sparse Adagrad step (glove_hyper.step_form): 0 the library chooses, "
                               "1 two launches, 2 / 3 fused forms, 4 fused on a twinned row table"),
     Flag("exchange", str, "auto", "multi-GPU gradient exchange: dense (all-reduce of the [V,d] gradient buffer), rows "

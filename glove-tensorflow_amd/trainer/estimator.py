@@ -72,15 +72,20 @@ class Estimator:
             for buf in (t.R, t.C, t.br, t.bc):
                 self.dist.broadcast(buf, src=0)
         self.row_sharded = bool(params.get("row_sharded")) and self.world > 1
+        # --shard-cols: the col table sharded by id % ranks as well (trainer.stepper.ShardedStepper)
+        self.both_sharded = self.row_sharded and bool(params.get("shard_cols"))
+        if params.get("shard_cols") and not params.get("row_sharded"):
+            raise ValueError("--shard-cols goes with --row-sharded")
         if self.row_sharded:
             if self.optimizer_name != "Adagrad":
                 raise ValueError("--row-sharded is implemented for Adagrad (Keras' Adam has no sparse form)")
-            # keep this rank's rows (u % world == rank) of the row side; the col side stays replicated
+            # keep this rank's rows (u % world == rank) of the row side; the col side stays replicated, or is cut the same way
             from trainer.hip_api import DeviceTables
             from trainer.stepper import owned_rows
             whole = self.model.tables
+            mine = owned_rows(whole.V, self.world, self.rank)
             shard = DeviceTables(whole.V, whole.d_model, whole.optimizer, device=self.device, seed=0,
-                                 V_row=owned_rows(whole.V, self.world, self.rank))
+                                 V_row=mine, V_col=mine if self.both_sharded else None)
             shard.load_whole_state_dict(whole.state_dict(), self.world, self.rank)
             self.model.tables = shard
             if hasattr(self.backend, "shard_rows"):
@@ -151,7 +156,12 @@ class Estimator:
         log_every = max(1, int(p.get("log_every", 100)))
         # a reshuffled stream has no resident plans: the exchange is agreed from the batch size (prepare(batch_size=...))
         plans_or_size = dict(batch_size=p["batch_size"]) if self.reshuffling else dict(plans=stream.plans)
-        if self.row_sharded:
+        if self.both_sharded:
+            if not self.reshuffling:
+                raise ValueError("--shard-cols runs with --epoch-shuffle full (a batch's fetch lists are prepared per epoch)")
+            from trainer.stepper import ShardedStepper
+            stepper = ShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.rank, self.dist)
+        elif self.row_sharded:
             from trainer.stepper import RowShardedStepper
             stepper = RowShardedStepper(self.backend, tables, hyper_kwargs, p["batch_size"], self.world, self.dist,
                                         exchange=p.get("exchange", "auto"))
@@ -337,6 +347,13 @@ class Estimator:
         RegressionHead metrics: average_loss = sum w l / sum w, loss = mean over batches of the
         batch-mean weighted loss, prediction/mean, label/mean."""
         tables, stream = self.model.tables, self.stream()
+        if self.both_sharded:
+            # the eval pass reads the col row of every pair: the whole col side is gathered for its duration (collective;
+            # V x d x 4 B per rank, every few minutes — the steps themselves never hold it)
+            from trainer.hip_api import TablesView
+            C_all = tables.gather_whole(tables.C, self.dist, self.world).contiguous()
+            bc_all = tables.gather_whole(tables.bc, self.dist, self.world).contiguous()
+            tables = TablesView(tables, tables.V, tables.V_row, keep=(C_all, bc_all), C=C_all, bc=bc_all)
         k = 6 if self.logistic else 4
         buf = torch.zeros(k + 1, dtype=torch.float64, device=self.device)       # the metric sums + this rank's nonzero count
         sums = buf[:k]
@@ -353,13 +370,13 @@ class Estimator:
         if self.logistic:
             # BinaryClassHead metrics of the two heads ("pos": label 1, "neg": label 0) and MultiHead's merged loss
             nf = self.params.get("neg_factor", 1.0)
-            rec = {"global_step": tables.global_step, "loss": (s[0] + nf * s[2]) / n,
+            rec = {"global_step": self.model.tables.global_step, "loss": (s[0] + nf * s[2]) / n,
                    "average_loss/pos": s[0] / max(s[1], 1e-300), "average_loss/neg": s[2] / max(s[3], 1e-300),
                    "prediction/mean/pos": s[4] / max(s[1], 1e-300), "prediction/mean/neg": s[5] / max(s[3], 1e-300),
                    "label/mean/pos": 1.0, "label/mean/neg": 0.0}
             rec["average_loss"] = rec["average_loss/pos"] + nf * rec["average_loss/neg"]
         else:
-            rec = {"global_step": tables.global_step, "average_loss": s[0] / s[1], "loss": s[0] / n,
+            rec = {"global_step": self.model.tables.global_step, "average_loss": s[0] / s[1], "loss": s[0] / n,
                    "prediction/mean": s[2] / s[1], "label/mean": s[3] / s[1]}
         self._log(os.path.join("eval", "eval_log.jsonl"), rec)
         logger.info("eval at global_step %d: average_loss = %.6f", rec["global_step"], rec["average_loss"])

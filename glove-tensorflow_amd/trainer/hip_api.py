@@ -447,24 +447,31 @@ class DeviceTables:
     # ---- row-sharded tables (BASELINE config 5): row u lives on rank u % world at local index u // world
     ROW_SIDE = ("R", "br")
 
-    def gathered_state_dict(self, dist, world: int) -> dict:
-        """state_dict() of the WHOLE model: the row-side shards of all ranks are all-gathered and interleaved
-        back into [V, ...] arrays, so the checkpoint has the same format as an unsharded run's (collective)."""
-        per = (self.V + world - 1) // world
+    COL_SIDE = ("C", "bc")
 
-        def whole(x):
-            pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            pad[:x.shape[0]] = x
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad)
-            return torch.stack(parts, 1).reshape((per * world,) + tuple(x.shape[1:]))[:self.V]
+    def _sharded_names(self):
+        return self.ROW_SIDE + (self.COL_SIDE if self.V_col < self.V else ())
+
+    def gather_whole(self, x, dist, world: int):
+        """A table sharded by id % world (this rank's shard `x`) as the whole [V, ...] array, on every rank (collective)."""
+        per = (self.V + world - 1) // world
+        pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        return torch.stack(parts, 1).reshape((per * world,) + tuple(x.shape[1:]))[:self.V]
+
+    def gathered_state_dict(self, dist, world: int) -> dict:
+        """state_dict() of the WHOLE model: the shards of all ranks (the row side; the col side too when it is sharded) are
+        all-gathered and interleaved back into [V, ...] arrays, so the checkpoint has the same format as an unsharded
+        run's (collective)."""
         out = self.state_dict()
         out["V_row"] = self.V
-        for n in self.ROW_SIDE:
-            out[n] = self._logical(whole(getattr(self, n)))
-            out["slot1_" + n] = self._logical(whole(self.s1[n]))
+        for n in self._sharded_names():
+            out[n] = self._logical(self.gather_whole(getattr(self, n), dist, world))
+            out["slot1_" + n] = self._logical(self.gather_whole(self.s1[n], dist, world))
             if n in self.s2:
-                out["slot2_" + n] = self._logical(whole(self.s2[n]))
+                out["slot2_" + n] = self._logical(self.gather_whole(self.s2[n], dist, world))
         return out
 
     def load_whole_state_dict(self, sd: dict, world: int, rank: int):
@@ -472,7 +479,7 @@ class DeviceTables:
         if sd.get("V_row", sd["V"]) != sd["V"]:
             raise ValueError("the checkpoint holds a row shard, not the whole model")
         mine = dict(sd, V_row=self.V_row)
-        for n in self.ROW_SIDE:
+        for n in self._sharded_names():
             for key in (n, "slot1_" + n, "slot2_" + n):
                 if key in sd:
                     mine[key] = sd[key][rank::world]

@@ -676,6 +676,50 @@ def test_two_rank_row_sharded_trainer_on_one_gpu(hip, tmp_path):
     assert (job / "model.ckpt-70.pt").exists()
 
 
+def test_two_rank_trainer_with_both_tables_sharded_on_one_gpu(hip, tmp_path):
+    """--row-sharded --shard-cols end to end with two ranks on the box's one GPU (gloo transport): rows AND cols live on
+    id % 2, a step fetches the col rows its batch touches and returns their gradients (the form `bench.py --gpus N` times at
+    configs 4 / 5), epochs reshuffled with the next epoch's batches prepared beside the steps; eval passes gather the col
+    side; the checkpoint holds the WHOLE model; same seed, same routing as --row-sharded alone: the same model within the
+    fp32 rounding of where the col gradients are summed."""
+    import torch.multiprocessing as mp
+    from trainer import estimator
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    V = len(vocab.read_text().split("\n"))
+    blobs = {}
+    for name, extra in (("both", ["--shard-cols"]), ("rows", [])):
+        out = tmp_path / name
+        out.mkdir()
+        job = out / "job"
+        argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+                "--embedding-size", "24", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "48",
+                "--train-steps", "90", "--log-every", "30", "--seed", "9", "--row-sharded"] + extra
+        mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(out)), nprocs=2, join=True)
+        a, b = (torch.load(out / ("rank%d.pt" % r)) for r in range(2))
+        assert a["R"].shape[0] + b["R"].shape[0] == V
+        if extra:
+            assert a["C"].shape[0] + b["C"].shape[0] == V and a["C"].shape[0] == (V + 1) // 2      # disjoint col shards too
+        else:
+            assert torch.equal(a["C"], b["C"])
+        assert a["g"] == b["g"] and a["step"] == b["step"] == 90
+        log = [json.loads(l) for l in (job / "train_log.jsonl").read_text().splitlines()]
+        assert [r["global_step"] for r in log] == [30, 60, 90]
+        ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+        assert ev[-1]["global_step"] == 90 and 0 < ev[-1]["average_loss"] < 10          # (the eval pass saw whole col rows)
+        blob = torch.load(job / "model.ckpt-90.pt", weights_only=False)["tables"]
+        assert blob["R"].shape == (V, 24) and blob["C"].shape == (V, 24) and blob["V_row"] == V
+        if extra:
+            assert torch.equal(blob["C"][0::2], a["C"]) and torch.equal(blob["C"][1::2], b["C"]) and torch.equal(blob["bc"][1::2], b["bc"])
+        blobs[name] = (blob, ev[-1]["average_loss"], job, argv)
+    for k in ("R", "C", "br", "bc", "slot1_R", "slot1_C"):
+        np.testing.assert_allclose(blobs["both"][0][k].numpy(), blobs["rows"][0][k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(blobs["both"][1], blobs["rows"][1], rtol=1e-4)
+    # a single process resumes from the whole-model checkpoint as an ordinary run
+    _, _, job, argv = blobs["both"]
+    estimator.main([x for x in argv if x not in ("--row-sharded", "--shard-cols")][:-6] + ["--train-steps", "100", "--log-every", "10", "--seed", "9"])
+    assert (job / "model.ckpt-100.pt").exists()
+
+
 def test_train_then_train_more_in_one_interpreter(hip, tmp_path):
     """A process that trains, keeps the first Estimator (stream, tables, staging plans) alive and trains on with a second one
     — a notebook, or train -> evaluate -> train: the second reshuffling runner captures and replays its hipGraphs beside
