@@ -111,9 +111,13 @@ class NonzeroStream:
     """
 
     def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
-                 chunk_cap=0, static_plans=True, route=None):
+                 chunk_cap=0, static_plans=True, route=None, cols_by_owner=0):
         """`static_plans=False`: no index is built here; the caller re-permutes the pairs every epoch
-        (`reshuffle_in_place`) and indexes each batch when it is used (--epoch-shuffle full)."""
+        (`reshuffle_in_place`) and indexes each batch when it is used (--epoch-shuffle full).
+        `cols_by_owner` = W > 0 (both tables sharded over W ranks): col ids are renumbered owner-major — id v becomes
+        (v % W) * ceil(V / W) + v // W — so that ascending col order IS the order in which a batch's col rows are fetched
+        from their owners (owner after owner, local index ascending): a dealt batch then arrives sorted for the sharded step
+        as well (`col_per` = ceil(V / W), `V_cols` = W * col_per: the range of the renumbered ids)."""
         self.B, self.V, self.backend, self.device = int(batch_size), int(V), backend, torch.device(device)
         self.chunk_cap = chunk_cap
         self.gen = torch.Generator(device="cpu")
@@ -150,6 +154,14 @@ class NonzeroStream:
                 "row-sharded stream: %d nonzeros on this rank, most / least over the ranks = %d / %d (%.2fx): "
                 "the nonzeros of the lighter ranks are revisited that much more often", self.row.numel(), most, least,
                 self.load_imbalance)
+        self.col_per, self.V_cols = 0, self.V
+        if cols_by_owner:
+            W = int(cols_by_owner)
+            self.col_per = (self.V + W - 1) // W
+            self.V_cols = W * self.col_per
+            c = self.col.long()
+            c = torch.where((c < 0) | (c >= self.V), torch.zeros_like(c), c)     # (an id outside the vocabulary is the unknown token, id 0)
+            self.col = ((c % W) * self.col_per + c // W).to(torch.int32)
         self.nnz = int(self.row.numel())
         if self.nnz < self.B:
             raise ValueError("batch size %d exceeds the %d nonzeros of this rank" % (self.B, self.nnz))
@@ -167,7 +179,7 @@ class NonzeroStream:
         hip = getattr(backend, "hip", None)
         if not static_plans and hip is not None and self.device.type == "cuda":
             self.masters = hip.build_masters(self.row.contiguous(), self.col.contiguous(), self.w.contiguous(), self.y.contiguous(),
-                                             self.V, getattr(backend, "shard_rows", 0) or 0)
+                                             self.V_cols, getattr(backend, "shard_rows", 0) or 0)
             self.row, self.col, self.w, self.y = self.masters.row_major.arrays()
             from trainer.hip_api import Pairs
             self._sets = [(Pairs(self.nnz, self.device), Pairs(self.nnz, self.device)) for _ in range(2)]

@@ -111,7 +111,8 @@ class Estimator:
                                          rank=self.rank, world=self.world, seed=self.params.get("seed"),
                                          chunk_cap=self.params.get("chunk_cap", 0),
                                          static_plans=not self.reshuffling,
-                                         route=self.dist if self.row_sharded else None)
+                                         route=self.dist if self.row_sharded else None,
+                                         cols_by_owner=self.world if self.both_sharded else 0)
         return self._stream
 
     def _log(self, name, record, histograms=None):
@@ -351,9 +352,10 @@ class Estimator:
             # the eval pass reads the col row of every pair: the whole col side is gathered for its duration (collective;
             # V x d x 4 B per rank, every few minutes — the steps themselves never hold it)
             from trainer.hip_api import TablesView
-            C_all = tables.gather_whole(tables.C, self.dist, self.world).contiguous()
-            bc_all = tables.gather_whole(tables.bc, self.dist, self.world).contiguous()
-            tables = TablesView(tables, tables.V, tables.V_row, keep=(C_all, bc_all), C=C_all, bc=bc_all)
+            # (rank after rank: the stream's col ids are numbered owner-major, NonzeroStream(cols_by_owner=))
+            C_all = tables.gather_by_owner(tables.C, self.dist, self.world).contiguous()
+            bc_all = tables.gather_by_owner(tables.bc, self.dist, self.world).contiguous()
+            tables = TablesView(tables, C_all.shape[0], tables.V_row, keep=(C_all, bc_all), C=C_all, bc=bc_all)
         k = 6 if self.logistic else 4
         buf = torch.zeros(k + 1, dtype=torch.float64, device=self.device)       # the metric sums + this rank's nonzero count
         sums = buf[:k]

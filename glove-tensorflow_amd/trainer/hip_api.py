@@ -461,6 +461,16 @@ class DeviceTables:
         dist.all_gather(parts, pad)
         return torch.stack(parts, 1).reshape((per * world,) + tuple(x.shape[1:]))[:self.V]
 
+    def gather_by_owner(self, x, dist, world: int):
+        """A table sharded by id % world as [world * ceil(V / world), ...]: rank after rank, each shard padded to the same
+        length — row (v % world) * per + v // world holds id v (the numbering of NonzeroStream(cols_by_owner=world))."""
+        per = (self.V + world - 1) // world
+        pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        return torch.cat(parts, 0)
+
     def gathered_state_dict(self, dist, world: int) -> dict:
         """state_dict() of the WHOLE model: the shards of all ranks (the row side; the col side too when it is sharded) are
         all-gathered and interleaved back into [V, ...] arrays, so the checkpoint has the same format as an unsharded
@@ -545,7 +555,9 @@ class Plan:
         # (`records=True`: a staging plan of a big batch on big tables, refilled every step and stepped in a fused form)
         self.r_crec = self.c_crec = None
         if self.B > 0 and (self.B <= RECORDS_AT_BUILD_MAX if records is None else records):
-            self.r_crec, self.c_crec = (torch.zeros(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
+            # (uninitialised: a build writes every record slot a step reads — the poisoned-plan tests — and a capacity-sized
+            # record array is hundreds of MB per side at B = 1 M: zero-filling it cost more than the build)
+            self.r_crec, self.c_crec = (torch.empty(self.cap_chunks * self.rec_dwords, **i32) for _ in range(2))
         if not own_pairs and self.r_crec is None and not _no_pairs_ok:
             raise ValueError("a plan without pair arrays of its own needs chunk records")
         self.r_partner, self.c_partner = (torch.empty(n, **i32), torch.empty(n, **i32)) if own_pairs else (None, None)

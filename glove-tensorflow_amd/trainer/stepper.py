@@ -566,6 +566,7 @@ class ShardedStepper(GraphedSteps):
         if self._multi and hasattr(backend, "exchange"):
             backend.exchange = True         # plans built from here on keep chunk records (the packing passes read them)
         self.local_only = self.world == 1 and not exercise_exchange
+        self.col_per = 0        # > 0: the col ids handed in are numbered owner-major, ceil(V / world) per owner (the runner sets it from its stream)
         if hasattr(backend, "exchange"):
             backend.exchange = not self.local_only      # (alone in the world the step is the plain one: run words will do)
         if self.local_only and hasattr(tables, "maybe_enable_twin"):
@@ -589,13 +590,14 @@ class ShardedStepper(GraphedSteps):
             self.batches.append(dict(plan=plan, want=[0], serve=[0], serve_idx=None, n=0, ns=0))
             return len(self.batches) - 1
         uc = torch.unique(col.long())                                  # ascending
-        owner = uc % W
+        per = getattr(self, "col_per", 0)                              # > 0: col ids numbered owner-major (NonzeroStream(cols_by_owner=))
+        owner = uc // per if per else uc % W
         order = torch.argsort(owner, stable=True)                      # (owner, id) order = fetch order
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
         compact = inv[torch.searchsorted(uc, col.long())].to(torch.int32)
         want = torch.bincount(owner, minlength=W)
-        req = (uc[order] // W).to(torch.int32).contiguous()
+        req = ((uc[order] % per) if per else (uc[order] // W)).to(torch.int32).contiguous()        # the owners' local indices
         serve = torch.empty_like(want)
         if self._multi:
             dist.all_to_all_single(serve, want)
@@ -611,6 +613,55 @@ class ShardedStepper(GraphedSteps):
         plan = self.backend.build_plan(row, compact, w, y, max(n_uc, self.tables.V_row), chunk_cap)
         self.batches.append(dict(plan=plan, want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l)))
         self._dirty = True                                               # capacities may have grown
+        return len(self.batches) - 1
+
+    def add_batch_dealt(self, row_side, col_side, first: int, B: int, chunk_cap: int) -> int:
+        """The batch at positions [first, first + B) of a dealt epoch whose col ids are numbered owner-major (`col_per`): it lies
+        sorted by local row id on the row side and by col id — i.e. in fetch order: owner after owner, local index ascending —
+        on the col side, so nothing is sorted here: the distinct col ids are the runs of the col side, a pair's compact col id is
+        the number of its run, and the index is numbered by glove_plan_build_sorted.  Collective; returns the batch's handle.
+        Same fetch lists and the same plan as add_batch gives for the batch in row-major arrival order."""
+        from trainer.hip_api import Pairs, PlanBlock
+        hip, W, dist, per = self.backend.hip, self.world, self.dist, self.col_per
+        sl = slice(first, first + B)
+        uc, run = torch.unique_consecutive(col_side.id[sl], return_inverse=True)       # (one host read: the number of runs)
+        n_uc = int(uc.numel())
+        if getattr(self, "_lut", None) is None:
+            self._lut = torch.zeros(W * per, dtype=torch.int32, device=uc.device)
+        self._lut[uc.long()] = torch.arange(n_uc, dtype=torch.int32, device=uc.device)
+        want = torch.bincount(uc.long() // per, minlength=W)
+        req = (uc % per).to(torch.int32).contiguous()
+        serve = torch.empty_like(want)
+        if self._multi:
+            dist.all_to_all_single(serve, want)
+        else:
+            serve.copy_(want)
+        # the index over compact col ids, while the counts travel
+        def side(src, ids, partner):
+            p = Pairs.__new__(Pairs)
+            p.n, p.id, p.partner, p.w, p.y, p._struct = B, ids.contiguous(), partner.contiguous(), src.w[sl], src.y[sl], None
+            return p
+        rs = side(row_side, row_side.id[sl], self._lut[row_side.partner[sl].long()])
+        cs = side(col_side, run.to(torch.int32), col_side.partner[sl])
+        V_plan = max(n_uc, self.tables.V_row)
+        from trainer.hip_api import auto_chunk_cap
+        cap = chunk_cap or auto_chunk_cap(B, V_plan, self.tables.d)
+        plan = hip.staging_plan(B, V_plan, cap, uc.device, V_row=self.tables.V_row, records=True)
+        block = PlanBlock([plan])
+        if getattr(self, "_sorted_ws", None) is None or self._sorted_ws_B != B:
+            self._sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, 1), 256), dtype=torch.uint8, device=uc.device)
+            self._sorted_ws_B = B
+        hip.build_plans_sorted(rs, cs, 0, block, 1, V_plan, self._sorted_ws)
+        block.fetch_counts()
+        want_l, serve_l = [int(x) for x in want.tolist()], [int(x) for x in serve.tolist()]        # (host reads: everything above has run)
+        block.adopt_counts(1)
+        serve_idx = torch.empty(sum(serve_l), dtype=torch.int32, device=req.device)
+        if self._multi:
+            dist.all_to_all_single(serve_idx, req, serve_l, want_l)
+        else:
+            serve_idx.copy_(req)
+        self.batches.append(dict(plan=plan, want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l), block=block))
+        self._dirty = True
         return len(self.batches) - 1
 
     def clear_batches(self):
@@ -761,6 +812,7 @@ class ReshufflingRunner:
             self.nb = int(t.item())
         stream.reshuffle_in_place()
         if self.sharded:
+            stepper.col_per = int(getattr(stream, "col_per", 0) or 0)
             self._prepare_epoch()
             return
         if hip is None:
@@ -905,11 +957,15 @@ class ReshufflingRunner:
         """Batch len(into) of `epoch`: its col ids' fetch lists agreed between the ranks and its index, issued on the prepare
         stream (its host reads wait for that stream only: the steps on the compute stream keep running)."""
         b = len(into)
-        rs, _ = self.stream.epoch_sides(epoch)
+        rs, cs = self.stream.epoch_sides(epoch)
         with torch.cuda.stream(self._prep):
             if b == 0:
                 self._prep.wait_event(self.stream.dealt_event(epoch))
-            into.append(self.stepper.add_batch(*(t.contiguous() for t in rs.arrays(b * self.stream.B, (b + 1) * self.stream.B)), self.cap))
+            B = self.stream.B
+            if self.stepper.col_per and not self.stepper.local_only:        # (col ids numbered owner-major: the batch arrives sorted for this form too)
+                into.append(self.stepper.add_batch_dealt(rs, cs, b * B, B, self.cap))
+            else:
+                into.append(self.stepper.add_batch(*(t.contiguous() for t in rs.arrays(b * B, (b + 1) * B)), self.cap))
 
     def _prepare_ahead(self):
         """One batch of the NEXT epoch per step of this one (every rank the same sequence: the collectives inside line up)."""
@@ -967,8 +1023,11 @@ class ReshufflingRunner:
         first = self.position
         if self.sharded:
             count = min(n_steps, nb - first, self.burst)
+            # the run's steps first, then as many batches of the next epoch: the prepare's host reads (its fetch lists' sizes)
+            # block this thread, and the compute stream should have the whole run queued by then
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
+            for _ in range(count):
                 self._prepare_ahead()
         elif self.hip is None:                     # a test backend: one synchronous build per step
             count = min(n_steps, nb - first, self.burst)

@@ -305,6 +305,19 @@ def test_cli_with_adam_in_one_launch_equals_the_two_launch_form(hip, tmp_path, s
         np.testing.assert_allclose(rec["item_embedding"], state["1"][token]["item_embedding"], rtol=2e-4, atol=2e-6)
 
 
+def _two_rank_trainer_sorting_prepare(rank, port, argv, out_dir):
+    """As _two_rank_trainer, but the sharded stepper prepares every batch the general way (torch.unique, owner order, the
+    sorting index builder) instead of reading it off the dealt order: the reference for add_batch_dealt with two owners."""
+    import sys
+    here = Path(__file__).resolve().parent
+    for p in (here.parent, here):
+        sys.path.insert(0, str(p))
+    from trainer.stepper import ShardedStepper
+    ShardedStepper.add_batch_dealt = lambda self, rs, cs, first, B, cap: self.add_batch(
+        *(t.contiguous() for t in rs.arrays(first, first + B)), cap)
+    _two_rank_trainer(rank, port, argv, out_dir)
+
+
 def _two_rank_trainer(rank, port, argv, out_dir):
     """One rank of `python -m trainer.estimator` under a launcher, both ranks on the box's one GPU: the HIP
     kernels are the product's, only the transport of the collectives is gloo instead of RCCL."""
@@ -601,13 +614,15 @@ def test_sharded_runner_prepares_the_next_epoch_beside_the_steps(hip):
             "w": rng.uniform(0.1, 1, nnz).astype(np.float32), "y": rng.normal(0, 1, nnz).astype(np.float32)}
     dev = torch.device("cuda:0")
     out = []
-    for mode in ("ahead", "boundary", "plain"):
+    for mode in ("ahead", "boundary", "plain", "dealt"):
         backend = HipBackend(dev)
         backend.hip = hip
         tables = DeviceTables(V, d, "Adagrad", device=dev, seed=2)
         backend.row_floats = tables.d
         stepper = None if mode == "plain" else ShardedStepper(backend, tables, dict(learning_rate=0.05), B, 1, 0, None, exercise_exchange=True)
-        stream = NonzeroStream(dict(data), B, V, backend, dev, seed=21, static_plans=False)
+        # "dealt": col ids numbered owner-major (the identity with one owner) — the batches' fetch lists and indexes then come
+        # straight from the dealt order (add_batch_dealt: no sort), the same lists and plans bit for bit
+        stream = NonzeroStream(dict(data), B, V, backend, dev, seed=21, static_plans=False, cols_by_owner=1 if mode == "dealt" else 0)
         hyper = make_hyper(batch_size=B, learning_rate=0.05)
         runner = ReshufflingRunner(hip, stream, tables, stepper.hyper if stepper else hyper, stepper=stepper, graphs=False, burst=4)
         if mode == "boundary":
@@ -615,14 +630,18 @@ def test_sharded_runner_prepares_the_next_epoch_beside_the_steps(hip):
         steps, done = 6 * 4 + 3, 0
         while done < steps:
             done += runner.run(min(5, steps - done))
-            if mode == "ahead" and 0 < runner.position < runner.nb:
+            if mode == "dealt":
+                assert stepper.col_per == V and "block" in stepper.batches[runner.handles[0]]     # the dealt path really prepared them
+            if mode in ("ahead", "dealt") and 0 < runner.position < runner.nb:
                 assert 0 < len(runner._ahead) <= runner.nb                  # batches of the next epoch are being prepared
         torch.cuda.synchronize()
         out.append((tables, runner.read_loss()["loss"]))
         if stepper is not None:
             assert sum(b is not None for b in stepper.batches) <= 2 * runner.nb      # finished epochs are dropped
-    (a, la), (b, lb), (c, lc) = out
-    assert a.global_step == b.global_step == c.global_step == 27 and la == lb
+    (a, la), (b, lb), (c, lc), (e, le) = out
+    assert a.global_step == b.global_step == c.global_step == e.global_step == 27 and la == lb == le
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(e, n)), ("dealt", n)
     np.testing.assert_allclose(la, lc, rtol=1e-4)
     for n in ("R", "C", "br", "bc"):
         assert torch.equal(getattr(a, n), getattr(b, n)), n
@@ -687,14 +706,15 @@ def test_two_rank_trainer_with_both_tables_sharded_on_one_gpu(hip, tmp_path):
     csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
     V = len(vocab.read_text().split("\n"))
     blobs = {}
-    for name, extra in (("both", ["--shard-cols"]), ("rows", [])):
+    for name, extra, entry in (("both", ["--shard-cols"], _two_rank_trainer), ("sorted", ["--shard-cols"], _two_rank_trainer_sorting_prepare),
+                               ("rows", [], _two_rank_trainer)):
         out = tmp_path / name
         out.mkdir()
         job = out / "job"
         argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
                 "--embedding-size", "24", "--optimizer", "Adagrad", "--learning-rate", "0.05", "--batch-size", "48",
                 "--train-steps", "90", "--log-every", "30", "--seed", "9", "--row-sharded"] + extra
-        mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(out)), nprocs=2, join=True)
+        mp.spawn(entry, args=(free_port(), argv, str(out)), nprocs=2, join=True)
         a, b = (torch.load(out / ("rank%d.pt" % r)) for r in range(2))
         assert a["R"].shape[0] + b["R"].shape[0] == V
         if extra:
@@ -711,11 +731,19 @@ def test_two_rank_trainer_with_both_tables_sharded_on_one_gpu(hip, tmp_path):
         if extra:
             assert torch.equal(blob["C"][0::2], a["C"]) and torch.equal(blob["C"][1::2], b["C"]) and torch.equal(blob["bc"][1::2], b["bc"])
         blobs[name] = (blob, ev[-1]["average_loss"], job, argv)
+    # the batches read off the dealt order (col ids numbered owner-major: fetch order = sorted order) give the fetch lists and
+    # indexes the general preparation gives: the same model bit for bit
     for k in ("R", "C", "br", "bc", "slot1_R", "slot1_C"):
-        np.testing.assert_allclose(blobs["both"][0][k].numpy(), blobs["rows"][0][k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
-    np.testing.assert_allclose(blobs["both"][1], blobs["rows"][1], rtol=1e-4)
+        assert torch.equal(blobs["both"][0][k], blobs["sorted"][0][k]), k
+    # (--row-sharded alone deals other batches — its masters are sorted by the plain col ids —: the same loss level, not the same model)
+    np.testing.assert_allclose(blobs["both"][1], blobs["rows"][1], rtol=0.05)
+    # one process, plain tables, the whole-model checkpoint: the eval pass gives the loss the two ranks computed over their routed
+    # pairs against the owner-major gathered col side (the renumbering is consistent with where the owners keep their rows)
+    _, loss2, job, argv = blobs["both"]
+    params = json.loads((job / "params.json").read_text())
+    params.update(row_sharded=False, shard_cols=False)
+    np.testing.assert_allclose(estimator.Estimator(params).evaluate()["average_loss"], loss2, rtol=1e-5)
     # a single process resumes from the whole-model checkpoint as an ordinary run
-    _, _, job, argv = blobs["both"]
     estimator.main([x for x in argv if x not in ("--row-sharded", "--shard-cols")][:-6] + ["--train-steps", "100", "--log-every", "10", "--seed", "9"])
     assert (job / "model.ckpt-100.pt").exists()
 

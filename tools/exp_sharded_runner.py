@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reshuffling runner over a fully sharded stepper with one rank and the exchange exercised (every collective issued, a
 process group of one): steps per second across epoch boundaries — what preparing an epoch's batches costs beside its steps.
-Usage: tools/exp_sharded_runner.py [workload] [B] [steps] [--at-the-boundary]"""
+Usage: tools/exp_sharded_runner.py [workload] [B] [steps] [--at-the-boundary] [--sorting-prepare]"""
 import os
 import sys
 import time
@@ -30,7 +30,10 @@ backend = HipBackend(dev)
 backend.hip = hip
 backend.row_floats = tables.d
 stepper = ShardedStepper(backend, tables, dict(learning_rate=0.05), B, 1, 0, dist, collectives=True, exercise_exchange=True)
-stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False)
+# (col ids numbered owner-major — the identity with one owner —: the batches' fetch lists and indexes come straight from the
+# dealt order; --sorting-prepare: the general preparation, torch.unique + the sorting index builder)
+stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False,
+                       cols_by_owner=0 if "--sorting-prepare" in sys.argv else 1)
 runner = ReshufflingRunner(hip, stream, tables, stepper.hyper, stepper=stepper, graphs=False)
 if "--at-the-boundary" in sys.argv:      # as before: the whole epoch prepared when it begins
     runner._prepare_ahead = lambda: None
