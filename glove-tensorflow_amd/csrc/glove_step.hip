@@ -276,10 +276,12 @@ __global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWav
     int stage_first = 0;
     bool staged = false;
     if (use_desc && j < j_end) {
-        if (lg <= j_end - j && lg < kDescSlots) desc[lg] = sd.chunk_start[j + lg];
-        if (lg < j_end - j && lg < kDescSlots) {
-            desc[kDescSlots + lg] = sd.chunk_id[j + lg];
-            desc[2 * kDescSlots + lg] = (int32_t)sd.chunk_hw[j + lg];
+        for (int x = lg; x <= j_end - j; x += LPR) {                 // (a group of 8 lanes owns up to 12 chunks: two rounds)
+            desc[x] = sd.chunk_start[j + x];
+            if (x < j_end - j) {
+                desc[kDescSlots + x] = sd.chunk_id[j + x];
+                desc[2 * kDescSlots + x] = (int32_t)sd.chunk_hw[j + x];
+            }
         }
         stage_first = desc[0];
         const int span = desc[j_end - j] - stage_first;

@@ -129,7 +129,9 @@ def test_sorted_build_equals_the_oracle_index(hip, plan_checker, n, V, B, cap, r
                                                      # arrays + run words (the staging plans of big batches) against RECORDS on the other side:
                                                      # the fused forms read the same pairs in the same order either way
                                                      (3000, 300, 8192, 32, "words", 3), (3000, 128, 8192, 32, "words", 4), (500, 64, 8192, 16, "words", 3),
-                                                     (2000, 16, 4096, 4, "words", 2), (40, 1024, 3000, 7, "words", 4), (60000, 32, 65536, 2, "words", 3)])
+                                                     (2000, 16, 4096, 4, "words", 2), (40, 1024, 3000, 7, "words", 4), (60000, 32, 65536, 2, "words", 3),
+                                                     # 12 chunks per lane group of 8 lanes (the descriptors of a group arrive in two rounds)
+                                                     (150000, 32, 300000, 2, "words", 3), (150000, 64, 300000, 2, "words", 4)])
 def test_steps_on_dealt_batches_equal_steps_on_sorted_batches(hip, V, d, B, cap, records, form):
     """Training on the staging plans of a dealt epoch == training on plans glove_plan_build makes of the same batches in
     the same (row-major) arrival order, bit for bit, over a few steps — records only (no pair arrays), arrays only, and
