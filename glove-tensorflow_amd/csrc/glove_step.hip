@@ -1267,6 +1267,8 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
 //     dependency between consecutive steps that needs all pairs, i.e. a grid-wide reduction: a kernel boundary is the
 //     cheapest one there is.
 // ------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct OneSide {
     const int32_t *crec;
     float *own, *own_bias;              // this side's table and bias vector, twinned
@@ -1305,7 +1307,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_step_kernel(
     // group's first record is requested before anything else (records exist up to the plan's capacity; one that lies behind
     // the side's last chunk is dropped unread)
     constexpr int kPre = (1 + 3 * kChunkMax / 4 + LPR - 1) / LPR;
-    uint4 pre[kPre];
+    u32x4 pre[kPre];       // (a native vector type: an array of the struct uint4 went through scratch at kPre = 4)
     {
         const int jf = bid * GPB + grp;
         const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)(jf < sd.cap_chunks ? jf : sd.cap_chunks - 1) * rec_stride_q(sd.capP);
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_step_kernel(
 #pragma unroll
         for (int x = 0; x < kPre; ++x) {
             const int f = lg + x * LPR;
-            pre[x] = rp[rec_gq(f < rq0 ? f : 0)];
+            pre[x] = reinterpret_cast<const u32x4 *>(rp)[rec_gq(f < rq0 ? f : 0)];
         }
     }
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
@@ -1355,7 +1357,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_step_kernel(
 #pragma unroll
                 for (int x = 0; x < kPre; ++x) {
                     const int f = lg + x * LPR;
-                    if (f < rq) lrec[f] = pre[x];
+                    if (f < rq) reinterpret_cast<u32x4 *>(lrec)[f] = pre[x];
                 }
             } else {
                 const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j0 * sq;
@@ -1678,7 +1680,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_adam_kernel(
     const int nblk = is_row ? row_blocks : chunk_blocks - row_blocks;
     // the group's first record is requested before anything else (as in tagged_step_kernel)
     constexpr int kPre = (1 + 3 * kChunkMax / 4 + LPR - 1) / LPR;
-    uint4 pre[kPre];
+    u32x4 pre[kPre];       // (a native vector type: an array of the struct uint4 went through scratch at kPre = 4)
     {
         const int jf = bid * GPB + grp;
         const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)(jf < sd.cap_chunks ? jf : sd.cap_chunks - 1) * rec_stride_q(sd.capP);
@@ -1686,7 +1688,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_adam_kernel(
 #pragma unroll
         for (int x = 0; x < kPre; ++x) {
             const int f = lg + x * LPR;
-            pre[x] = rp[rec_gq(f < rq0 ? f : 0)];
+            pre[x] = reinterpret_cast<const u32x4 *>(rp)[rec_gq(f < rq0 ? f : 0)];
         }
     }
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
@@ -1722,7 +1724,7 @@ __global__ __launch_bounds__(kBlock, NV <= 2 ? 2 : 1) void tagged_adam_kernel(
 #pragma unroll
                 for (int x = 0; x < kPre; ++x) {
                     const int f = lg + x * LPR;
-                    if (f < rq) lrec[f] = pre[x];
+                    if (f < rq) reinterpret_cast<u32x4 *>(lrec)[f] = pre[x];
                 }
             } else {
                 const uint4 *rp = reinterpret_cast<const uint4 *>(sd.crec) + (size_t)j0 * sq;
