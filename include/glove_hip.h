@@ -488,10 +488,19 @@ int glove_step_sparse_f32(const glove_plan *plan, const glove_tables *t, const g
 /* One Keras-legacy Adam step.  G_flat (glove_dense_grad_floats floats, all zero on entry) is scratch and is all zero
  * again on return.  A batch of at most (V_row + V) / 2 pairs takes two launches: the passes also mark the batch's
  * ids (in G_flat's bias segments), then one kernel applies the marked ids and gives every other row the G = 0
- * update; larger batches run passes + glove_dense_grad_f32 + glove_dense_adam_f32.  Same result bit for bit. */
+ * update; larger batches run passes + glove_dense_grad_f32 + glove_dense_adam_f32.  Same result bit for bit.
+ * ONE launch (glove_hyper.step_form AUTO or GLOVE_STEP_TAGGED) when both tables are twinned (glove_tables.R_tag / C_tag
+ * non-NULL: R, br hold 2 x V_row rows / entries, C, bc 2 x V; the tags themselves stay zero), the plan carries chunk records
+ * and id bitmaps (r_mark / c_mark) and the batch has at most 2,048 pairs and touches a minority of the rows: every row of
+ * both tables moves from the current copy to the other one — the batch's rows by the lane group that holds the id's first
+ * chunk (gradient, then Adam), all others by a sweep that skips the bitmaps' ids; scalars[3] says which copy is current
+ * (glove_canonicalize_f32 copies the second copies home; every other entry point calls it first).  Swept rows and ids of
+ * up to heavy_chunks chunks bit-identical to the two-launch form, the others within fp32 rounding of their sums' order. */
 int glove_step_adam_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
-/* n consecutive Keras-legacy Adam steps from one host call; G_flat is left zeroed after every step. */
+/* n consecutive Keras-legacy Adam steps from one host call; G_flat is left zeroed after every step.  Consecutive steps that
+ * take the one-launch form go out as a chain: one launch per step — the global bias and its moments handed on through records
+ * in the workspace — and one epilogue per chain (loss, scalars, global_step += n). */
 int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
                          const glove_hyper *h, void *ws, size_t ws_bytes, float *G_flat, float *loss_out,
                          void *stream);
