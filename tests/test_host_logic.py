@@ -181,6 +181,46 @@ def test_event_files_are_valid_tfrecords_of_event_protos(tmp_path):
     assert last[1] == 300 and last[2]["loss"] == np.float32(0.1) and last[2]["mf/col_biases"] == h
 
 
+def test_histogram_encoding_matches_the_bucket_by_bucket_walk():
+    """histogram_of (vectorised: searchsorted over TensorFlow's default bucket limits, empty runs merged with array masks)
+    against the plain walk of Histogram::EncodeToProto — a run of empty buckets becomes one entry with its last limit —
+    on random data of every scale, constants, a single value and the empty tensor; tensors and arrays alike."""
+    import bisect
+    import torch
+    from trainer.event_writer import default_bucket_limits, histogram_of
+    limits = default_bucket_limits()
+
+    def walk(values):
+        counts = [0] * len(limits)
+        for v in values:
+            counts[min(bisect.bisect_right(limits, float(v)), len(limits) - 1)] += 1
+        out_l, out_c, i = [], [], 0
+        while i < len(counts):
+            c, end = counts[i], limits[i]
+            i += 1
+            if c <= 0:
+                while i < len(counts) and counts[i] <= 0:
+                    end = limits[i]
+                    i += 1
+            out_l.append(end)
+            out_c.append(float(c))
+        return out_l, out_c
+    rng = np.random.default_rng(0)
+    cases = [rng.normal(0, s, 500).astype(np.float32) for s in (1e-9, 1e-3, 0.05, 1.0, 1e6)]
+    cases += [np.zeros(7, np.float32), np.array([3.25], np.float32), np.array([], np.float32),
+              np.array([-1e30, 1e30, 0.0, -0.0, 1e-13, -1e-13], np.float64), rng.uniform(-1, 1, 2000)]
+    for x in cases:
+        for values in (x, torch.from_numpy(np.ascontiguousarray(x))):
+            h = histogram_of(values)
+            want_l, want_c = walk(x)
+            assert h["bucket_limit"] == want_l and h["bucket"] == want_c
+            assert h["num"] == len(x) and sum(h["bucket"]) == len(x)
+            if len(x):
+                assert h["min"] == float(x.min()) and h["max"] == float(x.max())
+                np.testing.assert_allclose(h["sum"], float(x.astype(np.float64).sum()), rtol=1e-12, atol=1e-300)
+                np.testing.assert_allclose(h["sum_squares"], float((x.astype(np.float64) ** 2).sum()), rtol=1e-12)
+
+
 def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
     """`python bench.py --gpus N` without a launcher (how the driver calls it): bench.py starts N ranks as a child
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`, relays rank 0's one
