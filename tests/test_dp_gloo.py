@@ -254,6 +254,8 @@ def _reshuffle_worker(rank, port, out_dir, form):
                w=np.arange(RN, dtype=np.float32) + 1.0, y=rng.normal(size=RN).astype(np.float32))    # w = the pair's serial number
     full = ref.Tables(V, D, "Adagrad", dtype=np.float64, seed=3)
     shard = full.copy()
+    owner_major = form == "sharded_owner_major"     # col ids renumbered owner-major by the stream (NonzeroStream(cols_by_owner=))
+    form = "sharded" if owner_major else form
     sharded_names = {"dp_dense": (), "dp_rows": (), "rowsharded": ("R", "br", "A_R", "A_br"),
                      "sharded": ("R", "br", "A_R", "A_br", "C", "bc", "A_C", "A_bc")}[form]
     for n in sharded_names:
@@ -261,7 +263,12 @@ def _reshuffle_worker(rank, port, out_dir, form):
     tables = OracleTables(shard)
     backend = _Recorder(OracleBackend())
     stream = NonzeroStream(coo, RB, V, backend, "cpu", rank=rank, world=WORLD, seed=11, static_plans=False,
-                           route=dist if sharded_names else None)
+                           route=dist if sharded_names else None, cols_by_owner=WORLD if owner_major else 0)
+    if owner_major:
+        per = (V + WORLD - 1) // WORLD
+        assert stream.col_per == per and stream.V_cols == WORLD * per and int(stream.col.max()) < WORLD * per
+        back = (stream.col % per) * WORLD + stream.col // per           # the numbering is a bijection of the ids
+        assert int(back.max()) < V
     kw = dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05)
     if form == "sharded":
         stepper = ShardedStepper(backend, tables, kw, RB, WORLD, rank, dist)
@@ -327,16 +334,20 @@ def test_reshuffled_epochs_on_two_ranks_equal_one_rank_on_the_joint_stream(tmp_p
 def test_reshuffled_epochs_with_both_tables_sharded(tmp_path):
     """ShardedStepper under the reshuffling runner: the epoch's batches (fetch lists, renumbered col ids) are prepared
     collectively when the epoch starts.  The model after 24 steps over four epoch boundaries is finite, every rank made
-    the same number of steps, and re-running gives the same bits (the permutations are seeded)."""
+    the same number of steps, re-running gives the same bits (the permutations are seeded), and so does a stream whose col
+    ids are numbered owner-major."""
     port = free_port()
     outs = []
-    for attempt in range(2):
+    for attempt, form in enumerate(("sharded", "sharded", "sharded_owner_major")):
         d = tmp_path / ("run%d" % attempt)
         d.mkdir()
-        mp.spawn(_reshuffle_worker, args=(port + attempt, str(d), "sharded"), nprocs=WORLD, join=True)
+        mp.spawn(_reshuffle_worker, args=(port + attempt, str(d), form), nprocs=WORLD, join=True)
         outs.append([np.load(d / ("re%d.npz" % r)) for r in range(WORLD)])
     for r in range(WORLD):
         for n in ("R", "C", "br", "bc", "g"):
             assert np.isfinite(outs[0][r][n]).all()
             np.testing.assert_array_equal(outs[0][r][n], outs[1][r][n])
+            # col ids renumbered owner-major by the stream (the form the trainer's --shard-cols runs): the same owners, the same
+            # fetch order, the same compact ids — the same bits
+            np.testing.assert_array_equal(outs[0][r][n], outs[2][r][n])
         assert int(outs[0][r]["step"]) == RSTEPS
