@@ -152,23 +152,35 @@ def algorithmic_bytes(B, d, u_row, u_col):
     return 16 * B + 16 * (d + 1) * (u_row + u_col)
 
 
-def measured_traffic(workload, B, cap, fused, index="static"):
-    """HBM-side bytes per step from the committed PMC summary of this exact configuration
-    (profiles/*_traffic.json, produced by tools/pmc_traffic.py from separate `rocprofv3 --pmc`
-    passes of this bench); None when no summary matches.  `fused`: the step ran in a fused form — a summary counts
-    when its pass kernel is of the same kind (last template argument of `sidepass_kernel<...>`)."""
-    import glob
-    for f in sorted(glob.glob(str(REPO / "profiles" / "*_traffic.json")), reverse=True):
-        try:
-            j = json.load(open(f))
-            m = j.get("meta", {})
-            prof_fused = any(k.startswith("sidepass_kernel") and k.rstrip().endswith(("true>", ", 1>", ", 2>")) for k in j.get("kernels", {}))
-            if m.get("workload") == workload and int(m.get("batch", -1)) == B and int(m.get("chunk_cap", cap)) == cap \
-                    and prof_fused == bool(fused) and m.get("index", "static") == index:
-                return float(j["traffic_bytes_per_step"]), os.path.basename(f)
-        except (OSError, ValueError, KeyError):
-            continue
-    return None, None
+# (workload, batch, index mode) -> the committed PMC summary of exactly that bench command (tools/pmc_traffic.py:
+# separate `rocprofv3 --pmc` passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Looked up by key,
+# never by name matching; a configuration without a row reports traffic null and says so in `traffic_source`.
+TRAFFIC_PROFILES = {
+    ("zipf_v400k_d300", 1048576, "dealt"): "r04_c4_v400k_d300_b1m_index_rebuilt_traffic.json",
+    ("zipf_v400k_d300", 1048576, "static"): "r04_c4_v400k_d300_b1m_static_index_traffic.json",
+    ("zipf_v2m_d128", 1048576, "dealt"): "r04_c5_v2m_d128_b1m_index_rebuilt_traffic.json",
+    ("zipf_v2m_d128", 1048576, "static"): "r03_c5_v2m_d128_b1m_traffic.json",
+    ("text8_v50k_d300", 131072, "dealt"): "r04_c3_v50k_d300_b131072_index_rebuilt_traffic.json",
+    ("text8_v50k_d300", 131072, "static"): "r03_c3_v50k_d300_b131072_traffic.json",
+    ("text8_d64", 131072, "dealt"): "r04_text8_d64_b131072_index_rebuilt_traffic.json",
+    ("text8_d64", 131072, "static"): "r03_text8_d64_b131072_traffic.json",
+    ("text8_d64", 1024, "dealt"): "r04_text8_d64_b1024_index_rebuilt_traffic.json",
+    ("text8_d64", 1024, "static"): "r03_text8_d64_b1024_traffic.json",
+}
+
+
+def measured_traffic(workload, B, index="static"):
+    """HBM-side bytes per step of this configuration from its committed PMC summary (TRAFFIC_PROFILES), with the file's
+    name — or (None, the reason there is none).  The counters need their own rocprofv3 passes, so this is the profile of
+    the same command, not a measurement of the run that prints it."""
+    name = TRAFFIC_PROFILES.get((workload, int(B), index))
+    if name is None:
+        return None, "no PMC profile committed for (%s, B=%d, %s)" % (workload, B, index)
+    try:
+        j = json.load(open(REPO / "profiles" / name))
+        return float(j["traffic_bytes_per_step"]), "profiles/" + name
+    except (OSError, ValueError, KeyError) as exc:
+        return None, "profiles/%s unreadable (%s)" % (name, type(exc).__name__)
 
 
 def cpu_model() -> str:
@@ -449,8 +461,7 @@ def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.
                                   stream=stream.side) / nb
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     achieved = alg / (elapsed / steps) / 1e9
-    fused = (runner.records or getattr(runner, "run_words", False)) and getattr(tables, "_twin_dirty", False)
-    traffic, traffic_src = measured_traffic(workload, B, cap, fused, "dealt") if not adam else (None, None)
+    traffic, traffic_src = measured_traffic(workload, B, "dealt") if not adam else (None, "Adam: not profiled with counters")
     out = {
         "metric": "co-occurrence nonzeros/sec", "value": steps * B / elapsed, "unit": "nonzeros/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -722,8 +733,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     alg = algorithmic_bytes_adam(B, V, d) if adam else algorithmic_bytes(B, d, u_row, u_col)
     # the whole step as timed (contract: bytes / ms_per_step); the kernels alone, back to back, are reported beside it
     achieved = alg / (elapsed / steps) / 1e9
-    traffic, traffic_src = measured_traffic(workload, B, cap, any(k.startswith("step_fused") for k in kern)) \
-        if mode == "single" and not adam else (None, None)
+    traffic, traffic_src = measured_traffic(workload, B, "static") if mode == "single" and not adam else \
+        (None, "Adam: not profiled with counters" if adam else "multi-rank form: not profiled with counters")
     rows = getattr(stepper, "rows", False)
     parallelism = {"single": "single GPU",
                    "dp": "dp%d, %s" % (world, "touched-rows all-gather" if rows else "dense-grad all-reduce"),
@@ -766,10 +777,77 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
 
 
 def brief(r: dict) -> dict:
-    """A configuration as it appears in the headline's `configs` array."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "repeats", "dtype", "data", "config", "roofline",
-            "final_loss", "collectives")
+    """A configuration as the side file (bench_configs.json) keeps it."""
+    keep = ("name", "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "repeats", "dtype", "data", "config",
+            "roofline", "final_loss", "collectives")
     return {k: r[k] for k in keep if k in r}
+
+
+def config_line(r: dict) -> dict:
+    """A configuration as its own short stderr line (`[bench-config] {...}`, well under 1 KB)."""
+    rf, cf = r["roofline"], r["config"]
+    out = {"name": r.get("name"), "workload": cf["workload"], "optimizer": cf["optimizer"], "B": cf["batch_size_per_gpu"],
+           "n_gpus": r["n_gpus"], "index": "static" if cf["index"].startswith("static") else "dealt",
+           "parallelism": cf["parallelism"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+           "frac": rf["frac"], "step_kernels_alone_frac": rf["step_kernels_alone_frac"],
+           "traffic_over_algorithmic": rf["traffic_over_algorithmic"], "algorithmic_bytes_per_step": rf["algorithmic_bytes_per_step"],
+           "kernel_us": {k: round(v, 2) for k, v in rf["kernel_us"].items()}}
+    if "collectives" in r:
+        out["collectives_ms"] = {k: round(v, 4) for k, v in r["collectives"].items() if k.endswith("_ms")}
+    return out
+
+
+def headline(out: dict) -> dict:
+    """The ONE stdout line: the headline configuration only, a few KB at most (a driver keeps the tail of stdout — every
+    other configuration goes to stderr as `[bench-config]` lines and, whole, to bench_configs.json)."""
+    rf = out["roofline"]
+    cfg = {k: out["config"][k] for k in ("workload", "V", "d", "optimizer", "batch_size_per_gpu", "global_batch", "nnz_per_gpu",
+                                         "chunk_cap", "parallelism", "rehearsal", "same_workload_static_index",
+                                         "exchange_floats_per_rank_per_step") if k in out["config"]}
+    cfg["index"] = "static" if out["config"]["index"].startswith("static") else "dealt"
+    cfg["index_note"] = out["config"]["index"][:160]
+    cfg["launch"] = out["config"]["launch"][:120]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = cfg
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                           "traffic_over_algorithmic", "algorithmic_bytes_per_step", "kernel",
+                                           "step_kernels_alone_frac", "frac_of_measured_stream_ceiling") if k in rf}
+    line["roofline"]["kernel_us"] = {k: round(v, 2) for k, v in rf["kernel_us"].items()}
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "usable_cores",
+                                                   "cpu_model", "label") if k in cb}
+        line["cpu_baseline"]["legs"] = {name: {"value": leg["value"], "cores": leg["cores"]}
+                                        for name, leg in cb.get("legs", {}).items() if isinstance(leg, dict)}
+        if "error" in cb.get("legs", {}):
+            line["cpu_baseline"]["error"] = str(cb["legs"]["error"])[:200]
+    for k in ("configs_skipped", "configs_file", "final_loss", "wall_seconds"):
+        if k in out:
+            line[k] = out[k]
+    if "configs" in out:
+        line["configs_run"] = [r["name"] for r in out["configs"]]
+    if "collectives" in out:        # the per-phase times are in roofline.kernel_us already
+        line["collectives"] = {k: round(v, 4) for k, v in out["collectives"].items() if k.endswith("_ms")}
+    if "process_group" in out:
+        pg = out["process_group"]
+        line["process_group"] = {k: pg[k] for k in ("world_size", "backend", "rccl_version", "distinct_devices") if k in pg}
+        line["process_group"]["devices_by_rank"] = [r.get("pci_bus_id") or r.get("cuda_device") for r in pg.get("ranks", [])]
+    return line
+
+
+def write_configs_file(out: dict) -> str:
+    """The full objects (headline + every configs[] entry) beside the run; returns the path written ('' if none could be)."""
+    for d in (REPO / "gpurun_out", REPO, Path("/tmp")):
+        try:
+            d.mkdir(exist_ok=True)
+            path = d / "bench_configs.json"
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            return str(path.relative_to(REPO)) if d != Path("/tmp") else str(path)
+        except OSError:
+            continue
+    return ""
 
 
 def main(argv=None):
@@ -873,9 +951,12 @@ def main(argv=None):
                 continue
             kw = dict(extra)
             kw.update({k: v for k, v in spec.items() if k not in ("workload", "B")})
-            r = brief(run_config(ctx, spec["workload"], spec["B"], **kw))
+            r = run_config(ctx, spec["workload"], spec["B"], **kw)
             r["name"] = name
+            r = brief(r)
             configs.append(r)
+            if rank == 0:
+                print("[bench-config] " + json.dumps(config_line(r)), file=sys.stderr, flush=True)
         out["configs_skipped"] = skipped
         out["configs"] = configs
         # the headline workload in the trainer's static mode, beside the headline
@@ -885,7 +966,11 @@ def main(argv=None):
                     "nonzeros_per_s": r["value"], "ms_per_step": r["ms_per_step"], "index": r["config"]["index"]}
     out["wall_seconds"] = time.perf_counter() - T_START
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["name"] = "headline"
+        print("[bench-config] " + json.dumps(config_line(out)), file=sys.stderr, flush=True)
+        out["configs_file"] = write_configs_file(out)
+        sys.stderr.flush()
+        print(json.dumps(headline(out)), flush=True)          # the last thing on stdout, and the only JSON line
     faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         import gc

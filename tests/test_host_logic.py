@@ -275,3 +275,87 @@ def test_reference_module_names_are_aliases():
                       ("src.data.text8", "--context-size"), ("src.models.export_embeddings", "--job-dir")):
         out = run(mod, "--help")
         assert out.returncode == 0 and flag in out.stdout, (mod, out.stderr[-300:])
+
+
+def _fake_bench_result(name, world=1):
+    """What bench.run_config / run_dealt return, with the longest strings and the most keys they produce."""
+    kern = {"step": 585.123456, "index_build": 60.123456, "epoch_deal": 12.3456789, "fetch_all_to_all": 207.0, "push_all_to_all": 219.0,
+            "loss_tail": 24.0, "all_reduce": 100.0}
+    r = {"name": name, "metric": "co-occurrence nonzeros/sec", "value": 1.54e9, "unit": "nonzeros/s", "n_gpus": world, "steps": 200,
+         "warmup": 20, "ms_per_step": 0.6805, "repeats": 3, "ms_per_step_min_max": [0.67, 0.69], "higher_is_better": True,
+         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic " + "x" * 150,
+         "config": {"workload": "zipf_v400k_d300", "V": 400000, "d": 300, "optimizer": "Adagrad", "batch_size_per_gpu": 1048576,
+                    "global_batch": 1048576 * world, "nnz_per_gpu": 25000000, "batches_per_epoch": 23, "chunk_cap": 32,
+                    "index": "rebuilt every step: " + "y" * 400, "launch": "the trainer's runner: " + "z" * 200,
+                    "parallelism": "both tables sharded x8, touched col rows by all-to-all", "chunk_records": False,
+                    "chunk_run_words": True, "exchange_floats_per_rank_per_step": 123456789},
+         "roofline": {"bound": "hbm", "achieved": 2400.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.2995,
+                      "frac_of_measured_stream_ceiling": 0.38, "stream_ceiling": 6290.0, "traffic": 3.478e9,
+                      "traffic_source": "profiles/r04_c4_v400k_d300_b1m_index_rebuilt_traffic.json", "traffic_over_algorithmic": 2.13,
+                      "kernel": "one step as timed = step kernels, beside them on a side stream index_build and epoch_deal",
+                      "algorithmic_bytes_per_step": 1630400000, "kernel_us": kern, "kernel_us_note": "n" * 300, "per_kernel": None,
+                      "step_kernels_alone_frac": 0.348, "heavy_ids_per_step": 100.0, "uniq_rows_per_step": 167438.0,
+                      "uniq_cols_per_step": 167610.0, "chunks_per_step": 400000.0},
+         "masters_build_ms_at_load": 100.0, "final_loss": 1.25}
+    if world > 1:
+        r["collectives"] = {"phases_ms_per_step": {k: v / 1e3 for k, v in kern.items()}, "all_reduce_ms": 0.124, "all_gather_ms": 0.0, "all_to_all_ms": 0.426}
+        r["process_group"] = {"world_size": world, "backend": "nccl", "rccl_version": "2.26.6", "distinct_devices": world,
+                              "ranks": [{"rank": i, "cuda_device": i, "device_name": "AMD Instinct MI355X", "pci_bus_id": "0000:%02x:00.0" % i,
+                                         "host": "h" * 40, "pid": 100000 + i, "visible_devices": 8} for i in range(world)]}
+    return r
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_bench_headline_is_one_short_line(world):
+    """The driver keeps the tail of stdout: the ONE JSON line is the headline alone and stays under 4 KB whatever the run
+    carried (twelve configs[] entries, eight ranks, the longest notes), with the contract's fields, `roofline` and
+    `cpu_baseline` in it; every configs[] entry has its own stderr line under 1 KB."""
+    import json
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    out = _fake_bench_result("headline", world)
+    leg = {"value": 1.07e7, "unit": "nonzeros/s", "steps_per_s": 10.2, "cores": 16, "kind": "port", "sample": "s" * 150}
+    out["cpu_baseline"] = dict(leg, host_cpus=256, usable_cores=16, cpu_model="AMD EPYC 9575F 64-Core Processor",
+                               label="CPU restatement of yxtay/glove-tensorflow estimator step (TF 2.11 unavailable offline)",
+                               legs={"adagrad_at_gpu_batch": leg, "adagrad_at_gpu_batch_one_core": dict(leg, cores=1),
+                                     "c1_adam_bs1024": leg, "c1_adam_bs1024_one_core": dict(leg, cores=1)})
+    out["configs"] = [bench.brief(_fake_bench_result("config_number_%d_with_a_long_name_static_index" % i, world)) for i in range(12)]
+    out["configs_skipped"] = ["another_config_with_a_long_name_%d" % i for i in range(12)]
+    out["config"]["same_workload_static_index"] = {"nonzeros_per_s": 1.67e9, "ms_per_step": 0.628, "index": "static, built at load (the trainer's --epoch-shuffle static)"}
+    out["wall_seconds"], out["configs_file"] = 240.0, "gpurun_out/bench_configs.json"
+    line = json.dumps(bench.headline(out))
+    assert len(line) < 4096 and "\n" not in line
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["config"]["workload"] == "zipf_v400k_d300" and "model" not in j["config"] and j["config"]["index"] == "dealt"
+    assert j["config"]["same_workload_static_index"]["ms_per_step"] == 0.628
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_over_algorithmic",
+              "algorithmic_bytes_per_step", "kernel_us"):
+        assert k in j["roofline"], k
+    assert j["roofline"]["frac"] == 0.2995 and j["cpu_baseline"]["value"] == 1.07e7 and j["cpu_baseline"]["cores"] == 16
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and len(j["cpu_baseline"]["legs"]) == 4
+    assert "configs" not in j and len(j["configs_run"]) == 12 and len(j["configs_skipped"]) == 12
+    if world > 1:
+        assert j["process_group"]["world_size"] == world and len(j["process_group"]["devices_by_rank"]) == world
+        assert j["collectives"]["all_to_all_ms"] == 0.426
+    for r in out["configs"]:
+        assert len(json.dumps(bench.config_line(r))) < 1024
+
+
+def test_bench_traffic_table_points_at_committed_profiles():
+    """bench.TRAFFIC_PROFILES: every row names a committed PMC summary of that very configuration (workload, batch, index
+    mode in the file's own meta), and a configuration without a row says why its traffic is null."""
+    import json
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    for (workload, B, index), name in bench.TRAFFIC_PROFILES.items():
+        meta = json.load(open(Path(bench.REPO) / "profiles" / name))["meta"]
+        assert meta["workload"] == workload and int(meta["batch"]) == B and meta.get("index", "static") == index, name
+        traffic, src = bench.measured_traffic(workload, B, index)
+        assert traffic > 0 and src == "profiles/" + name
+    traffic, why = bench.measured_traffic("text8_d64", 12345, "dealt")
+    assert traffic is None and "no PMC profile" in why
