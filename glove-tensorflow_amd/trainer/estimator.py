@@ -245,8 +245,15 @@ class Estimator:
                         self.evaluate()
             if pending is not None:
                 self._finish_log_point(pending)
-        finally:
-            self._drain_logs(stop=True)
+        except BaseException:
+            # the loop is unwinding with its own error (the NaN stop, a GloveHipError): stop the writer, but a writer error
+            # must not replace the cause
+            try:
+                self._drain_logs(stop=True)
+            except Exception as log_exc:
+                logger.error("log writer failed while the training loop was stopping: %r", log_exc)
+            raise
+        self._drain_logs(stop=True)
 
     # ---- logging points
     HOST_BIASES_MAX = 1 << 18       # bias vectors up to this length are logged from a host copy (one 1 MB copy at most)
@@ -268,7 +275,10 @@ class Estimator:
             bufs[k].copy_(v, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        dev = None if "br" in src else (br, bc)            # big vocabularies: statistics and histograms on the device, at the finish
+        # big vocabularies: statistics and histograms on the device, at the finish — of copies taken HERE, in stream order behind
+        # the point's last step (the steps issued meanwhile flip rows of a twinned table to their other copy and move on: a view
+        # read at the finish would mix old and new rows under this point's global_step); 8 B per id
+        dev = None if "br" in src else (br.clone(), bc.clone())
         return {"step": step, "host": bufs, "event": ev, "dev": dev}
 
     def _finish_log_point(self, pt):
@@ -283,7 +293,7 @@ class Estimator:
         rate = (step - s_last) / max(now - t_last, 1e-9)
         self._clock = (now, step)
         if pt["dev"] is not None:
-            biases = pt["dev"]                             # (read as they are NOW: a big table's log point waits for the stream)
+            biases = pt["dev"]                             # (the device copies taken at the point)
         else:
             biases = (host["br"].clone(), host["bc"].clone())
         rec = {"loss": loss, "weighted_mse": L, "regularization_loss": reg, "global_step": step, "steps_per_sec": rate,

@@ -253,7 +253,7 @@ class GraphedSteps:
         graphs = getattr(self, "_graphs", None)
         if graphs is None:
             return self.step_eager(item)
-        key = item if isinstance(item, int) else id(item)
+        key = item if isinstance(item, int) else self._graph_key(item)
         # the captured launches hold raw pointers into the backend's shared, lazily growing step workspace: a plan with a
         # larger one reallocates it — every graph captured before that replays into freed memory and has to go
         gen = getattr(getattr(self.backend, "hip", None), "ws_generation", 0)
@@ -261,6 +261,7 @@ class GraphedSteps:
         if g is not None and g[2] != gen:
             torch.cuda.synchronize()
             del graphs[key]
+            self._seen.pop(key, None)        # counted afresh: a workspace that keeps growing does not re-capture at every growth
             g = None
         if g is None:
             n = self._seen.get(key, 0)
@@ -285,6 +286,21 @@ class GraphedSteps:
             graphs[key] = (g, item, getattr(getattr(self.backend, "hip", None), "ws_generation", 0))
             g = graphs[key]
         g[0].replay()
+
+    _graph_serials = iter(range(1 << 62))
+
+    @classmethod
+    def _graph_key(cls, item):
+        """A serial number given to the plan at first sight (kept on the object): unlike id(), never handed to a later plan
+        that happens to be allocated at a dropped one's address."""
+        key = getattr(item, "_graph_serial", None)
+        if key is None:
+            key = ("plan", next(cls._graph_serials))
+            try:
+                item._graph_serial = key
+            except AttributeError:             # an object without attributes of its own: its address, as before
+                key = ("id", id(item))
+        return key
 
     def step_eager(self, item):
         for _, fn in self.phases():
