@@ -209,14 +209,26 @@ struct StepConsts {
 // d = 300 shape misses by one register otherwise
 // FUSE: 0 classic schedule, 1 run-merged and applying (kFuseSlot / kFuseInPlace / kFuseTwin), 2 run-merged and packing
 // (kFusePack) — a build of its own: the apply code and its accumulator rows would cost the other their registers
+// Run-merged passes over rows of ONE float4 per lane (d = 128: 512-byte rows, bound by requests in flight, not by bytes): four
+// partner rows per trip at four waves per SIMD (<= 128 VGPRs; 114 - 121 as built, nothing spilled) instead of eight at three —
+// most chunks of a big batch hold one to three pairs, so half of an eight-row trip's loads were repeats of the chunk's first
+// partner, and the fourth wave hides more of every trip than the second half of the trip did.  One process, same resident plans
+// (tools/ab_kernels.py, V = 2 M, d = 128, B = 1 M, twin form): 505 -> 407 us per step, bit-identical tables; five waves spill
+// (815 us), eight rows at four waves spill (1,088).  Three float4 per lane (d = 300) stay at four rows and three waves: two rows
+// at four waves (128 VGPRs, nothing spilled) measured 610 against 582 us at V = 400 k and 107 against 97 at V = 50 k.
+template <int LPR, int NV, int FUSE> struct FusePass {
+    static constexpr bool narrow = FUSE != 0 && LPR != 8 && NV == 1;
+    static constexpr int unroll = narrow ? 4 : PassUnroll<NV>::value;
+    static constexpr int waves = narrow ? 4 : (FUSE != 0 && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value;
+};
 template <int LPR, int NV, bool FULL, bool REC, int FUSE>
-__global__ __launch_bounds__(kBlock, (FUSE && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value) void sidepass_kernel(
+__global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
 {
     constexpr int GPB = kBlock / LPR;
-    constexpr int U = PassUnroll<NV>::value;
+    constexpr int U = FusePass<LPR, NV, FUSE>::unroll;
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
     static_assert(U % 4 == 0 && U <= kRecPad && kRecPad % U == 0, "fields are read back four pairs at a time; record fields are padded to kRecPad slots");
     // [group][field][pair]: 0 partner, 1 w (REC) or w2 = 2 w inv_batch, 2 y.  With records the group's LDS image

@@ -21,7 +21,10 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int kD4 = 75, kLPR = 32, kNV = 3, kBlock = 256;
+#ifndef D4
+#define D4 75
+#endif
+constexpr int kD4 = D4, kLPR = 32, kNV = (D4 + 31) / 32, kBlock = 256;
 constexpr uint32_t kOwn = 0u, kPair = 1u, kAcc = 2u;
 constexpr int kMaxEntries = 192;          // per group: 12 chunks x 1..32 pairs would be 384 + 24; the generator caps a group's pairs at 128
 
@@ -37,6 +40,7 @@ struct Args {
     int ngroups;
     const float *own, *partner, *acc_in;
     float *own_out, *acc_out;
+    const float *bias;
     int mode;            // bit 0: no stores; bit 1: own / accumulator rows folded into the first 1,024 rows (cache hits); bit 2: stores folded likewise
 };
 
@@ -89,9 +93,14 @@ __global__ __launch_bounds__(kBlock) void ring_kernel(Args a)
             if (a.mode & 4) row &= 1023u;
             f4 c[kNV];
             const uint32_t addr = (uint32_t)(uintptr_t)(wring + (t % D) * kNV * 64) + lane * 16;
-            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]) : "v"(addr) : "memory");
-            if (lg + 2 * kLPR >= kD4) c[2] = f4{0, 0, 0, 0};
+            if constexpr (kNV == 3)
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]) : "v"(addr) : "memory");
+            else if constexpr (kNV == 2)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c[0]), "=&v"(c[1]) : "v"(addr) : "memory");
+            else
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c[0]) : "v"(addr) : "memory");
+            if (lg + (kNV - 1) * kLPR >= kD4) c[kNV - 1] = f4{0, 0, 0, 0};
             if (type == kOwn) {
 #pragma unroll
                 for (int k = 0; k < kNV; ++k) { r[k] = c[k]; acc[k] = f4{0, 0, 0, 0}; }
@@ -131,8 +140,10 @@ __global__ __launch_bounds__(kBlock) void ring_kernel(Args a)
     for (; t < Tw; ++t) consume(t);
 }
 
-// ---- the present structure, reduced: per chunk one dependent trip of U = 4 partner rows into registers ----------------
-__global__ __launch_bounds__(kBlock, 3) void trip_kernel(Args a)
+// ---- the present structure, reduced: per trip U partner rows into registers, W waves per SIMD allowed ------------------
+// mode bit 3: a 4-byte partner-bias gather per pair (lane 0 of the group), as the product does
+template <int U, int W>
+__global__ __launch_bounds__(kBlock, W) void trip_kernel(Args a)
 {
     __shared__ uint32_t ent[(kBlock / kLPR) * kMaxEntries];
     const int lg = threadIdx.x % kLPR, grp = threadIdx.x / kLPR;
@@ -162,22 +173,27 @@ __global__ __launch_bounds__(kBlock, 3) void trip_kernel(Args a)
             for (int k = 0; k < kNV; ++k) acc[k] = f4{0, 0, 0, 0};
             ++t;
         } else if (type == kPair) {
-            // up to 4 consecutive pairs (the product's trips also stop at chunk ends: 32 pairs; here at the run's end)
-            uint32_t rows[4];
+            // up to U consecutive pairs (the product's trips also stop at chunk ends: 32 pairs; here at the run's end)
+            uint32_t rows[U];
             int n = 0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+            for (int x = 0; x < U; ++x) {
                 const uint32_t ex = t + x < T ? my[t + x] : 0u;
                 const bool ok = n == x && t + x < T && (ex >> 30) == kPair;
                 rows[x] = ok ? (ex & 0x3fffffffu) : rows[0];
                 n = ok ? x + 1 : n;
             }
-            f4 c[4][kNV];
+            f4 c[U][kNV];
+            float bv[U];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) load(c[x], a.partner, rows[x]);
+            for (int x = 0; x < U; ++x) {
+                load(c[x], a.partner, rows[x]);
+                bv[x] = 0.f;
+                if ((a.mode & 8) && lg == 0) bv[x] = a.bias[rows[x]];
+            }
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                float dp = 0.f;
+            for (int x = 0; x < U; ++x) {
+                float dp = bv[x];
 #pragma unroll
                 for (int k = 0; k < kNV; ++k) dp += r[k].x * c[x][k].x + r[k].y * c[x][k].y + r[k].z * c[x][k].z + r[k].w * c[x][k].w;
                 dp = grp_sum32(dp);
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(kBlock, 3) void trip_kernel(Args a)
             }
             t += n;
         } else {
+            if (!(a.mode & 1)) {
             f4 *wo = reinterpret_cast<f4 *>(a.own_out) + (size_t)row * kD4, *ao = reinterpret_cast<f4 *>(a.acc_out) + (size_t)row * kD4;
 #pragma unroll
             for (int k = 0; k < kNV; ++k) {
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(kBlock, 3) void trip_kernel(Args a)
                     ao[i4] = An;
                     wo[i4] = r[k] - 0.05f * acc[k] / (f4{sqrtf(An.x), sqrtf(An.y), sqrtf(An.z), sqrtf(An.w)} + 1e-7f);
                 }
+            }
             }
             ++t;
         }
@@ -283,7 +301,8 @@ int main(int argc, char **argv)
     const int per = argc > 3 ? atoi(argv[3]) : 12;
     const int fold = argc > 4 ? atoi(argv[4]) : 0;
     const size_t tbytes = (size_t)V * kD4 * 16;
-    float *own, *partner, *acc, *own_out, *acc_out;
+    float *own, *partner, *acc, *own_out, *acc_out, *bias;
+    CK(hipMalloc(&bias, (size_t)V * 4)); CK(hipMemset(bias, 0, (size_t)V * 4));
     CK(hipMalloc(&own, tbytes)); CK(hipMalloc(&partner, tbytes)); CK(hipMalloc(&acc, tbytes)); CK(hipMalloc(&own_out, tbytes)); CK(hipMalloc(&acc_out, tbytes));
     {
         std::vector<float> h((size_t)V * kD4 * 4);
@@ -306,9 +325,9 @@ int main(int argc, char **argv)
         const int ng = (int)s.off.size() - 1, nb = (ng + 7) / 8;
         const size_t sb = (size_t)2000 * kD4 * 16;
         std::vector<float> o1(sb / 4), o2(sb / 4), a1(sb / 4), a2(sb / 4);
-        Args a{de, dof, ng, own, partner, acc, own_out, acc_out, 0};
+        Args a{de, dof, ng, own, partner, acc, own_out, acc_out, bias, 0};
         CK(hipMemset(own_out, 0, sb)); CK(hipMemset(acc_out, 0, sb));
-        hipLaunchKernelGGL(trip_kernel, dim3(nb), dim3(kBlock), 0, 0, a);
+        hipLaunchKernelGGL((trip_kernel<4, 3>), dim3(nb), dim3(kBlock), 0, 0, a);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(o1.data(), own_out, sb, hipMemcpyDeviceToHost)); CK(hipMemcpy(a1.data(), acc_out, sb, hipMemcpyDeviceToHost));
         CK(hipMemset(own_out, 0, sb)); CK(hipMemset(acc_out, 0, sb));
@@ -332,21 +351,37 @@ int main(int argc, char **argv)
     CK(hipMemcpy(de, s.entries.data(), s.entries.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dof, s.off.data(), s.off.size() * 4, hipMemcpyHostToDevice));
     const int ng = (int)s.off.size() - 1, nb = (ng + 7) / 8;
-    Args a{de, dof, ng, own, partner, acc, own_out, acc_out, 0};
+    Args a{de, dof, ng, own, partner, acc, own_out, acc_out, bias, 0};
     const double rows = (double)s.entries.size();
-    const double alg = s.ids * 4.0 * 1200 + B * 16.0;           // own + acc read, two rows written, the pair stream
+    const double alg = s.ids * 4.0 * (kD4 * 16) + B * 16.0;           // own + acc read, two rows written, the pair stream
     printf("V %d, B %ld, per %d, partner fold %d: %d groups, %ld run entries (ids x groups), %.0f row loads, %.1f entries per group; algorithmic %.3f GB per side\n",
            V, B, per, fold, ng, s.ids, rows, rows / ng, alg / 1e9);
 #define RUN(NAME, K) { const float us = time_us([&] { hipLaunchKernelGGL(K, dim3(nb), dim3(kBlock), 0, 0, a); }, 20); \
-    printf("%-28s %8.1f us   %.2f row loads/ns   loads %.2f TB/s   algorithmic %.2f TB/s\n", NAME, us, rows / us / 1e3, rows * 1200 / us / 1e6, alg / us / 1e6); fflush(stdout); }
-    RUN("trip (U = 4, 3 waves/SIMD)", trip_kernel);
-    for (int mode : {0, 1, 2, 3, 4, 6}) {
+    printf("%-28s %8.1f us   %.2f row loads/ns   loads %.2f TB/s   algorithmic %.2f TB/s\n", NAME, us, rows / us / 1e3, rows * (kD4 * 16) / us / 1e6, alg / us / 1e6); fflush(stdout); }
+    for (int mode : {0, 8, 1}) {
+        a.mode = mode;
+        printf("-- mode %d (%s%s)\n", mode, mode & 1 ? "no stores " : "", mode & 8 ? "a 4-byte partner-bias gather per pair" : "");
+        RUN("trip U = 4, <= 3 waves/SIMD", (trip_kernel<4, 3>));
+        RUN("trip U = 8, <= 3 waves/SIMD", (trip_kernel<8, 3>));
+        RUN("trip U = 2, <= 8 waves/SIMD", (trip_kernel<2, 8>));
+        RUN("trip U = 4, <= 8 waves/SIMD", (trip_kernel<4, 8>));
+        RUN("trip U = 4, <= 4 waves/SIMD", (trip_kernel<4, 4>));
+        RUN("trip U = 8, <= 4 waves/SIMD", (trip_kernel<8, 4>));
+        RUN("trip U = 2, <= 4 waves/SIMD", (trip_kernel<2, 4>));
+        RUN("trip U = 2, <= 5 waves/SIMD", (trip_kernel<2, 5>));
+        RUN("trip U = 2, <= 6 waves/SIMD", (trip_kernel<2, 6>));
+        RUN("trip U = 1, <= 8 waves/SIMD", (trip_kernel<1, 8>));
+    }
+    for (int mode : {0}) {
         a.mode = mode;
         printf("-- mode %d (%s%s%s)\n", mode, mode & 1 ? "no stores " : "", mode & 2 ? "own/acc loads folded " : "", mode & 4 ? "stores folded" : "");
         RUN("ring D = 2", ring_kernel<2>);
         RUN("ring D = 3", ring_kernel<3>);
         RUN("ring D = 5", ring_kernel<5>);
         RUN("ring D = 8", ring_kernel<8>);
+#if D4 <= 32
+        RUN("ring D = 12", ring_kernel<12>); RUN("ring D = 16", ring_kernel<16>);
+#endif
     }
     return 0;
 }
