@@ -13,8 +13,8 @@ builds on a side stream, steps replayed from hipGraphs).  `--static-index` times
 N = 1: the sparse Adagrad step (fused forward+gradient pass kernel(s) + apply kernel; glove_step_adagrad_f32 picks the
 form).  The headline is the workload BASELINE.json's metric is quoted on at 1, 2, 4 and 8 GPUs — config 4, synthetic
 Zipf V = 400 k, d = 300 — as the one-GPU shard of its 200 M nonzeros (25 M, batches of 1 M): the configuration where
-"achieved HBM GB/s vs peak" is about HBM (text8's tables live in the caches).  Unless `--single` is given the same JSON
-line also carries `configs`: text8 d = 64 (BASELINE configs[1]: static index, index rebuilt every step, the
+"achieved HBM GB/s vs peak" is about HBM (text8's tables live in the caches).  Unless `--single` is given the run also
+times the other configurations (each a `[bench-config]` line on stderr): text8 d = 64 (BASELINE configs[1]: static index, index rebuilt every step, the
 reference's batch size, Keras-legacy Adam), V = 50 k at d = 300 and V = 2 M at d = 128, each with its own roofline —
 as far as the wall-clock budget (`--budget-seconds`) goes; what did not fit is named in `configs_skipped`.  `roofline.frac`
 of every entry = algorithmic bytes per step / ms_per_step / 8 TB/s (the whole step as timed, index work included).
@@ -22,10 +22,14 @@ of every entry = algorithmic bytes per step / ms_per_step / 8 TB/s (the whole st
 N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child process; under a launcher it
 is a rank).  Every rank owns its own shard of nonzeros (global batch = N * B, weak scaling).  The headline is config 4
 with both tables sharded (touched col rows fetched from / returned to their owners by all-to-all: the exchange follows
-the batch, not the vocabulary); `configs` carries config 4 data parallel as BASELINE.json words it (dense-gradient
-all-reduce or touched-rows all-gather, whichever is the shorter payload) and config 5 sharded.
+the batch, not the vocabulary) in the same mode as the one-GPU headline: every rank deals its shard anew every epoch,
+fetch lists and indexes prepared beside the steps (what `python -m trainer.estimator --row-sharded --shard-cols` runs);
+the other configurations (stderr lines, bench_configs.json): the same with a static index, config 4 data parallel as
+BASELINE.json words it (dense-gradient all-reduce or touched-rows all-gather, whichever is the shorter payload), config 5
+sharded in both modes.
 
-Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is measured live with HIP events on the
+Rank 0 prints ONE JSON line — the headline alone, a few KB, the last thing on stdout; every other configuration is a
+`[bench-config] {...}` line on stderr and an entry of bench_configs.json (gpurun_out/ when it exists).  `roofline` is measured live with HIP events on the
 launch stream in a second, instrumented pass over the same batches; `cpu_baseline` times the C port of the oracle
 (oracle/glove_ref.c: all cores with OpenMP, and one core) on a bounded sample.
 """
@@ -386,6 +390,149 @@ def event_us(fn, reps=3, stream=None):
     return sorted(spans)[len(spans) // 2]
 
 
+def run_dealt_multi(ctx, workload, B, mode, steps=200, warmup=20, lr=0.05, chunk_cap=0, step_form=0, exchange="auto",
+                    no_graph=False, min_timed_ms=20.0, segment=0):
+    """The multi-rank forms in the trainer's default mode (--epoch-shuffle full), set up as trainer.estimator sets them up:
+    every rank deals ITS shard anew every epoch (NonzeroStream + ReshufflingRunner over the form's stepper); with both tables
+    sharded the epoch's fetch lists are agreed between the ranks beside the steps.  mode: "dp", "rowsharded", "sharded"."""
+    from trainer.data_utils import NonzeroStream
+    from trainer.hip_api import DeviceTables, make_hyper
+    from trainer.stepper import HipBackend, ReshufflingRunner, RowShardedStepper, ShardedStepper, Stepper, owned_rows
+    hip, dev, dist, world, rank = ctx.hip, ctx.dev, ctx.dist, ctx.world, ctx.rank
+    log("%s B=%d Adagrad mode=%s, epochs dealt and indexed inside the timed region: generating the workload" % (workload, B, mode))
+    wl = ctx.workload(workload)
+    V, d = wl["V"], wl["d"]
+    V_row = V_col = V
+    if mode in ("sharded", "rowsharded"):
+        V_row = owned_rows(V, world, rank)
+        V_col = V_row if mode == "sharded" else V
+    backend = HipBackend(dev)
+    backend.hip = hip
+    tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1, V_row=V_row, V_col=V_col)
+    backend.row_floats = tables.d
+    backend.exchange = True
+    if mode in ("sharded", "rowsharded"):
+        backend.shard_rows = tables.V_row
+    t0 = time.perf_counter()
+    stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, rank=rank, world=world, seed=0,
+                           static_plans=False, route=dist if mode in ("sharded", "rowsharded") and world > 1 else None,
+                           cols_by_owner=world if mode == "sharded" else 0, presharded=True)
+    torch.cuda.synchronize()
+    masters_ms = (time.perf_counter() - t0) * 1e3
+    nnz = stream.nnz
+    hyper_kw = dict(learning_rate=lr, step_form=step_form)
+    if mode == "sharded":
+        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives)
+    elif mode == "rowsharded":
+        stepper = RowShardedStepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange, collectives=ctx.args.collectives)
+        stepper.prepare(batch_size=B)
+    else:
+        stepper = Stepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange, collectives=ctx.args.collectives)
+        if world > 1 or ctx.args.collectives:
+            stepper.prepare(batch_size=B)
+        else:
+            stepper.dense, stepper.G = True, backend.dense_grad_buffer(tables)
+    hyper = make_hyper(batch_size=B * world, **hyper_kw)
+    # (a captured multi-rank step issues its collectives in line; the trainer takes graphs there only with --multi-rank-graphs)
+    runner = ReshufflingRunner(hip, stream, tables, hyper, chunk_cap=chunk_cap, burst=64, stepper=stepper, graphs=False, segment=segment)
+    nb = runner.nb
+    log("  masters in %.1f ms (once, at load); %d batches per epoch" % (masters_ms, nb))
+
+    def run(n_steps):
+        done = 0
+        while done < n_steps:
+            done += runner.run(n_steps - done)
+    elapsed, elapsed_all = timed_region(ctx, run, steps, warmup, min_timed_ms)
+    final_loss = float(stepper.loss_out[0].item())
+    log("  %.4f ms per step (%d repeats); per-phase pass" % (elapsed / steps * 1e3, len(elapsed_all)))
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+    torch.cuda.synchronize()
+    # ---- what the batches touched, and the phases of one step apart (each timed to its end, collectives included)
+    if runner.sharded:
+        items = [h for h in runner.handles if stepper.batches[h] is not None][:8]
+        plans = [stepper.batches[h]["plan"] for h in items]
+    else:
+        run(1)                                  # (the current segment's plans are built and adopted)
+        torch.cuda.synchronize()
+        slot = runner.slots[(runner._g) % 2]
+        plans = items = slot.plans[:max(1, min(8, runner.S))]
+    counts = torch.stack([p.counts for p in plans]).double()
+    counts = counts[counts[:, 0] > 0].mean(0).tolist()
+    chunks, u_row, u_col, n_heavy = counts[0] + counts[2], counts[1], counts[3], counts[4]
+    if dist is not None and world > 1:          # the ranks' batches differ: the job's bytes are the sum over ranks
+        tot = torch.tensor([u_row, u_col], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        u_row_all, u_col_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        u_row_all, u_col_all = u_row, u_col
+    calls = dict(stepper.phases())
+    finish = getattr(stepper, "finish_async", None)
+    if finish is not None:
+        calls = {name: (lambda x, fn=fn: (fn(x), finish())) for name, fn in calls.items()}
+    kern = {}
+    reps = max(len(items), 8)
+    for name, fn in calls.items():
+        for i in range(min(len(items), 4)):
+            fn(items[i % len(items)])
+        torch.cuda.synchronize()
+        spans = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(reps):
+                fn(items[i % len(items)])
+            b.record()
+            torch.cuda.synchronize()
+            spans.append(a.elapsed_time(b) * 1e3 / reps)
+        kern[name] = sorted(spans)[1]
+    step_us = sum(kern.values())
+    # per GPU, like the peak it is held against: one rank's share of the job's step (the mean over the ranks' batches)
+    alg = 16 * B + 16 * (d + 1) * (u_row_all + u_col_all) / world
+    achieved = alg / (elapsed / steps) / 1e9
+    rows = getattr(stepper, "rows", False)
+    parallelism = {"dp": "dp%d, %s" % (world, "touched-rows all-gather" if rows else "dense-grad all-reduce"),
+                   "sharded": "both tables sharded x%d, touched col rows by all-to-all" % world,
+                   "rowsharded": "row table sharded x%d, col side %s" % (
+                       world, "local (one rank)" if world == 1 else "touched-rows all-gather" if rows else "dense all-reduce")}[mode]
+    peak = HBM_PEAK_GBS
+    out = {
+        "metric": "co-occurrence nonzeros/sec", "value": steps * B * world / elapsed, "unit": "nonzeros/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "repeats": len(elapsed_all), "ms_per_step_min_max": [min(elapsed_all) / steps * 1e3, max(elapsed_all) / steps * 1e3],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": DATA_NOTE.get(workload, "synthetic"),
+        "config": {"workload": workload, "V": V, "d": d, "optimizer": "Adagrad",
+                   "batch_size_per_gpu": B, "global_batch": B * world, "nnz_per_gpu": nnz, "batches_per_epoch": nb, "chunk_cap": runner.cap,
+                   **({"rehearsal": "ranks share cuda:0 over gloo: control flow only, the numbers mean nothing"}
+                      if ctx.args.rehearse_on_one_gpu else {}),
+                   "index": "rebuilt every step: every rank deals its shard anew every epoch (trainer.stepper.ReshufflingRunner over the "
+                            "form's stepper), indexes and fetch lists prepared beside the steps, inside the timed region",
+                   "launch": "the trainer's runner, steps launched eagerly (collectives on the transport's stream)",
+                   "parallelism": parallelism,
+                   "exchange_floats_per_rank_per_step": getattr(stepper, "payload_floats", None)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                     "frac": achieved / peak, "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
+                     "stream_ceiling": HBM_STREAM_GBS, "traffic": None,
+                     "traffic_source": "multi-rank form: not profiled with counters", "traffic_over_algorithmic": None,
+                     "kernel": "per GPU; one step = " + " + ".join(kern),
+                     "algorithmic_bytes_per_step": alg, "kernel_us": kern,
+                     "step_kernels_alone_frac": alg / (step_us * 1e-6) / 1e9 / peak,
+                     "heavy_ids_per_step": n_heavy, "uniq_rows_per_step": u_row, "uniq_cols_per_step": u_col, "chunks_per_step": chunks},
+        "masters_build_ms_at_load": masters_ms, "final_loss": final_loss,
+    }
+    out["collectives"] = collectives_breakdown(kern)
+    out["process_group"] = process_group_facts(ctx)
+    runner.release_graphs()
+    if hasattr(stepper, "release_graphs"):
+        stepper.release_graphs()
+    del runner, stream, tables, plans, items, stepper
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    log("  done: %.3g nonzeros/s, %.1f us per step of phases, roofline %.3f" % (out["value"], step_us, out["roofline"]["frac"]))
+    return out
+
+
 def run_dealt(ctx, workload, B, optimizer="Adagrad", steps=200, warmup=20, lr=0.05, chunk_cap=0, step_form=0,
               no_graph=False, min_timed_ms=20.0, segment=0):
     """One GPU, the trainer's default mode (--epoch-shuffle full): the stream object and the runner are the trainer's own
@@ -514,6 +661,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         raise SystemExit("--optimizer Adam is benchmarked on one GPU")
     if dynamic and mode == "single":
         return run_dealt(ctx, workload, B, optimizer, steps, warmup, lr, chunk_cap, step_form, no_graph, min_timed_ms, segment)
+    if dynamic:
+        return run_dealt_multi(ctx, workload, B, mode, steps, warmup, lr, chunk_cap, step_form, exchange, no_graph, min_timed_ms, segment)
     log("%s B=%d %s mode=%s: generating the workload" % (workload, B, optimizer, mode))
     wl = ctx.workload(workload)
     V, d = wl["V"], wl["d"]
@@ -938,8 +1087,10 @@ def main(argv=None):
                   ("c5_zipf_v2m_d128_one_gpu_shard_static_index", 15, dict(workload="zipf_v2m_d128", B=1048576, steps=24, warmup=4))]
                  if world == 1 else
                  # config 4 as BASELINE.json words it (nonzeros sharded, gradient exchange per step), and config 5
-                 [("c4_zipf_v400k_d300_data_parallel", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="dp")),
-                  ("c5_zipf_v2m_d128_both_tables_sharded", 60, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
+                 [("c4_zipf_v400k_d300_static_index", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="sharded")),
+                  ("c4_zipf_v400k_d300_data_parallel_static_index", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="dp")),
+                  ("c5_zipf_v2m_d128_both_tables_sharded", 70, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded", dynamic=True)),
+                  ("c5_zipf_v2m_d128_both_tables_sharded_static_index", 60, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
         configs, skipped = [], []
         for name, est, spec in specs:
             # the decision is rank 0's (the ranks' clocks differ) and collective

@@ -111,7 +111,7 @@ class NonzeroStream:
     """
 
     def __init__(self, coo: dict, batch_size: int, V: int, backend, device, rank=0, world=1, seed=None,
-                 chunk_cap=0, static_plans=True, route=None, cols_by_owner=0):
+                 chunk_cap=0, static_plans=True, route=None, cols_by_owner=0, presharded=False):
         """`static_plans=False`: no index is built here; the caller re-permutes the pairs every epoch
         (`reshuffle_in_place`) and indexes each batch when it is used (--epoch-shuffle full).
         `cols_by_owner` = W > 0 (both tables sharded over W ranks): col ids are renumbered owner-major — id v becomes
@@ -130,7 +130,7 @@ class NonzeroStream:
         perm = torch.randperm(n, generator=self.gen)
         # every nonzero belongs to exactly one rank: the first n % world ranks take one more
         lo, hi = rank * (n // world) + min(rank, n % world), (rank + 1) * (n // world) + min(rank + 1, n % world)
-        mine = perm[lo:hi] if world > 1 else perm
+        mine = perm[lo:hi] if world > 1 and not presharded else perm
         def take(a):        # numpy arrays (the parsed CSV) or tensors already on the device (bench.py's synthetic workloads)
             if torch.is_tensor(a):
                 return a[mine.to(a.device)].to(self.device)
