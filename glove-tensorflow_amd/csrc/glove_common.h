@@ -103,7 +103,7 @@ __device__ inline float wave_sum(float v) { return group_sum<64>(v); }
 // (high) and ceil(b / 2) (low) bits, four rounds of a multiply-xorshift mix that alternately rewrite the high half from the low
 // one and the low half from the high one, one 32-bit round key each — with cycle walking: positions that land outside [0, n)
 // go round again (2^b < 2 n: fewer than two rounds of it on average; a balanced network over an even number of bits would
-// waste up to four).  What an epoch's reshuffle of a resident nonzero stream is drawn from (glove_shuffle_stream,
+// waste up to four).  What an epoch's reshuffle of a resident nonzero stream is drawn from (the deal of glove_epoch.hip,
 // glove_epoch_deal): no sort of n random keys, no index array.  oracle/glove_ref.py:feistel_walk restates it.
 __host__ __device__ inline uint32_t feistel_mix(uint32_t x, uint32_t k)
 {

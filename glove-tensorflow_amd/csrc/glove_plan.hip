@@ -106,7 +106,7 @@ __device__ inline void sort_load_keys(const SortSide &sd, int64_t n, int64_t bas
 }
 
 // The passes of up to kPlanSetMax batches of the same size share their launches as well (blockIdx.z = batch): the
-// indexes of consecutive batches of a stream in the launches of one (glove_plan_build_many).
+// indexes of consecutive batches of a stream in the launches of one (the set builders below; glove_plan_build_sorted).
 struct SortPassSet { SortPass b[kPlanSetMax]; };
 // (a single batch takes its arguments bare: a 2-KB argument block costs every launch of a lone build ~1.5 us)
 __device__ inline const SortPass &pick(const SortPass &a) { return a; }
@@ -1009,25 +1009,6 @@ static int build_tiled_set(const int32_t *row, const int32_t *col, const float *
     return (int)hipGetLastError();
 }
 
-// ---- the epoch's permutation of the nonzero stream ---------------------------------------------------------------
-// out[i] = in[pi(i)] for a keyed bijection pi of [0, n): a balanced Feistel network over the 2h >= log2 n bits of the
-// position (four rounds of a multiply-xorshift mix, one 32-bit round key each) with cycle walking — positions that land
-// outside [0, n) go round again (2^(2h) < 4 n: fewer than four rounds of it on average).  One gather launch per epoch
-// instead of a sort of n random keys and four gathers (torch.randperm + index_select: 2.7 ms for the 25 M pairs of the C4
-// shard, an eighth of its epoch; 0.25 ms of 0.75 at 131,072-pair batches of a 1.2 M-pair stream).  The reference shuffles
-// through a 10,000-element buffer (data_utils.py:12-21): any bijection mixes harder.
-__global__ __launch_bounds__(kBlock) void shuffle_stream_kernel(const int32_t *__restrict__ row, const int32_t *__restrict__ col,
-                                                                const float *__restrict__ w, const float *__restrict__ y, int64_t n,
-                                                                int h, uint4 key, int32_t *__restrict__ row_out,
-                                                                int32_t *__restrict__ col_out, float *__restrict__ w_out,
-                                                                float *__restrict__ y_out)
-{
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const uint64_t x = feistel_walk((uint64_t)i, (uint64_t)n, h, key);
-        row_out[i] = row[x]; col_out[i] = col[x]; w_out[i] = w[x]; y_out[i] = y[x];
-    }
-}
-
 }  // namespace glove
 
 using namespace glove;
@@ -1077,53 +1058,6 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
         return plan->r_crec ? launch_fill_records(plan, st, true) : 0;
     }
     return build_tiled_set(row, col, w, y, B, V, &plan, 1, ws, ws_bytes, st);
-}
-
-int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t n,
-                          int32_t V, const glove_plan *const *plans, void *ws, size_t ws_bytes, void *stream)
-{
-    if (!plans || n < 1 || B < 0 || V <= 0) return GLOVE_E_BADARG;
-    for (int j = 0; j < n; ++j)
-        if (!plans[j] || plans[j]->B != B || plans[j]->chunk_cap <= 0 || plans[j]->chunk_cap != plans[0]->chunk_cap || !plans[j]->counts ||
-            (plans[j]->r_crec == nullptr) != (plans[0]->r_crec == nullptr))
-            return GLOVE_E_BADARG;
-    if (B == 0) {
-        for (int j = 0; j < n; ++j)
-            if (int rc = glove_plan_build(row, col, w, y, 0, V, plans[j], ws, ws_bytes, stream)) return rc;
-        return 0;
-    }
-    if (!row || !col || !w || !y) return GLOVE_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (B > kSmallPlanMax) {
-        // the tiled builder: as many batches per set of launches as the workspace holds (a slice of
-        // glove_plan_workspace_bytes(B, V) each), up to kPlanSetMax
-        if (!ws) return GLOVE_E_BADARG;
-        const size_t per = carve_plan_ws(nullptr, B).bytes;
-        int fit = (int)(ws_bytes / per);
-        if (fit < 1) return GLOVE_E_WORKSPACE;
-        fit = fit > kPlanSetMax ? kPlanSetMax : fit;
-        for (int j0 = 0; j0 < n; j0 += fit) {
-            const int m = n - j0 < fit ? n - j0 : fit;
-            for (int j = 0; j < m; ++j)
-                if (int rc = check_plan_for_build(plans[j0 + j], B, V)) return rc;
-            const size_t off = (size_t)j0 * B;
-            if (int rc = build_tiled_set(row + off, col + off, w + off, y + off, B, V, plans + j0, m, ws, ws_bytes, st)) return rc;
-        }
-        return 0;
-    }
-    for (int j0 = 0; j0 < n; j0 += kPlanSetMax) {
-        const int m = n - j0 < kPlanSetMax ? n - j0 : kPlanSetMax;
-        PlanSet set;
-        for (int j = 0; j < m; ++j) {
-            if (int rc = check_plan_for_build(plans[j0 + j], B, V)) return rc;
-            set.p[j] = *plans[j0 + j];
-        }
-        const size_t off = (size_t)j0 * B;
-        if (int rc = plan_build_small(row + off, col + off, w + off, y + off, B, V, set, m, st)) return rc;
-        if (plans[0]->r_crec)
-            if (int rc = launch_fill_records_set(plans + j0, m, st, nullptr, nullptr, true)) return rc;
-    }
-    return 0;
 }
 
 // ---- the index of batches that arrive sorted on both sides (an epoch dealt by glove_epoch_deal) ---------------------------
@@ -1219,21 +1153,6 @@ int glove_plan_build_sorted(const glove_pairs *row_side, const glove_pairs *col_
             hipLaunchKernelGGL(fill_records<RecordDev>, dim3((unsigned)(nb < 1 ? 1 : nb), 2, nz), dim3(kBlock), 0, st, RecordDev{part}, rec_cap(cap), B >= 262144 ? 1 : 0);
         }
     }
-    return (int)hipGetLastError();
-}
-
-int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n, uint64_t key_lo,
-                         uint64_t key_hi, int32_t *row_out, int32_t *col_out, float *w_out, float *y_out, void *stream)
-{
-    if (n < 0) return GLOVE_E_BADARG;
-    if (n == 0) return 0;
-    if (!row || !col || !w || !y || !row_out || !col_out || !w_out || !y_out || row == row_out || col == col_out || w == w_out || y == y_out)
-        return GLOVE_E_BADARG;                                   // (not in place: every position reads another one)
-    const int h = feistel_bits(n);                               // bits that cover [0, n)
-    if (h < 0) return GLOVE_E_BADARG;                            // n beyond 2^62: not a stream of this library
-    const uint4 key = make_uint4((uint32_t)key_lo, (uint32_t)(key_lo >> 32), (uint32_t)key_hi, (uint32_t)(key_hi >> 32));
-    hipLaunchKernelGGL(shuffle_stream_kernel, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, row, col, w, y, n, h,
-                       key, row_out, col_out, w_out, y_out);
     return (int)hipGetLastError();
 }
 

@@ -2628,7 +2628,6 @@ size_t glove_step_workspace_bytes(int64_t B, int32_t cap_chunks, int32_t d)
     return carve_step_ws(nullptr, B, cap_chunks, d).bytes;
 }
 
-size_t glove_dense_grad_floats(int32_t V, int32_t d) { return (size_t)grad_layout(V, V, d).total; }
 
 size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *offs)
 {
@@ -2884,7 +2883,7 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
     return (int)hipGetLastError();
 }
 
-size_t glove_packed_entry_floats(int32_t d) { return d > 0 ? (size_t)d + kPackExtra : 0; }
+static_assert(GLOVE_PACKED_ENTRY_FLOATS(0) == (size_t)kPackExtra, "the header's entry size is the kernels'");
 
 int glove_pack_grad_f32(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                         float *packed, int64_t capacity_entries, void *stream)
@@ -3120,7 +3119,6 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
 //   V = 10 k,  d = 64, B = 1 M (20 MB touched): 55.2 / 82.3 / 87.7
 // A tie at 146 MB, 4 - 6 % for the fused forms from 209 MB on (the twin form on tables beyond the Infinity Cache, the
 // three-launch form on the 61 MB table): the switch sits between.
-size_t glove_fused_step_bytes(void) { return (size_t)192 << 20; }
 
 // Which form a sparse Adagrad step takes (glove_hyper.step_form; see include/glove_hip.h).
 static int pick_step_form(const glove_plan *p, const glove_tables *t, const glove_hyper *h)
@@ -3142,7 +3140,7 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     const int64_t ids = p->host_counts[1] >= 0 && p->host_counts[3] >= 0 ? (int64_t)p->host_counts[1] + p->host_counts[3] : most;
     // (V = 50 k, d = 300, B = 131,072: 48 k ids = 230 MB per step, all of it living in the Infinity Cache: two launches
     // 106 us, fused 103 - 111; V = 400 k at B = 131,072, 336 MB: 172 against 156; V = 50 k at B = 1 M, 432 MB: 378 against 314)
-    if (ids * t->d * 16 < (int64_t)glove_fused_step_bytes()) return GLOVE_STEP_TWO_LAUNCH;        // (the table of measurements: glove_fused_step_bytes)
+    if (ids * t->d * 16 < (int64_t)GLOVE_FUSED_STEP_BYTES) return GLOVE_STEP_TWO_LAUNCH;        // (the table of measurements above)
     return t->R_ver ? GLOVE_STEP_FUSED_TWIN : GLOVE_STEP_FUSED_THREE_LAUNCH;
 }
 
@@ -3216,8 +3214,8 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
         if (int rc = plain_table(t, stream)) return rc;
     switch (form) {
     case GLOVE_STEP_FUSED_ONE_PASS:
-        // both sides in one launch: neither table may change under the other side's gathers, so both put their
-        // finished rows into the slots and the apply launch moves them
+        // (tests / comparisons) both sides in one launch: neither table may change under the other side's gathers, so both put
+        // their finished rows into the slots and the apply launch moves them
         if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 3, nullptr, nullptr, false, kFuseSlot, kFuseSlot)) return rc;
         return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseSlot, kFuseSlot);
     case GLOVE_STEP_FUSED_THREE_LAUNCH:
@@ -3519,47 +3517,5 @@ int glove_steps_adam_f32(const glove_plan *const *plans, int32_t n, const glove_
     return 0;
 }
 
-int glove_steps_rebuilt_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B, int32_t n_steps,
-                            int32_t V, const glove_build_ring *ring, const glove_tables *t, const glove_hyper *h, void *ws,
-                            size_t ws_bytes, float *G_flat, float *loss_out, void *stream)
-{
-    if (!row || !col || !w || !y || B <= 0 || n_steps < 0 || !ring || !t || !h) return GLOVE_E_BADARG;
-    if (ring->n < 1 || ring->n > 16 || !ring->plans || !ring->plan_ws || !ring->streams || !ring->built || !ring->stepped ||
-        !ring->start)
-        return GLOVE_E_BADARG;
-    for (int k = 0; k < ring->n; ++k)
-        if (!ring->plans[k] || ring->plans[k]->B != B || !ring->plan_ws[k] || !ring->built[k] || !ring->stepped[k]) return GLOVE_E_BADARG;
-    hipStream_t main = (hipStream_t)stream;
-    const int ahead = ring->n;
-#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
-    auto launch_build = [&](int i) -> int {
-        const int k = i % ahead;
-        hipStream_t bs = (hipStream_t)ring->streams[k];
-        // the staging plan is free once the step that read it last is done; the first builds of a call wait for what the
-        // compute stream held when the call began (the previous call's steps among it)
-        HIP_OK(hipStreamWaitEvent(bs, (hipEvent_t)(i >= ahead ? ring->stepped[k] : ring->start), 0));
-        if (int rc = glove_plan_build(row + (size_t)i * B, col + (size_t)i * B, w + (size_t)i * B, y + (size_t)i * B, B, V,
-                                      ring->plans[k], ring->plan_ws[k], ring->plan_ws_bytes, bs))
-            return rc;
-        HIP_OK(hipEventRecord((hipEvent_t)ring->built[k], bs));
-        return 0;
-    };
-    HIP_OK(hipEventRecord((hipEvent_t)ring->start, main));
-    for (int i = 0; i < ahead && i < n_steps; ++i)
-        if (int rc = launch_build(i)) return rc;
-    for (int i = 0; i < n_steps; ++i) {
-        const int k = i % ahead;
-        HIP_OK(hipStreamWaitEvent(main, (hipEvent_t)ring->built[k], 0));
-        float *lo = i == n_steps - 1 ? loss_out : nullptr;
-        if (int rc = G_flat ? glove_step_adam_f32(ring->plans[k], t, h, ws, ws_bytes, G_flat, lo, stream)
-                            : glove_step_adagrad_f32(ring->plans[k], t, h, ws, ws_bytes, lo, stream))
-            return rc;
-        HIP_OK(hipEventRecord((hipEvent_t)ring->stepped[k], main));
-        if (i + ahead < n_steps)
-            if (int rc = launch_build(i + ahead)) return rc;
-    }
-#undef HIP_OK
-    return 0;
-}
 
 }  // extern "C"

@@ -18,10 +18,10 @@ logger = logging.getLogger(__name__)
 PKG_DIR = Path(__file__).resolve().parent.parent
 LIB_PATH = PKG_DIR / "lib" / "libglove_hip.so"
 
-GLOVE_ABI_VERSION = 12
+GLOVE_ABI_VERSION = 13
 HEAD_REGRESSION, HEAD_LOGISTIC = 0, 1      # glove_hyper.head
 OPTIMIZER_CODES = {"Adagrad": 0, "SGD": 1, "RMSprop": 2, "Adamax": 3, "Adam": 4, "Adadelta": 5, "Ftrl": 6, "Nadam": 7}      # glove_hyper.optimizer (GLOVE_OPT_*)
-STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form
+STEP_AUTO, STEP_TWO_LAUNCH, STEP_FUSED_ONE_PASS, STEP_FUSED_THREE_LAUNCH, STEP_FUSED_TWIN, STEP_TAGGED = 0, 1, 2, 3, 4, 5   # glove_hyper.step_form (2: tests / comparisons only)
 TAGGED_STEP_MAX_BATCH = 2048      # GLOVE_STEP_AUTO takes the tagged step up to this batch size on step-tagged tables
 DEFAULT_CHUNK_CAP = 32
 RECORDS_AT_BUILD_MAX = 4096     # batches up to this size get their chunk records inside glove_plan_build
@@ -29,7 +29,7 @@ HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whol
 
 
 RUN_WORDS_MIN_CHUNKS = 98304    # chunks of a side from which a resident plan of the fused regime keeps run words instead of records (6 chunks per lane group)
-FUSED_STEP_BYTES = 192 << 20    # glove_fused_step_bytes(): touched ids x row bytes x 4 beyond which the fused step pays (re-read from the library at load)
+FUSED_STEP_BYTES = 192 << 20    # GLOVE_FUSED_STEP_BYTES (include/glove_hip.h): touched ids x row bytes x 4 beyond which the fused step pays (tests/test_abi.py holds the two together)
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -45,14 +45,14 @@ def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
 
 # every symbol include/glove_hip.h declares
 EXPORTED_SYMBOLS = (
-    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_build_many", "glove_plan_fill_records", "glove_shuffle_stream", "glove_step_workspace_bytes",
-    "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32", "glove_dense_grad_floats",
+    "glove_abi_version", "glove_plan_workspace_bytes", "glove_plan_build", "glove_plan_fill_records", "glove_step_workspace_bytes",
+    "glove_passes_f32", "glove_rowpass_f32", "glove_colpass_f32", "glove_apply_adagrad_f32",
     "glove_dense_grad_f32", "glove_dense_adagrad_f32", "glove_dense_adam_f32", "glove_step_adagrad_f32",
     "glove_steps_adagrad_f32", "glove_step_adam_f32", "glove_steps_adam_f32", "glove_eval_f32", "glove_eval_logistic_f32", "glove_topk_workspace_bytes", "glove_topk_cosine_f32",
     "glove_cooc_workspace_bytes", "glove_cooccurrence_i32", "glove_dense_grad_layout",
-    "glove_packed_entry_floats", "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_loss_partials_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
-    "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32", "glove_fused_step_bytes",
-    "glove_count_packed_f32", "glove_steps_rebuilt_f32",
+    "glove_pack_grad_f32", "glove_passes_packing_f32", "glove_pack_rest_f32", "glove_loss_partials_f32", "glove_combine_packed_f32", "glove_apply_packed_adagrad_f32",
+    "glove_gather_rows_f32", "glove_canonicalize_f32", "glove_rowside_step_adagrad_f32",
+    "glove_count_packed_f32",
     "glove_masters_workspace_bytes", "glove_masters_build", "glove_epoch_deal_workspace_bytes", "glove_epoch_deal",
     "glove_plan_sorted_workspace_bytes", "glove_plan_chunk_bound", "glove_plan_build_sorted", "glove_step_sparse_f32",
 )
@@ -96,12 +96,6 @@ class GlovePackedList(C.Structure):
     _fields_ = [("entries", _fp), ("ids", _fp), ("header", _fp), ("n", C.c_int32), ("side", C.c_int32)]
 
 
-class GloveBuildRing(C.Structure):
-    _fields_ = [("n", C.c_int32), ("plans", C.POINTER(C.POINTER(GlovePlan))), ("plan_ws", C.POINTER(C.c_void_p)),
-                ("plan_ws_bytes", C.c_size_t), ("streams", C.POINTER(C.c_void_p)), ("built", C.POINTER(C.c_void_p)),
-                ("stepped", C.POINTER(C.c_void_p)), ("start", C.c_void_p)]
-
-
 class GloveHipError(RuntimeError):
     pass
 
@@ -128,8 +122,6 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_abi_version": (C.c_int, []),
         "glove_plan_workspace_bytes": (sz, [i64, i32]),
         "glove_plan_build": (C.c_int, [vp, vp, vp, vp, i64, i32, P(GlovePlan), vp, sz, vp]),
-        "glove_plan_build_many": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, C.POINTER(P(GlovePlan)), vp, sz, vp]),
-        "glove_shuffle_stream": (C.c_int, [vp, vp, vp, vp, i64, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
         "glove_plan_fill_records": (C.c_int, [P(GlovePlan), vp]),
         "glove_masters_workspace_bytes": (sz, [i64]),
         "glove_masters_build": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, P(GlovePairs), P(GlovePairs), vp, vp, vp, sz, vp]),
@@ -144,7 +136,6 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_rowpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_colpass_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
         "glove_apply_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
-        "glove_dense_grad_floats": (sz, [i32, i32]),
         "glove_dense_grad_layout": (sz, [i32, i32, i32, vp]),
         "glove_dense_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp]),
         "glove_dense_adagrad_f32": (C.c_int, [P(GloveTables), P(GloveHyper), vp, vp, vp]),
@@ -154,7 +145,6 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_step_adam_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_step_sparse_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
         "glove_steps_adam_f32": (C.c_int, [P(P(GlovePlan)), i32, P(GloveTables), P(GloveHyper), vp, sz, vp, vp, vp]),
-        "glove_packed_entry_floats": (sz, [i32]),
         "glove_pack_grad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_passes_packing_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
         "glove_pack_rest_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp, i64, vp]),
@@ -163,11 +153,8 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
         "glove_count_packed_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), vp, vp, i64, vp]),
         "glove_apply_packed_adagrad_f32": (C.c_int, [P(GlovePackedList), i32, P(GloveTables), P(GloveHyper), vp, vp, vp, vp, i64, vp]),
         "glove_gather_rows_f32": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
-        "glove_fused_step_bytes": (sz, []),
         "glove_canonicalize_f32": (C.c_int, [P(GloveTables), vp]),
         "glove_rowside_step_adagrad_f32": (C.c_int, [P(GlovePlan), P(GloveTables), P(GloveHyper), vp, sz, vp]),
-        "glove_steps_rebuilt_f32": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, P(GloveBuildRing), P(GloveTables), P(GloveHyper), vp, sz,
-                                              vp, vp, vp]),
         "glove_eval_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_eval_logistic_f32": (C.c_int, [vp, vp, vp, vp, i64, P(GloveTables), vp, vp]),
         "glove_topk_workspace_bytes": (sz, [i32, i32, i32]),
@@ -180,9 +167,6 @@ def load_library(path: os.PathLike | None = None, any_abi: bool = False) -> C.CD
             continue
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    global FUSED_STEP_BYTES
-    if hasattr(lib, "glove_fused_step_bytes"):
-        FUSED_STEP_BYTES = int(lib.glove_fused_step_bytes())       # one number, owned by the library
     if lib.glove_abi_version() != GLOVE_ABI_VERSION and not (path and any_abi):
         raise GloveHipError("ABI mismatch: library %d, binding %d" % (lib.glove_abi_version(), GLOVE_ABI_VERSION))
     if path is None:
@@ -850,20 +834,6 @@ class GloveHip:
                                          _ptr(ws), ws.numel(), _stream()), "glove_plan_build")
         return plan.compact(self.lib, d) if compact else plan
 
-    def build_plans(self, row, col, w, y, V: int, plans: list, ws: torch.Tensor | None = None) -> None:
-        """The indexes of len(plans) consecutive batches of a stream (plan j: pairs [j B, (j + 1) B) of the arrays) refilled
-        in as few launches as they allow: small batches — the reference's 1,024 — go eight to a launch (glove_plan_build_many)."""
-        B, n = plans[0].B, len(plans)
-        for t, dt in ((row, torch.int32), (col, torch.int32), (w, torch.float32), (y, torch.float32)):
-            _require(t, dt)
-            if t.numel() < n * B:
-                raise ValueError("the arrays hold fewer than %d batches of %d pairs" % (n, B))
-        if ws is None:      # (the tiled builder takes as many batches per set of launches as the workspace holds slices)
-            ws = self._ws("_plan_ws", self.lib.glove_plan_workspace_bytes(B, V) * min(n, 8))
-        ptrs = (C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans])
-        _check(self.lib.glove_plan_build_many(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n, V, ptrs, _ptr(ws), ws.numel(),
-                                              _stream()), "glove_plan_build_many")
-
     # ---- epochs dealt from id-sorted master orders (include/glove_hip.h)
     def build_masters(self, row, col, w, y, V: int, V_row: int = 0) -> Masters:
         """The rank's nonzeros sorted once: row-major and col-major orders + the link between them (one host sync for the
@@ -930,14 +900,6 @@ class GloveHip:
                 st.r_partner, st.r_w, st.r_y = (base[k][0] + off for k in range(3))
                 st.c_partner, st.c_w, st.c_y = (base[k][0] + off for k in range(3, 6))
                 block.plans[j].lent = (row_side, col_side)          # (keeps the epoch's arrays alive as long as the plan points at them)
-
-    def shuffle_stream(self, src, dst, key: int) -> None:
-        """dst = the four arrays of `src` (row, col, w, y) under the bijection of positions the 128-bit `key` determines."""
-        n = src[0].numel()
-        for t, dt in zip(tuple(src) + tuple(dst), (torch.int32, torch.int32, torch.float32, torch.float32) * 2):
-            _require(t, dt, n)
-        _check(self.lib.glove_shuffle_stream(*(_ptr(t) for t in src), n, key & (2 ** 64 - 1), (key >> 64) & (2 ** 64 - 1),
-                                             *(_ptr(t) for t in dst), _stream()), "glove_shuffle_stream")
 
     # ---- passes
     def passes(self, plan, tables, hyper, ws=None):
@@ -1117,42 +1079,6 @@ class GloveHip:
         _check(self.lib.glove_steps_adam_f32(arr, len(plans), C.byref(_step_struct(tables, plans, hyper)), C.byref(hyper), _ptr(ws),
                                              ws.numel(), _ptr(G_flat), _ptr(loss_out), _stream()),
                "glove_steps_adam_f32")
-
-    # ---- steps over batches indexed as they are used (reshuffled epochs)
-    def make_build_ring(self, plans, workspaces, streams):
-        """The staging plans, build workspaces and build streams of glove_steps_rebuilt_f32 with the events it needs
-        (torch events, recorded once so that their handles exist).  Keep the returned object alive while it is in use."""
-        n = len(plans)
-        dev = self.device
-        events = [torch.cuda.Event() for _ in range(2 * n + 1)]
-        with torch.cuda.device(dev):
-            for ev in events:
-                ev.record()
-        ring = GloveBuildRing()
-        ring.n = n
-        keep = dict(plans=(C.POINTER(GlovePlan) * n)(*[C.pointer(p.struct()) for p in plans]),
-                    ws=(C.c_void_p * n)(*[w.data_ptr() for w in workspaces]),
-                    streams=(C.c_void_p * n)(*[s.cuda_stream for s in streams]),
-                    built=(C.c_void_p * n)(*[e.cuda_event for e in events[:n]]),
-                    stepped=(C.c_void_p * n)(*[e.cuda_event for e in events[n:2 * n]]),
-                    objects=(plans, workspaces, streams, events))
-        ring.plans, ring.plan_ws, ring.streams = keep["plans"], keep["ws"], keep["streams"]
-        ring.built, ring.stepped, ring.start = keep["built"], keep["stepped"], events[2 * n].cuda_event
-        ring.plan_ws_bytes = min(w.numel() for w in workspaces)
-        ring._keep = keep
-        return ring
-
-    def steps_rebuilt(self, row, col, w, y, B: int, n_steps: int, V: int, ring, tables, hyper, ws, G_flat=None, loss_out=None):
-        """n_steps steps over consecutive batches of B pairs of the (resident) arrays, each batch indexed on one of the
-        ring's build streams while earlier steps run on the current stream (the loop runs in C)."""
-        _require(row, torch.int32); _require(col, torch.int32); _require(w, torch.float32); _require(y, torch.float32)
-        if min(row.numel(), col.numel(), w.numel(), y.numel()) < n_steps * B:
-            raise GloveHipError("%d steps of %d pairs need %d pairs" % (n_steps, B, n_steps * B))
-        adam = G_flat is not None
-        struct = tables.struct() if adam else _step_struct(tables, [p for p in ring._keep["objects"][0]], hyper)
-        _check(self.lib.glove_steps_rebuilt_f32(_ptr(row), _ptr(col), _ptr(w), _ptr(y), B, n_steps, V, C.byref(ring),
-                                                C.byref(struct), C.byref(hyper), _ptr(ws), ws.numel(), _ptr(G_flat),
-                                                _ptr(loss_out), _stream()), "glove_steps_rebuilt_f32")
 
     # ---- eval / predict
     def eval_sums(self, row, col, w, y, tables, sums=None) -> torch.Tensor:

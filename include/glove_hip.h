@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLOVE_ABI_VERSION 12   /* 12: glove_plan.r_chunk_hw / c_chunk_hw (the fused step forms on plans without records); 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax, later Adadelta and Ftrl by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
+#define GLOVE_ABI_VERSION 13   /* 13: pruned — glove_plan_build_many, glove_shuffle_stream, glove_steps_rebuilt_f32 (+ glove_build_ring) are gone; glove_dense_grad_floats, glove_packed_entry_floats and glove_fused_step_bytes are what glove_dense_grad_layout returns and the macros GLOVE_PACKED_ENTRY_FLOATS / GLOVE_FUSED_STEP_BYTES; 12: glove_plan.r_chunk_hw / c_chunk_hw (the fused step forms on plans without records); 11: glove_plan.r_mark / c_mark (bitmaps of the batch's ids), the tagged form of glove_step(s)_adam_f32; 10: glove_hyper.optimizer / momentum / nesterov / rho, glove_step_sparse_f32 (SGD, RMSprop, Adamax, later Adadelta and Ftrl by their Keras names); 9: tagged step on step-tagged twinned tables (glove_tables.R_tag / C_tag, GLOVE_STEP_TAGGED); 8: epochs dealt from id-sorted master orders (glove_masters_build, glove_epoch_deal, glove_plan_build_sorted); plans whose pair fields live in their chunk records only; 7: chunk records start on 128-byte lines (capacity per record changed), glove_plan_build_many, glove_shuffle_stream; 6: glove_steps_rebuilt_f32; 5: record layout in 8-pair blocks; packing passes, loss partials */
 
 #define GLOVE_E_BADARG   (-1)   /* null pointer / non-positive size / d % 4 != 0 */
 #define GLOVE_E_WORKSPACE (-2)  /* workspace or plan storage too small */
@@ -97,12 +97,14 @@ typedef struct glove_hyper {
     /* form of glove_step_adagrad_f32 / glove_steps_adagrad_f32 (same result bit for bit in every form):
      *   GLOVE_STEP_AUTO                the library chooses from the plan's id counts and the row width
      *   GLOVE_STEP_TWO_LAUNCH          passes (both sides) -> apply: every chunk's sums travel through a partial row
-     *   GLOVE_STEP_FUSED_ONE_PASS      a chunk that holds ALL pairs of its id (most ids of a large vocabulary)
-     *                                  applies Adagrad itself: accumulator in place, the new row into the chunk's
-     *                                  partial-row slot; the apply launch moves those rows into the tables and
-     *                                  handles the ids with several chunks
-     *   GLOVE_STEP_FUSED_THREE_LAUNCH  row side as above, then the col side in a launch of its own, updating C and
-     *                                  bc in place (nothing reads them any more), then the apply launch
+     *   GLOVE_STEP_FUSED_ONE_PASS      (tests and A/B comparisons only) both sides in one launch, every finished row through
+     *                                  its partial-row slot, moved into the tables by the apply launch
+     *   GLOVE_STEP_FUSED_THREE_LAUNCH  a run of chunks that holds ALL pairs of its id (most ids of a large vocabulary)
+     *                                  applies Adagrad itself, accumulator in place: the row side first, its new rows
+     *                                  into the chunks' partial-row slots (the col side still gathers the old ones), then
+     *                                  the col side in a launch of its own, updating C and bc in place (nothing reads
+     *                                  them any more), then the apply launch (moves the row side's rows into the table,
+     *                                  handles the ids several lane groups share)
      *   GLOVE_STEP_FUSED_TWIN          the three-launch form on a twinned row table (glove_tables.R_ver): the row side
      *                                  writes its new rows into the other copy, the apply launch only flips versions
      *                                  (AUTO picks it whenever R_ver is set and the fused form pays)
@@ -163,7 +165,7 @@ typedef struct glove_hyper {
 
 #define GLOVE_STEP_AUTO 0
 #define GLOVE_STEP_TWO_LAUNCH 1
-#define GLOVE_STEP_FUSED_ONE_PASS 2
+#define GLOVE_STEP_FUSED_ONE_PASS 2      /* test / comparison form: AUTO never picks it, the trainer never asks for it */
 #define GLOVE_STEP_FUSED_THREE_LAUNCH 3
 #define GLOVE_STEP_FUSED_TWIN 4
 #define GLOVE_STEP_TAGGED 5
@@ -255,23 +257,6 @@ int glove_plan_build(const int32_t *row, const int32_t *col, const float *w, con
                      int64_t B, int32_t V, const glove_plan *plan,
                      void *ws, size_t ws_bytes, void *stream);
 
-/* The indexes of n consecutive batches of a stream in the launches of one: plan j (plans[j], a host array of n pointers)
- * indexes pairs [j B, (j + 1) B) of row / col / w / y.  All plans have the same B, chunk_cap and kind (records or not).  Up
- * to eight batches share every launch (a workgroup per batch in the one-workgroup builder of small batches, grid.z = batch
- * in the tiled builder): what a reshuffled epoch pays per step for its index is a fraction of the build's launch chain.  The
- * tiled builder (B > 4,096) needs a slice of glove_plan_workspace_bytes(B, V) per batch of a set: it takes as many batches
- * per set as `ws_bytes` holds.  The results are those of n calls of glove_plan_build. */
-int glove_plan_build_many(const int32_t *row, const int32_t *col, const float *w, const float *y,
-                          int64_t B, int32_t n, int32_t V, const glove_plan *const *plans,
-                          void *ws, size_t ws_bytes, void *stream);
-
-/* The epoch's reshuffle of a resident nonzero stream (the reference's input_fn reshuffles every epoch: data_utils.py:12-21):
- * out[i] = in[pi(i)] for a bijection pi of [0, n) determined by the 128-bit key (a Feistel network with cycle walking: no
- * sort, no index array) — one gather launch.  Out of place: the four outputs are other buffers than the inputs. */
-int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t n,
-                         uint64_t key_lo, uint64_t key_hi,
-                         int32_t *row_out, int32_t *col_out, float *w_out, float *y_out, void *stream);
-
 /* ---- epochs dealt from id-sorted master orders ----------------------------------------------------------------------------
  * The reference's input_fn reshuffles the file every epoch (data_utils.py:12-21: make_csv_dataset(shuffle=True,
  * num_epochs=None)), so Keras' Unique + UnsortedSegmentSum see new batches every step (a9).  Instead of sorting every batch
@@ -282,7 +267,7 @@ int glove_shuffle_stream(const int32_t *row, const int32_t *col, const float *w,
  *                         of the pair at col-major position q.  Ids outside their table count as id 0 (the reference's
  *                         unknown-token id, estimator.py:26-28): *mapped_out (device int32, optional) = how many.
  *   glove_epoch_deal      one epoch: a bijection seat() of [0, n) determined by the 128-bit key (the Feistel network of
- *                         glove_shuffle_stream) gives the pair at row-major position p the seat seat(p), i.e. batch
+ *                         glove_epoch.hip) gives the pair at row-major position p the seat seat(p), i.e. batch
  *                         seat(p) / B; a stable counting sort by batch number writes both orders so that batch k occupies
  *                         positions [k B, (k + 1) B) of row_side and of col_side, sorted by row id / by col id — ties in
  *                         master order.  Every full batch holds exactly B pairs; the n mod B pairs of the last, partial
@@ -358,8 +343,7 @@ int glove_apply_adagrad_f32(const glove_plan *plan, const glove_tables *t, const
  * w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, 0...}.  glove_dense_grad_f32 ADDS this batch's
  * summed gradients (incl. the activity-L2 terms) into G_flat, which the caller keeps all-zero
  * between steps (the dense apply kernels zero what they consume). */
-size_t glove_dense_grad_floats(int32_t V, int32_t d);                 /* V_row = V */
-/* offs[5] = float offsets of G_R, G_br, G_C, G_bc, tail; returns the total float count */
+/* offs[5] (may be NULL) = float offsets of G_R, G_br, G_C, G_bc, tail; returns the total float count of G_flat */
 size_t glove_dense_grad_layout(int32_t V_row, int32_t V, int32_t d, int64_t *offs);
 int glove_dense_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                          void *ws, size_t ws_bytes, float *G_flat, void *stream);
@@ -370,14 +354,14 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
 
 /* ---- touched-rows exchange (multi-GPU forms; SURVEY.md §8e "touched-rows exchange") ----------------
  * Instead of the dense [V,d] buffer a rank hands over ONE packed list per step.  An entry is
- * glove_packed_entry_floats(d) = d + 4 floats: [summed gradient row, d | bias gradient | id (int bits) |
+ * GLOVE_PACKED_ENTRY_FLOATS(d) = d + 4 floats: [summed gradient row, d | bias gradient | id (int bits) |
  * side (0 row, 1 col; int bits) | 0].  Entry 0 of a list is its header [row entries, col entries (int bits), sum_e,
  * sum w diff^2, sum |r|^2+|c|^2, sum br^2+bc^2, 0...]; the row-side entries follow in plan order (ascending id), then
  * the col-side entries.  glove_pack_grad_f32 writes the list of one plan (hyper.sides selects the sides; needs
  * 1 + distinct ids entries of capacity).  It replaces glove_dense_grad_f32 in the data-parallel step whenever the
  * ranks' lists together are shorter than the dense buffer (an all-gather of lists instead of an all-reduce of
  * 2 V (d+1) floats), and it is how a rank returns its col gradients to the owners of a sharded col table. */
-size_t glove_packed_entry_floats(int32_t d);
+#define GLOVE_PACKED_ENTRY_FLOATS(d) ((size_t)(d) + 4)
 int glove_pack_grad_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                         void *ws, size_t ws_bytes, float *packed, int64_t capacity_entries, void *stream);
 /* The same list in two calls, for plans with chunk records and host counts (otherwise the pair falls back to
@@ -446,7 +430,7 @@ int glove_rowside_step_adagrad_f32(const glove_plan *plan, const glove_tables *t
 /* GLOVE_STEP_AUTO takes a fused form when (distinct row ids + distinct col ids of the plan) x d x 16 B — the rows a
  * step reads and writes — reaches this many bytes (and the plan carries chunk records or run words); callers that keep a twinned
  * table use the same number to know whether a step may have left versions flipped. */
-size_t glove_fused_step_bytes(void);
+#define GLOVE_FUSED_STEP_BYTES ((size_t)192 << 20)
 /* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
  * cleared.  A no-op without a twin.  Call before anything but glove_step(s)_adagrad_f32 reads or writes R / br. */
 int glove_canonicalize_f32(const glove_tables *t, void *stream);
@@ -455,37 +439,14 @@ int glove_canonicalize_f32(const glove_tables *t, void *stream);
  * receives the scalars of the LAST step. */
 int glove_steps_adagrad_f32(const glove_plan *const *plans, int32_t n, const glove_tables *t,
                             const glove_hyper *h, void *ws, size_t ws_bytes, float *loss_out, void *stream);
-/* ---- a stream whose batches are indexed as they are used (reshuffled epochs: reference data_utils.py:12-21) ---------------
- * n consecutive steps over the batches row/col/w/y[i B .. (i + 1) B), i = 0 .. n-1, the dedup index of batch i built into
- * staging plan i % ring.n on ring.streams[i % ring.n] while earlier steps run on `stream`: ring.n index builds are in flight,
- * the way an input pipeline prefetches batches.  The build of batch i + ring.n waits for the step that read the same staging
- * plan (event ring.stepped[i % n]), step i waits for its index (ring.built[i % n]); the first builds of a call wait for
- * everything enqueued on `stream` before the call (ring.start).  All streams and events are the caller's (the library
- * creates nothing); the loop of launches and event operations runs in C: from Python a step of the reference's default batch
- * costs more host time than its kernels take.  G_flat == NULL: Adagrad (glove_step_adagrad_f32 per step); otherwise
- * Keras-legacy Adam with G_flat as glove_step_adam_f32 uses it.  loss_out: the last step's scalars. */
-typedef struct glove_build_ring {
-    int32_t n;                      /* staging plans = build streams, 1 .. 16 */
-    const glove_plan *const *plans; /* [n] staging plans of B pairs at full capacity (cap_chunks >= B) */
-    void *const *plan_ws;           /* [n] build workspaces of plan_ws_bytes >= glove_plan_workspace_bytes(B, V) each */
-    size_t plan_ws_bytes;
-    void *const *streams;           /* [n] hipStream_t */
-    void *const *built;             /* [n] hipEvent_t */
-    void *const *stepped;           /* [n] hipEvent_t */
-    void *start;                    /* hipEvent_t */
-} glove_build_ring;
-int glove_steps_rebuilt_f32(const int32_t *row, const int32_t *col, const float *w, const float *y, int64_t B,
-                            int32_t n_steps, int32_t V, const glove_build_ring *ring, const glove_tables *t,
-                            const glove_hyper *h, void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
-
 /* One step under the Keras optimizer glove_hyper.optimizer names (passes + one apply launch; RMSprop: passes + the dense
  * gradient + one sweep over its slots).  G_flat: as glove_step_adam_f32 uses it — needed for GLOVE_OPT_RMSPROP and GLOVE_OPT_ADAM
- * (glove_dense_grad_floats floats, all zero on entry and on return), ignored otherwise.  GLOVE_OPT_ADAGRAD / GLOVE_OPT_ADAM go to
+ * (glove_dense_grad_layout floats, all zero on entry and on return), ignored otherwise.  GLOVE_OPT_ADAGRAD / GLOVE_OPT_ADAM go to
  * glove_step_adagrad_f32 / glove_step_adam_f32. */
 int glove_step_sparse_f32(const glove_plan *plan, const glove_tables *t, const glove_hyper *h,
                           void *ws, size_t ws_bytes, float *G_flat, float *loss_out, void *stream);
 
-/* One Keras-legacy Adam step.  G_flat (glove_dense_grad_floats floats, all zero on entry) is scratch and is all zero
+/* One Keras-legacy Adam step.  G_flat (glove_dense_grad_layout floats, all zero on entry) is scratch and is all zero
  * again on return.  A batch of at most (V_row + V) / 2 pairs takes two launches: the passes also mark the batch's
  * ids (in G_flat's bias segments), then one kernel applies the marked ids and gives every other row the G = 0
  * update; larger batches run passes + glove_dense_grad_f32 + glove_dense_adam_f32.  Same result bit for bit.

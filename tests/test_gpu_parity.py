@@ -14,6 +14,8 @@ from helpers import assert_tables_close, make_batch, oracle_tables, tables_from_
 
 pytestmark = pytest.mark.gpu
 
+from trainer.hip_api import FUSED_STEP_BYTES  # noqa: E402
+
 LOSS_RTOL = 1e-5
 PARAM_RTOL, PARAM_ATOL = 1e-5, 1e-6
 
@@ -747,6 +749,27 @@ def test_eval_metrics(hip):
     assert dt.global_step == 0      # EVAL mode leaves the step alone
 
 
+def test_eval_metrics_of_the_logistic_heads(hip):
+    """glove_eval_logistic_f32: the BinaryClassHead sums of the two heads (logistic_matrix_factorisation.py:50-54) over a
+    batch — sum pos xent(p, 1), sum pos, sum neg xent(p, 0), sum neg, sum pos sigmoid(p), sum neg sigmoid(p) — against float64."""
+    from trainer.hip_api import DeviceTables
+    B, V, d = 10000, 300, 64
+    row, col, pos, neg = make_batch(23, B, V)
+    neg = np.abs(neg).astype(np.float32)
+    t = oracle_tables(V, d, "Adagrad")
+    t.g = np.float64(np.float32(-0.2))
+    dt = tables_from_oracle(t, DeviceTables)
+    sums = hip.eval_sums_logistic(*to_dev(row, col, pos, neg), dt).cpu().numpy()
+    R, Cm = np.asarray(t.R, np.float64), np.asarray(t.C, np.float64)
+    p = (R[row] * Cm[col]).sum(1) + np.asarray(t.br, np.float64).reshape(-1)[row] + np.asarray(t.bc, np.float64).reshape(-1)[col] + float(t.g)
+    softplus = lambda x: np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+    sig = 1.0 / (1.0 + np.exp(-p))
+    pos64, neg64 = pos.astype(np.float64), neg.astype(np.float64)
+    want = [(pos64 * softplus(-p)).sum(), pos64.sum(), (neg64 * softplus(p)).sum(), neg64.sum(), (pos64 * sig).sum(), (neg64 * sig).sum()]
+    np.testing.assert_allclose(sums, want, rtol=1e-5)
+    assert dt.global_step == 0
+
+
 @pytest.mark.parametrize("V,d,k", [(500, 64, 20), (1000, 300, 5), (64, 8, 64), (100000, 64, 20), (3000, 128, 33)])
 def test_topk_cosine(hip, V, d, k):
     rng = np.random.default_rng(5)
@@ -1108,12 +1131,14 @@ def test_packing_passes_write_the_same_list(hip, B, V, d, cap, sides):
         torch.testing.assert_close(a[1:], b[1:], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("count_first", [False, True])
 @pytest.mark.parametrize("B,V,d,W", [(3000, 101, 64, 2), (2000, 5000, 50, 3), (5000, 403, 128, 4), (900, 31, 300, 8),
                                      (700, 300, 64, 11)])
-def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
+def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W, count_first):
     """W virtual ranks on one GPU, each with its own batch: their packed lists combined in rank order == the dense
     buffer they would have all-reduced (dense_grad of every plan into one G, in rank order), bit for bit, and both
-    match the float64 oracle on the joint batch."""
+    match the float64 oracle on the joint batch.  `count_first`: glove_count_packed_f32 ahead of the combines (ids that one
+    list alone touches are then applied straight from their entry and skip the dense buffer) — the same bits."""
     from trainer.hip_api import DeviceTables, make_hyper
     t = oracle_tables(V, d, "Adagrad")
     a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
@@ -1130,6 +1155,8 @@ def test_lists_of_several_ranks_sum_in_rank_order(hip, B, V, d, W):
             hip.passes(p, a, h)
             hip.pack_grad(p, a, h, recv[r])
         lists = [hip.packed_list(recv[r]) for r in range(W)]
+        if count_first:
+            hip.count_packed(lists, a, Ga, mark, cap)
         for r, lst in enumerate(lists):
             hip.combine_packed(lst, r, a, Ga, mark, cap)
         tail = None
@@ -1284,7 +1311,7 @@ def test_auto_step_form_straddling_the_fused_threshold_on_a_twinned_table(hip):
                               chunk_cap=32).compact(hip.lib, plain.d, records=True)
     big = [build(0, 262144), build(262144, 262144)]
     small = [build(600000 + 4096 * k, 4096) for k in range(3)]
-    thr = hip.lib.glove_fused_step_bytes()
+    thr = FUSED_STEP_BYTES
     assert all((p.host_counts[1] + p.host_counts[3]) * plain.d * 16 >= thr for p in big)
     assert all((p.host_counts[1] + p.host_counts[3]) * plain.d * 16 < thr for p in small)
     lists = [small[0], big[0], small[1], big[1], small[2], big[0], big[1], small[0]]
@@ -1446,7 +1473,7 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
     if plan.r_crec is not None:
         # (1c) the form bench.py times at the HBM-bound sizes: the fused step on a TWINNED row table (form 4, and the
         # library's own choice on such a table) == the three-launch form, bit for bit, at this size
-        fused_auto = (plan.host_counts[1] + plan.host_counts[3]) * a.d * 16 >= hip.lib.glove_fused_step_bytes()
+        fused_auto = (plan.host_counts[1] + plan.host_counts[3]) * a.d * 16 >= FUSED_STEP_BYTES
         for form in (4, 0):
             c = DeviceTables(V, d, "Adagrad", seed=5)
             c.enable_twin()
@@ -1503,55 +1530,3 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
             gb = e.sum() + kappa_b * n * ownb0[u].double()
             want_b = ownb0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
             np.testing.assert_allclose(gotb[u].item(), want_b.item(), rtol=2e-5, atol=1e-6, err_msg="%s bias %d" % (side, u))
-
-
-@pytest.mark.parametrize("B,V,cap,n", [(300, 40, 8, 3), (1024, 10000, 16, 8), (2048, 500, 32, 4), (3000, 97, 3, 5), (4096, 12000, 16, 11),
-                                       (5000, 300, 8, 3), (9000, 40000, 16, 9), (70000, 300000, 32, 4)])
-def test_many_small_plans_from_one_launch(hip, plan_checker, B, V, cap, n):
-    """glove_plan_build_many: the indexes of n consecutive batches of a stream from the launches of one — a workgroup per
-    batch in the one-workgroup builder, grid.z = batch in the tiled one, as many batches per set as the workspace has slices —
-    are the indexes n calls of glove_plan_build give, array for array and record for record, into poisoned plans."""
-    from trainer.hip_api import Plan
-    batches = [make_batch(900 + 7 * j, B, V, zipf=(j % 2 == 0)) for j in range(n)]
-    batches[1][0][::5] = V + 3                                  # ids outside the vocabulary in one of them
-    row, col, w, y = (torch.from_numpy(np.concatenate([b[k] for b in batches])).cuda() for k in range(4))
-    plans = [Plan(B, V, cap, "cuda:0", records=True, links=(j % 2 == 0)) for j in range(n)]
-    # (9 batches through a workspace of 4 slices: sets of 4, 4 and 1)
-    ws = torch.empty(hip.lib.glove_plan_workspace_bytes(B, V) * min(n, 4), dtype=torch.uint8, device="cuda:0")
-    errors = torch.zeros(8, dtype=torch.int32, device="cuda:0")
-    for p_ in plans:
-        _poison(p_, ws)
-    hip.build_plans(row, col, w, y, V, plans, ws=ws)
-    for j, p_ in enumerate(plans):
-        plan_checker(p_, V, errors)
-        _assert_plan_equals_oracle(p_, ref.build_plan(batches[j][0], batches[j][1], cap, V=V), B, batches[j][2], batches[j][3])
-        single = hip.build_plan(*to_dev(*batches[j]), V, chunk_cap=cap, records=True)
-        assert torch.equal(p_.counts, single.counts)
-    assert errors.tolist() == [0] * 8, errors.tolist()
-
-
-@pytest.mark.parametrize("n", [1, 2, 7, 1000, 65536, 1_190_011])
-def test_stream_shuffle_is_a_keyed_bijection(hip, n):
-    """glove_shuffle_stream: the four arrays come out under ONE bijection of the positions (every pair stays a pair, nothing is
-    lost or doubled), determined by the key: the same key gives the same order, another key another one, and positions really
-    move (the reference reshuffles its input every epoch: data_utils.py:12-21)."""
-    g = torch.Generator(device="cpu").manual_seed(n)
-    row = torch.arange(n, dtype=torch.int32, device="cuda:0")                  # row = the position itself: reads the bijection off
-    col = torch.randint(0, 1000, (n,), generator=g, dtype=torch.int32).cuda()
-    w, y = torch.rand(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
-    outs = []
-    for key in (0x0123456789abcdef0011223344556677, 0x0123456789abcdef0011223344556677, 5):
-        dst = tuple(torch.full_like(t, -1) for t in (row, col, w, y))
-        hip.shuffle_stream((row, col, w, y), dst, key)
-        pi = dst[0].long()
-        assert torch.equal(torch.sort(pi).values, torch.arange(n, device="cuda:0"))               # a bijection
-        assert torch.equal(dst[1], col[pi]) and torch.equal(dst[2], w[pi]) and torch.equal(dst[3], y[pi])  # pairs stay pairs
-        outs.append(pi)
-    assert torch.equal(outs[0], outs[1])
-    if n >= 1000:
-        assert not torch.equal(outs[0], outs[2])
-        moved = (outs[0] != torch.arange(n, device="cuda:0")).float().mean().item()
-        assert moved > 0.99                                                                        # (a random permutation fixes ~1 position)
-        # neighbours part: the mean distance of the images of adjacent positions is about n / 3 for a random permutation
-        gap = (outs[0][1:] - outs[0][:-1]).abs().float().mean().item()
-        assert 0.25 * n < gap < 0.42 * n, gap
