@@ -651,7 +651,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
                min_timed_ms=20.0, segment=0):
     """mode: "auto" (single-GPU sparse step on one rank, data parallel on several), "dp" (data-parallel form also on
     one rank), "sharded" (both tables sharded), "rowsharded" (row table sharded, col side data parallel)."""
-    from trainer.hip_api import FUSED_STEP_BYTES, DeviceTables, auto_chunk_cap, make_hyper
+    from trainer.hip_api import FUSED_STEP_BYTES, DeviceTables, auto_chunk_cap, make_hyper, row_width
     from trainer.stepper import HipBackend, RowShardedStepper, ShardedStepper, Stepper, owned_rows, route_by_row_owner
     hip, dev, dist, world, rank = ctx.hip, ctx.dev, ctx.dist, ctx.world, ctx.rank
     adam = optimizer == "Adam"
@@ -673,7 +673,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         V_col = V_row if mode == "sharded" else V
         if world > 1:
             coo = route_by_row_owner(coo, world, rank, dist)
-    cap = chunk_cap or auto_chunk_cap(B, V, (d + 3) // 4 * 4)
+    cap = chunk_cap or auto_chunk_cap(B, V, row_width(max(V_row, V_col), d))
     nnz = coo["row"].numel()
     if nnz < B:
         raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))

@@ -209,6 +209,25 @@ def _require(t, dtype, n=None):
         raise GloveHipError("expected %d elements, got %d" % (n, t.numel()))
 
 
+def row_width(rows: int, d: int) -> int:
+    """Floats per stored table row (the row stride the kernels take) for an embedding size `d`: rows start on 16-byte
+    boundaries at least; when the padding costs at most d / 12 floats they start on 64-byte boundaries, and on 128-byte lines
+    for tables beyond the Infinity Cache (>= 128 MB: what the fused twin form also looks at).  d = 300: 304 floats (1,216 B =
+    19 x 64) on a 60 MB table, 320 (1,280 B = 10 lines) on a 480 MB one; 64 and 128 stay as they are, 50 becomes 52.
+    Measured on the same batches (tools/exp_row_stride.py, one process): V = 400 k, B = 1 M: 1,200-byte rows 622 - 628 us per step,
+    1,216 B 608 - 609, 1,280 B 602 — 6.7 % more bytes per row and 3.7 % less time: rows that start mid-line cost two partial
+    lines per access, on the write side two partial write-backs; V = 50 k (cache-resident): 101.5 / 99.8 - 100.4 / 101.7 - 103.0.
+    The padding columns are zero and stay zero (glove_tables.d_model keeps lambda / d on the model's size)."""
+    base = (int(d) + 3) // 4 * 4
+    if os.environ.get("GLOVE_ROW_ALIGN") == "4":        # experiments (tools/): the former rule
+        return base
+    for align, ok in ((32, int(rows) * int(d) * 4 >= (128 << 20)), (16, True)):
+        cand = (int(d) + align - 1) // align * align
+        if ok and cand - int(d) <= int(d) // 12:
+            return cand
+    return base
+
+
 class DeviceTables:
     """The five variables + optimizer slots as device buffers (reference model_utils.py:31-39)."""
 
@@ -216,9 +235,9 @@ class DeviceTables:
 
     def __init__(self, V: int, d: int, optimizer: str, device="cuda:0", seed: int | None = None,
                  V_row: int | None = None, V_col: int | None = None):
-        """`d`: --embedding-size, any positive int.  Rows are stored 16-byte aligned: `self.d` is the row
-        stride (d rounded up to a multiple of 4, what the kernels and workspace queries take), `self.d_model`
-        the reference's embedding size; the padding columns are zero and stay zero (glove_tables.d_model).
+        """`d`: --embedding-size, any positive int.  Rows are stored aligned: `self.d` is the row stride
+        (`row_width`: d rounded up to a multiple of 4, 16 or 32 floats — what the kernels and workspace queries take),
+        `self.d_model` the reference's embedding size; the padding columns are zero and stay zero (glove_tables.d_model).
         `V_row` < V: this process holds only a shard of the row table (row ids handed to the kernels
         are then local indices into the shard).  `V_col` < V: it also holds only a shard of the col table
         (trainer.stepper.ShardedStepper, which runs the passes against fetched col rows); such tables go through
@@ -228,9 +247,9 @@ class DeviceTables:
         if optimizer not in OPTIMIZER_CODES:
             raise ValueError("optimizer must be one of %s (Keras names), got %r" % (", ".join(OPTIMIZER_CODES), optimizer))
         self.V, self.d_model, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
-        self.d = (int(d) + 3) // 4 * 4
         self.V_row = int(V if V_row is None else V_row)
         self.V_col = int(V if V_col is None else V_col)
+        self.d = row_width(max(self.V_row, self.V_col), d)
         if not 0 < self.V_row <= self.V or not 0 < self.V_col <= self.V:
             raise ValueError("V_row and V_col must be in (0, V]")
         gen = torch.Generator(device="cpu")

@@ -934,7 +934,7 @@ def test_full_size_row_sharded_two_virtual_ranks(hip, exchange, workload):
             hip.dense_adagrad(dt, make_hyper(sides=2, **kw), G, loss_out)
     else:
         cap = 1 + max(p.host_counts[3] for _, p in ranks)
-        lists = torch.zeros(W, cap, d + 4, device="cuda:0")
+        lists = torch.zeros(W, cap, ranks[0][0].d + 4, device="cuda:0")     # (the stored row width: hip_api.row_width)
         for r, (dt, plan) in enumerate(ranks):
             hip.passes(plan, dt, make_hyper(**kw))
             hip.pack_grad(plan, dt, make_hyper(sides=2, **kw), lists[r])
@@ -1074,7 +1074,7 @@ def test_touched_rows_exchange_equals_dense_and_sparse_bitwise(hip, B, V, d, cap
     n_r, n_c = plan.host_counts[1], plan.host_counts[3]
     head = steppers[0].bufs["send"][0, :2].view(torch.int32).tolist()
     assert head == [n_r, n_c]
-    ids = steppers[0].bufs["send"][1:1 + n_r + n_c, d + (-d) % 4 + 1].view(torch.int32).cpu().numpy()
+    ids = steppers[0].bufs["send"][1:1 + n_r + n_c, tabs[0].d + 1].view(torch.int32).cpu().numpy()
     np.testing.assert_array_equal(ids, np.r_[np.unique(row), np.unique(col)])
 
 
