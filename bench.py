@@ -160,10 +160,10 @@ def algorithmic_bytes(B, d, u_row, u_col):
 # separate `rocprofv3 --pmc` passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Looked up by key,
 # never by name matching; a configuration without a row reports traffic null and says so in `traffic_source`.
 TRAFFIC_PROFILES = {
-    ("zipf_v400k_d300", 1048576, "dealt"): "r04_c4_v400k_d300_b1m_index_rebuilt_traffic.json",
-    ("zipf_v400k_d300", 1048576, "static"): "r04_c4_v400k_d300_b1m_static_index_traffic.json",
-    ("zipf_v2m_d128", 1048576, "dealt"): "r04_c5_v2m_d128_b1m_index_rebuilt_traffic.json",
-    ("zipf_v2m_d128", 1048576, "static"): "r03_c5_v2m_d128_b1m_traffic.json",
+    ("zipf_v400k_d300", 1048576, "dealt"): "r05_c4_v400k_d300_b1m_index_rebuilt_traffic.json",
+    ("zipf_v400k_d300", 1048576, "static"): "r05_c4_v400k_d300_b1m_static_index_traffic.json",
+    ("zipf_v2m_d128", 1048576, "dealt"): "r05_c5_v2m_d128_b1m_index_rebuilt_traffic.json",
+    ("zipf_v2m_d128", 1048576, "static"): "r05_c5_v2m_d128_b1m_static_index_traffic.json",
     ("text8_v50k_d300", 131072, "dealt"): "r04_c3_v50k_d300_b131072_index_rebuilt_traffic.json",
     ("text8_v50k_d300", 131072, "static"): "r03_c3_v50k_d300_b131072_traffic.json",
     ("text8_d64", 131072, "dealt"): "r04_text8_d64_b131072_index_rebuilt_traffic.json",
