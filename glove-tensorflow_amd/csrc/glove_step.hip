@@ -3132,7 +3132,11 @@ static int pick_step_form(const glove_plan *p, const glove_tables *t, const glov
     if (!records && h->step_form == GLOVE_STEP_TAGGED) return GLOVE_STEP_TWO_LAUNCH;        // (the one-launch form walks records)
     if (h->step_form != GLOVE_STEP_AUTO) return h->step_form;
     // the latency-bound regime on step-tagged tables: everything in one launch
-    if (t->R_tag && t->C_tag && p->B <= 2048 && records) return GLOVE_STEP_TAGGED;     // (measured against the two-launch form, 64 staging plans: 512 / 1,024 / 2,048 pairs -16 / -16 / -13 %, 4,096 +12 %)
+    // ... unless the batch is known to hold heavy ids (more than plan.heavy_chunks chunks: a frequent token with hundreds of the
+    // batch's pairs): the tagged form walks ALL chunks of an id in one lane group, one record trip after the other, and beyond
+    // heavy_chunks its summation order is no longer the two-launch form's.  (A plan refilled on the device keeps its counts
+    // there: host_counts[4] < 0, judged by the batch size alone.)
+    if (t->R_tag && t->C_tag && p->B <= 2048 && records && p->host_counts[4] <= 0) return GLOVE_STEP_TAGGED;     // (measured against the two-launch form, 64 staging plans: 512 / 1,024 / 2,048 pairs -16 / -16 / -13 %, 4,096 +12 %)
     // the fused forms pay off once the touched rows and their partials no longer live in the caches; the id counts
     // are known on the host for a plan whose build has been synchronised (a resident plan)
     // (a plan refilled on the device every step — a reshuffled epoch — is judged by the most ids its batch can hold)
@@ -3361,6 +3365,7 @@ static bool adam_one_launch(const glove_plan *p, const glove_tables *t, const gl
     if (!p || !t || !h || sides_of(h) != 3) return false;
     if (!t->R_tag || !t->C_tag || !p->r_crec || !p->c_crec || !p->r_mark || !p->c_mark) return false;
     if (h->step_form != GLOVE_STEP_AUTO && h->step_form != GLOVE_STEP_TAGGED) return false;
+    if (h->step_form == GLOVE_STEP_AUTO && p->host_counts[4] > 0) return false;     // heavy ids: as pick_step_form
     return p->B <= 2048 && 2 * p->B <= (int64_t)v_row(t) + t->V;
 }
 

@@ -158,3 +158,51 @@ def test_chained_tagged_steps_equal_single_ones(hip, B, V, d, n):
     assert torch.equal(a.scalars, b.scalars) and torch.equal(la, lb)
     np.testing.assert_allclose(la.cpu().numpy(), lc.cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(a.scalars.cpu().numpy(), c.scalars.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("optimizer", ["Adagrad", "Adam"])
+def test_auto_leaves_a_skewed_batch_to_the_two_launch_form(hip, optimizer):
+    """One token holding half of the batch's pairs (a frequent word): the one-launch forms would walk its 32 chunks in ONE lane
+    group, one record trip after the other, and sum them in another order than the two-launch form.  GLOVE_STEP_AUTO therefore takes
+    them only for batches without heavy ids (plan.host_counts[4] == 0 where the host knows it): here the step on tagged tables
+    is the two-launch form's, bit for bit, and equals the oracle; a balanced batch beside it still takes one launch."""
+    from trainer.hip_api import DeviceTables, make_hyper
+    B, V, d, cap = 1024, 2000, 64, 16
+    hp = ref.Hyper(learning_rate=0.05 if optimizer == "Adagrad" else 0.001)
+    row, col, w, y = make_batch(77, B, V, zipf=False)
+    row = row.copy()
+    row[::2] = 5                                               # id 5 holds every second pair: 512 pairs = 32 chunks
+    t = oracle_tables(V, d, optimizer)
+    a, b = tables_from_oracle(t, DeviceTables), tables_from_oracle(t, DeviceTables)
+    a.enable_tags()
+    kw = dict(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=hp.learning_rate, epsilon=hp.epsilon, batch_size=B)
+    plan = hip.build_plan(*to_dev(row, col, w, y), V, chunk_cap=cap, records=True).compact(hip.lib, records=True)
+    assert plan.host_counts[4] >= 1 and plan.host_counts[6] >= 32
+    la, lb = torch.zeros(4, device="cuda:0"), torch.zeros(4, device="cuda:0")
+    if optimizer == "Adagrad":
+        hip.step_adagrad(plan, a, make_hyper(step_form=0, **kw), la)
+        hip.step_adagrad(plan, b, make_hyper(step_form=1, **kw), lb)
+    else:
+        Ga, Gb = hip.dense_grad_buffer(a), hip.dense_grad_buffer(b)
+        hip.step_adam(plan, a, make_hyper(step_form=0, **kw), Ga, la)
+        hip.step_adam(plan, b, make_hyper(step_form=1, **kw), Gb, lb)
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+        assert torch.equal(a.s1[n], b.s1[n]), n
+    assert torch.equal(la, lb) and a.global_step == b.global_step == 1
+    loss, L, reg = ref.train_step(t, row, col, w, y, hp)
+    np.testing.assert_allclose(la.cpu().numpy()[:3], [loss, L, reg], rtol=1e-5)
+    assert_tables_close(a, t, 1e-5, 1e-6)
+    # a balanced batch on the same tables: one launch (rows are tagged / the twins flip)
+    row2, col2, w2, y2 = make_batch(78, B, V, zipf=False)
+    plan2 = hip.build_plan(*to_dev(row2, col2, w2, y2), V, chunk_cap=cap, records=True).compact(hip.lib, records=True)
+    assert plan2.host_counts[4] == 0
+    if optimizer == "Adagrad":
+        hip.step_adagrad(plan2, a, make_hyper(step_form=0, **kw), la)
+        assert int((a.R_tag != 0).sum()) == int(plan2.counts[1])
+    else:
+        before = float(a.scalars[3])
+        hip.step_adam(plan2, a, make_hyper(step_form=0, **kw), Ga, la)
+        assert float(a.scalars[3]) != before
+    ref.train_step(t, row2, col2, w2, y2, hp)
+    assert_tables_close(a, t, 2e-5, 2e-6)
