@@ -1151,17 +1151,76 @@ __global__ void sum_headers_kernel(PackedLists pls, float *__restrict__ acc4, in
     acc4[0] = t[0]; acc4[1] = t[1]; acc4[2] = t[2]; acc4[3] = t[3];
 }
 
+// ---- the element updates of the per-row Keras optimizers (SGD, Adamax, Adadelta, Ftrl): include/glove_hip.h glove_hyper.optimizer;
+// used by the apply epilogues of the single-GPU step (SparseOptApply) and of the touched-rows exchange (apply_packed_kernel)
+struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; float rho; };
+template <int OPT> struct OptSlots {
+    static constexpr bool two = OPT == GLOVE_OPT_ADAMAX || OPT == GLOVE_OPT_ADADELTA || OPT == GLOVE_OPT_FTRL;
+};
+template <int OPT>
+struct OptElem {
+    // Adadelta (kernel SparseApplyAdadelta): a = accum_grad, u = accum_var
+    __device__ static void adadelta(float &w, float &a, float &u, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        a = a * o.rho + g * g * (1.0f - o.rho);
+        const float upd = sqrtf(u + o.eps) / sqrtf(a + o.eps) * g;
+        w -= upd * o.lr;
+        u = u * o.rho + upd * upd * (1.0f - o.rho);
+    }
+    // Ftrl at its Keras defaults (kernel FtrlCompute; lr_power -0.5, l1 = l2 = 0): a = accumulator, z = linear
+    __device__ static void ftrl(float &w, float &a, float &z, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        const float na = a + g * g;
+        z += g - (sqrtf(na) - sqrtf(a)) / o.lr * w;
+        w = fabsf(z) > 0.f ? -z / (sqrtf(na) / o.lr) : 0.f;
+        a = na;
+    }
+    __device__ static void sgd(float &w, float &a, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        if (o.momentum == 0.f) { w -= o.lr * g; return; }
+        a = a * o.momentum - o.lr * g;
+        w += o.nesterov ? a * o.momentum - o.lr * g : a;
+    }
+    __device__ static void adamax(float &w, float &m, float &v, float g, const OptConsts &o)
+    {
+#pragma clang fp contract(off)
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = fmaxf(o.b2 * v, fabsf(g));
+        w -= o.lr_t * m / (v + o.eps);
+    }
+    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o)
+    {
+        if (OPT == GLOVE_OPT_SGD) sgd(w, a, g, o);
+        else if (OPT == GLOVE_OPT_ADAMAX) adamax(w, a, b, g, o);
+        else if (OPT == GLOVE_OPT_ADADELTA) adadelta(w, a, b, g, o);
+        else ftrl(w, a, b, g, o);
+    }
+};
+
 // A lane group walks entries gg, gg + TG, gg + 2 TG, ... (TG lane groups in the launch).  Looked up one entry at a time
 // that is three dependent round trips per entry (id -> mark -> rows) and ~16 entries per group at C5, a latency chain.
 // Instead the group's LPR lanes look LPR entries up at once — lane t the id, side, bias gradient and mark of the t-th
 // of them — and the rows are then moved two entries at a time, what each needs handed round by lane shuffles: one
 // round trip per pair of entries.
-template <int LPR, int NV>
-__global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
-    PackedLists pls, DenseViews dv, SideBufs rs, SideBufs cs, int d4, StepConsts k, int first_tag,
-    const float *__restrict__ tail_in, float *__restrict__ scalars, float *__restrict__ loss_out, int do_scalars)
+// OPT: GLOVE_OPT_ADAGRAD, or one of the per-row Keras optimizers (OptElem: SGD, Adamax, Adadelta, Ftrl) — only touched rows move
+// under all of them, so the exchange is the same and the epilogue differs.  s2: the second slot of every variable where the
+// optimizer has one (scalars[2] for the global bias).
+struct SlotTwo { float *R, *C, *br, *bc; };
+template <int LPR, int NV, int OPT>
+__global__ __launch_bounds__(kBlock) void apply_packed_kernel(
+    PackedLists pls, DenseViews dv, SideBufs rs, SideBufs cs, SlotTwo s2, int d4, StepConsts k, OptConsts o, double ln_beta1,
+    const int64_t *__restrict__ step, int first_tag, const float *__restrict__ tail_in, float *__restrict__ scalars,
+    float *__restrict__ loss_out, int do_scalars)
 {
     constexpr int GPB = kBlock / LPR;
+    constexpr bool kAdagrad = OPT == GLOVE_OPT_ADAGRAD;
+    constexpr bool kTwo = !kAdagrad && OptSlots<OPT>::two;
+    const bool slots = kAdagrad || !(OPT == GLOVE_OPT_SGD && o.momentum == 0.f);     // (plain SGD keeps no slot)
+    // t = global_step as the passes of this step left it (Adamax: lr_t = lr / (1 - beta1^t), as apply_sparse_opt_kernel)
+    if (OPT == GLOVE_OPT_ADAMAX) o.lr_t = o.lr / -expm1f((float)((double)(*step) * ln_beta1));
     const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const size_t stride4 = (size_t)d4 + 1;
     const PackedList &pl = pls.l[blockIdx.y];
@@ -1187,14 +1246,15 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
             int todo[2];
             int32_t id[2];
             bool is_row[2];
-            float Gb[2], bval[2], Ab[2];
-            f4 G[2][NV], Wv[2][NV], A[2][NV];
+            float Gb[2], bval[2], Ab[2], Bb[2];
+            f4 G[2][NV], Wv[2][NV], A[2][NV], Bv[2][kTwo ? NV : 1];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 todo[e] = __shfl(todo_l, tt + e, LPR);
                 id[e] = __shfl(id_l, tt + e, LPR);
                 is_row[e] = __shfl(row_l, tt + e, LPR) != 0;
                 Gb[e] = __shfl(gb_l, tt + e, LPR);
+                Ab[e] = Bb[e] = 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -1213,21 +1273,46 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
                     Gb[e] = (is_row[e] ? dv.G_br : dv.G_bc)[id[e]];
                 }
                 load_row<LPR, NV>(Wv[e], W, id[e], d4, lg);
-                load_row<LPR, NV>(A[e], S1, id[e], d4, lg);
                 bval[e] = (is_row[e] ? rs.bias : cs.bias)[id[e]];
-                Ab[e] = (is_row[e] ? rs.S1b : cs.S1b)[id[e]];
+                if (slots) {
+                    load_row<LPR, NV>(A[e], S1, id[e], d4, lg);
+                    Ab[e] = (is_row[e] ? rs.S1b : cs.S1b)[id[e]];
+                }
+                if constexpr (kTwo) {
+                    load_row<LPR, NV>(Bv[e], is_row[e] ? s2.R : s2.C, id[e], d4, lg);
+                    Bb[e] = (is_row[e] ? s2.br : s2.bc)[id[e]];
+                }
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 if (!todo[e]) continue;
                 float *W = is_row[e] ? rs.W : cs.W, *S1 = is_row[e] ? rs.S1 : cs.S1;
+                if constexpr (kAdagrad) {
 #pragma unroll
-                for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[e][kk], A[e][kk], G[e][kk], k.lr, k.eps);
-                store_row<LPR, NV>(S1, (size_t)id[e], d4, lg, A[e]);
+                    for (int kk = 0; kk < NV; ++kk) adagrad_vec(Wv[e][kk], A[e][kk], G[e][kk], k.lr, k.eps);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < NV; ++kk) {
+                        float w[4] = {Wv[e][kk].x, Wv[e][kk].y, Wv[e][kk].z, Wv[e][kk].w};
+                        float a[4] = {A[e][kk].x, A[e][kk].y, A[e][kk].z, A[e][kk].w};
+                        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (kTwo) { bb[0] = Bv[e][kk].x; bb[1] = Bv[e][kk].y; bb[2] = Bv[e][kk].z; bb[3] = Bv[e][kk].w; }
+                        const float g[4] = {G[e][kk].x, G[e][kk].y, G[e][kk].z, G[e][kk].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) OptElem<OPT>::one(w[i], a[i], bb[i], g[i], o);
+                        Wv[e][kk] = f4{w[0], w[1], w[2], w[3]};
+                        A[e][kk] = f4{a[0], a[1], a[2], a[3]};
+                        if constexpr (kTwo) Bv[e][kk] = f4{bb[0], bb[1], bb[2], bb[3]};
+                    }
+                }
+                if (slots) store_row<LPR, NV>(S1, (size_t)id[e], d4, lg, A[e]);
+                if constexpr (kTwo) store_row<LPR, NV>(is_row[e] ? s2.R : s2.C, (size_t)id[e], d4, lg, Bv[e]);
                 store_row<LPR, NV>(W, (size_t)id[e], d4, lg, Wv[e]);
                 if (lg == 0) {
-                    adagrad_elem(bval[e], Ab[e], Gb[e], k.lr, k.eps);
-                    (is_row[e] ? rs.S1b : cs.S1b)[id[e]] = Ab[e];
+                    if constexpr (kAdagrad) adagrad_elem(bval[e], Ab[e], Gb[e], k.lr, k.eps);
+                    else OptElem<OPT>::one(bval[e], Ab[e], Bb[e], Gb[e], o);
+                    if (slots) (is_row[e] ? rs.S1b : cs.S1b)[id[e]] = Ab[e];
+                    if constexpr (kTwo) (is_row[e] ? s2.br : s2.bc)[id[e]] = Bb[e];
                     (is_row[e] ? rs.bias : cs.bias)[id[e]] = bval[e];
                     dv.mark[(is_row[e] ? 0 : dv.V_row) + id[e]] = 0;
                 }
@@ -1250,7 +1335,13 @@ __global__ __launch_bounds__(kBlock) void apply_packed_adagrad_kernel(
         float loss, L, reg;
         loss_from_partials(tot, k, g, loss, L, reg);
         const float dg = t[0] + 2.0f * k.m * k.l2 * g;
-        adagrad_elem(scalars[0], scalars[1], dg, k.lr, k.eps);
+        if constexpr (kAdagrad) {
+            adagrad_elem(scalars[0], scalars[1], dg, k.lr, k.eps);
+        } else {
+            float gn = g, a = scalars[1], b = scalars[2];
+            OptElem<OPT>::one(gn, a, b, dg, o);
+            scalars[0] = gn; scalars[1] = a; scalars[2] = b;
+        }
         if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = t[0]; }
     }
 }
@@ -2070,9 +2161,6 @@ __global__ __launch_bounds__(kBlock) void dense_adam_kernel(
 // epilogues on the same traversal as AdagradApply.  Semantics: include/glove_hip.h glove_hyper.optimizer; restated in
 // oracle/glove_ref.py (_sgd, _rmsprop_dense_decay, _adamax).
 // ------------------------------------------------------------------------------------------
-struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; float rho; };
-template <int OPT> struct OptSlots { static constexpr bool two = OPT == GLOVE_OPT_ADAMAX || OPT == GLOVE_OPT_ADADELTA || OPT == GLOVE_OPT_FTRL; };
-
 template <int LPR, int NV, int OPT>
 struct SparseOptApply {
     SideBufs rs, cs;
@@ -2091,45 +2179,7 @@ struct SparseOptApply {
             st.Bb = (is_row ? S2_br : S2_bc)[id];
         }
     }
-    // Adadelta (kernel SparseApplyAdadelta): a = accum_grad, u = accum_var
-    __device__ static void adadelta(float &w, float &a, float &u, float g, const OptConsts &o)
-    {
-#pragma clang fp contract(off)
-        a = a * o.rho + g * g * (1.0f - o.rho);
-        const float upd = sqrtf(u + o.eps) / sqrtf(a + o.eps) * g;
-        w -= upd * o.lr;
-        u = u * o.rho + upd * upd * (1.0f - o.rho);
-    }
-    // Ftrl at its Keras defaults (kernel FtrlCompute; lr_power -0.5, l1 = l2 = 0): a = accumulator, z = linear
-    __device__ static void ftrl(float &w, float &a, float &z, float g, const OptConsts &o)
-    {
-#pragma clang fp contract(off)
-        const float na = a + g * g;
-        z += g - (sqrtf(na) - sqrtf(a)) / o.lr * w;
-        w = fabsf(z) > 0.f ? -z / (sqrtf(na) / o.lr) : 0.f;
-        a = na;
-    }
-    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o)
-    {
-        if (OPT == GLOVE_OPT_SGD) sgd(w, a, g, o);
-        else if (OPT == GLOVE_OPT_ADAMAX) adamax(w, a, b, g, o);
-        else if (OPT == GLOVE_OPT_ADADELTA) adadelta(w, a, b, g, o);
-        else ftrl(w, a, b, g, o);
-    }
-    __device__ static void sgd(float &w, float &a, float g, const OptConsts &o)
-    {
-#pragma clang fp contract(off)
-        if (o.momentum == 0.f) { w -= o.lr * g; return; }
-        a = a * o.momentum - o.lr * g;
-        w += o.nesterov ? a * o.momentum - o.lr * g : a;
-    }
-    __device__ static void adamax(float &w, float &m, float &v, float g, const OptConsts &o)
-    {
-#pragma clang fp contract(off)
-        m = o.b1 * m + (1.0f - o.b1) * g;
-        v = fmaxf(o.b2 * v, fabsf(g));
-        w -= o.lr_t * m / (v + o.eps);
-    }
+    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o) { OptElem<OPT>::one(w, a, b, g, o); }
     __device__ void finish(bool is_row, int32_t id, int32_t wid, int q, f4 (&G)[NV], f4 (&Wv)[NV], float Gb, float bval, State &st) const
     {
         const SideBufs &sb = is_row ? rs : cs;
@@ -2874,6 +2924,15 @@ int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_f
 {
     DenseSegs segs; float *tail; int nbx, sides;
     if (int rc = plain_table(t, stream)) return rc;
+    if (h && h->optimizer == GLOVE_OPT_RMSPROP) {
+        // the other dense-decay optimizer of the Keras set: its whole rms slot decays every step, entries with a gradient move —
+        // the sweep of glove_step_sparse_f32, here on a G_flat that holds the ranks' summed gradients (data-parallel step)
+        if (int rc = dense_common(t, h, G_flat, false, segs, tail, nbx, sides)) return rc;
+        if (!(h->rho > 0.f && h->rho < 1.f) || sides != 3) return GLOVE_E_BADARG;
+        hipLaunchKernelGGL(dense_rmsprop_kernel, dim3(nbx, 4), dim3(kBlock), 0, (hipStream_t)stream, segs, make_consts(t, h), h->rho,
+                           t->scalars, tail, loss_out, 1);
+        return (int)hipGetLastError();
+    }
     if (int rc = dense_common(t, h, G_flat, true, segs, tail, nbx, sides)) return rc;
     if (!(h->beta1 > 0.0 && h->beta1 < 1.0 && h->beta2 > 0.0 && h->beta2 < 1.0)) return GLOVE_E_BADARG;
     const StepConsts k = make_consts(t, h);
@@ -3048,6 +3107,18 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
     if (int rc = packed_common(t, G_flat, mark, dv)) return rc;
     if (!h || !lists || n_lists < 1 || capacity_entries < 0) return GLOVE_E_BADARG;
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
+    // glove_hyper.optimizer: Adagrad, or one of the per-row Keras optimizers (only touched rows move: the exchange is the same)
+    const int opt = h->optimizer;
+    const bool two_slots = opt == GLOVE_OPT_ADAMAX || opt == GLOVE_OPT_ADADELTA || opt == GLOVE_OPT_FTRL;
+    if (opt != GLOVE_OPT_ADAGRAD && opt != GLOVE_OPT_SGD && !two_slots) return GLOVE_E_BADARG;
+    if (two_slots && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;
+    if (opt == GLOVE_OPT_ADAMAX && (!(h->beta1 > 0.0 && h->beta1 < 1.0) || !(h->beta2 > 0.0 && h->beta2 < 1.0) || !t->step)) return GLOVE_E_BADARG;
+    if (opt == GLOVE_OPT_ADADELTA && !(h->rho > 0.f && h->rho < 1.f)) return GLOVE_E_BADARG;
+    if (opt == GLOVE_OPT_FTRL && !(h->learning_rate > 0.f)) return GLOVE_E_BADARG;
+    if (opt == GLOVE_OPT_SGD && !(h->momentum >= 0.f && h->momentum < 1.f)) return GLOVE_E_BADARG;
+    const OptConsts o = {h->learning_rate, h->epsilon, h->momentum, 0.f, (float)h->beta1, (float)h->beta2, h->nesterov ? 1 : 0, h->rho};
+    const double ln_b1 = opt == GLOVE_OPT_ADAMAX ? log((double)(float)h->beta1) : 0.0;
+    const SlotTwo s2 = {t->s2_R, t->s2_C, t->s2_br, t->s2_bc};
     if (int rc = plain_table(t, stream)) return rc;
     const int d4 = t->d / 4;
     const RowShape shape = pick_row_shape(d4);
@@ -3082,10 +3153,17 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
         }
         const int nbx = blocks_for(n_max > 0 ? n_max : 1, kBlock / shape.lpr);
         const int scal = first == 0 ? do_scalars : 0;
+#define LAUNCH_OPT(LPR, NV, OPT)                                                                                     \
+        hipLaunchKernelGGL((apply_packed_kernel<LPR, NV, OPT>), dim3(nbx, pls.n), dim3(kBlock), 0, st, pls, dv, rs, cs, s2, \
+                           d4, k, o, ln_b1, (const int64_t *)t->step, (int)first, tail, t->scalars, loss_out, scal)
 #define CALL(LPR, NV)                                                                                               \
-        hipLaunchKernelGGL((apply_packed_adagrad_kernel<LPR, NV>), dim3(nbx, pls.n), dim3(kBlock), 0, st, pls, dv, rs, cs, \
-                           d4, k, (int)first, tail, t->scalars, loss_out, scal)
+        if (opt == GLOVE_OPT_ADAGRAD) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADAGRAD);                                       \
+        else if (opt == GLOVE_OPT_SGD) LAUNCH_OPT(LPR, NV, GLOVE_OPT_SGD);                                          \
+        else if (opt == GLOVE_OPT_ADAMAX) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADAMAX);                                    \
+        else if (opt == GLOVE_OPT_ADADELTA) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADADELTA);                                \
+        else LAUNCH_OPT(LPR, NV, GLOVE_OPT_FTRL)
         GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef LAUNCH_OPT
 #undef CALL
     }
     if (scratch) {

@@ -66,7 +66,9 @@ class HipBackend:
     def apply_dense(self, tables, hyper, G, loss_out):
         if tables.optimizer == "Adagrad":
             self.hip.dense_adagrad(tables, hyper, G, loss_out)
-        elif tables.optimizer == "Adam":
+        elif tables.optimizer in ("Adam", "RMSprop"):    # the dense-decay optimizers: every row's slots move every step
+            from trainer.hip_api import OPTIMIZER_CODES
+            hyper.optimizer = OPTIMIZER_CODES[tables.optimizer]
             self.hip.dense_adam(tables, hyper, G, loss_out)
         else:
             raise ValueError("no dense apply for %s" % tables.optimizer)
@@ -323,8 +325,15 @@ class GraphedSteps:
 
 class Stepper(GraphedSteps):
     """`exchange`: "dense" = all-reduce of the flat dense gradient buffer; "rows" = all-gather of packed touched-row
-    lists (Adagrad); "auto" = rows when `prepare(plans)` finds the ranks' lists together shorter than the dense
-    buffer, else dense."""
+    lists; "auto" = rows when `prepare(plans)` finds the ranks' lists together shorter than the dense buffer, else dense.
+    Which optimizers (`tf.keras.optimizers.get`, reference train_utils.py:13-16) run on several ranks, and how:
+    Adagrad either way; the per-row ones (SGD, Adamax, Adadelta, Ftrl: only touched rows move) on the touched-rows
+    exchange, whose apply takes their epilogue; the dense-decay ones (Adam, RMSprop: every row's slots move every step) on
+    the dense all-reduce.  Nadam (m, v decay everywhere, touched rows move: it needs the union of the ranks' id marks) runs on
+    one GPU only."""
+
+    ROWS_ONLY = ("SGD", "Adamax", "Adadelta", "Ftrl")       # per-row optimizers: touched-rows exchange
+    DENSE_ONLY = ("Adam", "RMSprop")                        # dense-decay optimizers: dense all-reduce
 
     def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None, exchange="auto",
                  collectives=False):
@@ -337,16 +346,21 @@ class Stepper(GraphedSteps):
             raise ValueError("world > 1 needs an initialised torch.distributed module")
         if exchange not in ("auto", "dense", "rows"):
             raise ValueError("exchange must be auto, dense or rows")
-        if exchange == "rows" and tables.optimizer != "Adagrad":
-            raise ValueError("the touched-rows exchange is for Adagrad (Keras' Adam moves every row every step)")
-        if self._multi and tables.optimizer not in ("Adagrad", "Adam"):
-            raise ValueError("the multi-GPU forms are implemented for Adagrad and Adam, got %s" % tables.optimizer)
+        if exchange == "rows" and tables.optimizer in self.DENSE_ONLY:
+            raise ValueError("the touched-rows exchange is for optimizers that move touched rows only (Keras' %s moves every row "
+                             "every step)" % tables.optimizer)
+        if exchange == "dense" and self._multi and tables.optimizer in self.ROWS_ONLY:
+            raise ValueError("%s runs on the touched-rows exchange (its dense form would need the ranks' id marks)" % tables.optimizer)
+        if self._multi and tables.optimizer not in ("Adagrad",) + self.ROWS_ONLY + self.DENSE_ONLY:
+            raise ValueError("the data-parallel form takes Adagrad, SGD, Adamax, Adadelta, Ftrl, Adam and RMSprop, got %s" % tables.optimizer)
+        if self._multi and tables.optimizer in self.ROWS_ONLY:
+            exchange = "rows"
         self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=tables.device)
         # Adam (dense whole-table decay) and every multi-rank step go through the dense buffer; RMSprop (whole-slot decay) too,
         # inside its own entry point
         self.dense = self._multi or tables.optimizer == "Adam"
-        self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer in ("RMSprop", "Nadam") else None
+        self._rms_G = backend.dense_grad_buffer(tables) if tables.optimizer in ("RMSprop", "Nadam") and not self._multi else None
         form = int(hyper_kwargs.get("step_form", 0) or 0)
         if not self.dense and hasattr(tables, "maybe_enable_twin"):
             if form in (0, 5):
@@ -364,7 +378,8 @@ class Stepper(GraphedSteps):
         Stream whose batches are indexed as they are used (`plans` None, `batch_size` given: reshuffled epochs): from the
         most ids a batch of that size can touch — the lists' capacity has to hold any batch."""
         world = self.world if force_world is None else force_world
-        if self.tables.optimizer != "Adagrad" or self.exchange == "dense" or (world == 1 and not self._multi and self.exchange != "rows"):
+        if self.tables.optimizer in self.DENSE_ONLY + ("Nadam",) or self.exchange == "dense" or (
+                world == 1 and not self._multi and self.exchange != "rows"):
             return
         if self.G is None:
             self.G, self.dense = self.backend.dense_grad_buffer(self.tables), True

@@ -349,6 +349,8 @@ int glove_dense_grad_f32(const glove_plan *plan, const glove_tables *t, const gl
                          void *ws, size_t ws_bytes, float *G_flat, void *stream);
 int glove_dense_adagrad_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,
                             float *loss_out, void *stream);
+/* (Keras-legacy Adam; with glove_hyper.optimizer = GLOVE_OPT_RMSPROP the legacy RMSprop sweep instead: the whole rms slot decays,
+ * entries with a non-zero summed gradient move) */
 int glove_dense_adam_f32(const glove_tables *t, const glove_hyper *h, float *G_flat,
                          float *loss_out, void *stream);
 
@@ -404,7 +406,9 @@ int glove_count_packed_f32(const glove_packed_list *lists, int32_t n_lists, cons
  * zeroing.  capacity_entries bounds the entry count of a list whose count lives in its header. */
 int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const glove_tables *t, float *G_flat,
                              int32_t *mark, int64_t capacity_entries, void *stream);
-/* Adagrad on every id the lists touched (lists[i] was combined with tag i): each id is applied from the list that
+/* The optimizer glove_hyper.optimizer names — Adagrad, or one of the per-row Keras optimizers (GLOVE_OPT_SGD, _ADAMAX, _ADADELTA,
+ * _FTRL: only touched rows move under them, so they ride the same exchange; their second slots are glove_tables.s2_*) — on
+ * every id the lists touched (lists[i] was combined with tag i): each id is applied from the list that
  * touched it first, its mark is cleared.  tail: device float[4] {sum_e, sum w diff^2, sum |r|^2+|c|^2, sum b^2}
  * already summed over the ranks, or NULL = summed here over the lists' headers in list order.  With the col side
  * selected (hyper.sides) the call also updates the global bias and writes loss_out. */

@@ -24,9 +24,9 @@ class OracleBackend:
         return tuple(np.asarray(a) for a in (row, col, w, y))
 
     def make_hyper(self, batch_size, l2_reg=0.01, reg_mult=2.0, learning_rate=0.001, sides=0, head=0, neg_factor=1.0, step_form=0,
-                   optimizer="Adagrad"):
+                   optimizer="Adagrad", momentum=0.0, nesterov=False, rho=None):
         return dict(hp=ref.Hyper(l2_reg=l2_reg, reg_mult=reg_mult, learning_rate=learning_rate, head=head,
-                                 neg_factor=neg_factor),
+                                 neg_factor=neg_factor, momentum=momentum, nesterov=nesterov, rho=rho),
                     inv_batch=1.0 / batch_size, sides=sides or 3)
 
     # flat layout [G_R | G_br | G_C | G_bc | tail 8], as the product's (without alignment padding)
@@ -153,6 +153,19 @@ class OracleBackend:
                     G[sd][key] = (G[sd][key][0] + e[:d], G[sd][key][1] + e[d])
                 else:
                     G[sd][key] = (e[:d].copy(), e[d])
+        if t.optimizer != "Adagrad":
+            # the per-row Keras optimizers on the touched-rows exchange (both sides in one step): the lists' sums as dense
+            # gradients + the union of the ranks' ids, then the optimizer as one rank applies it to the joint batch
+            assert sides == 3, "side-restricted applies exist for Adagrad only"
+            gr = dict(G_R=np.zeros_like(t.R), G_C=np.zeros_like(t.C), G_br=np.zeros_like(t.br), G_bc=np.zeros_like(t.bc),
+                      touched_r=np.zeros(len(t.R), bool), touched_c=np.zeros(len(t.C), bool),
+                      sum_e=tail[0], dg_reg=2.0 * hp.reg_mult * hp.l2_reg * t.g)
+            for sd, GW, Gb, touched in ((0, "G_R", "G_br", "touched_r"), (1, "G_C", "G_bc", "touched_c")):
+                for key, (g, gb) in G[sd].items():
+                    gr[GW][key], gr[Gb][key], gr[touched][key] = g, gb, True
+            loss_out[1] = tail[1] * inv_batch
+            ref.apply_update(t, gr, hp)
+            return
         lr, eps = t.dtype(np.float32(hp.learning_rate)), t.dtype(np.float32(hp.epsilon))
         for sd, W, A, b, Ab in ((0, t.R, t.A_R, t.br, t.A_br), (1, t.C, t.A_C, t.bc, t.A_bc)):
             for key, (g, gb) in G[sd].items():

@@ -28,7 +28,8 @@ def _batches():
     return [[make_batch(100 * s + r, B, V) for r in range(WORLD)] for s in range(STEPS)]
 
 
-def _worker(rank, port, optimizer, out_dir, exchange="dense"):
+def _worker(rank, port, optimizer, out_dir, exchange="dense", extra=None):
+    extra = extra or {}
     for p in (HERE.parent, HERE.parent / "oracle", HERE):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
@@ -38,12 +39,14 @@ def _worker(rank, port, optimizer, out_dir, exchange="dense"):
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     tables = OracleTables(ref.Tables(V, D, optimizer, dtype=np.float64, seed=3))
     backend = OracleBackend()
-    stepper = Stepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05), B, WORLD, dist, exchange=exchange)
+    stepper = Stepper(backend, tables, dict(l2_reg=0.01, reg_mult=2.0, learning_rate=0.05, optimizer=optimizer, **extra), B, WORLD, dist,
+                      exchange=exchange)
     assert stepper.dense and abs(stepper.hyper["inv_batch"] - 1.0 / (WORLD * B)) < 1e-15
     plans = [backend.build_plan(*step_batches[rank], V, 32) for step_batches in _batches()]
     stepper.prepare(plans)                       # collective: the ranks agree on the exchange
-    assert stepper.rows == (exchange == "rows") and [n for n, _ in stepper.phases()].count("all_gather") == int(stepper.rows)
-    if exchange == "auto":                       # 2 x ~80 ids x (d+4) floats against 2 V (d+1): dense is the shorter payload here
+    want_rows = exchange == "rows" or optimizer in Stepper.ROWS_ONLY      # the per-row optimizers always travel as lists
+    assert stepper.rows == want_rows and [n for n, _ in stepper.phases()].count("all_gather") == int(stepper.rows)
+    if exchange == "auto" and optimizer == "Adagrad":      # 2 x ~80 ids x (d+4) floats against 2 V (d+1): dense is the shorter payload here
         assert not stepper.rows
     for plan in plans:
         stepper.step(plan)
@@ -52,15 +55,20 @@ def _worker(rank, port, optimizer, out_dir, exchange="dense"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("optimizer,exchange", [("Adagrad", "dense"), ("Adam", "dense"), ("Adagrad", "rows"), ("Adagrad", "auto")])
-def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer, exchange):
+@pytest.mark.parametrize("optimizer,exchange,extra", [
+    ("Adagrad", "dense", {}), ("Adam", "dense", {}), ("Adagrad", "rows", {}), ("Adagrad", "auto", {}),
+    # the other names tf.keras.optimizers.get resolves (train_utils.py:13-16): per-row ones on the touched-rows exchange
+    # (whatever was asked for), the dense-decay RMSprop on the all-reduce
+    ("SGD", "auto", {}), ("SGD", "rows", dict(momentum=0.9, nesterov=True)), ("Adamax", "auto", {}), ("Adadelta", "auto", {}),
+    ("Ftrl", "auto", {}), ("RMSprop", "auto", {})])
+def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer, exchange, extra):
     """Dense all-reduce and touched-rows all-gather: either way two ranks == one rank on the joint batch."""
     sys.path.insert(0, str(HERE.parent / "oracle"))
     import glove_ref as ref
     port = free_port()
-    mp.spawn(_worker, args=(port, optimizer, str(tmp_path), exchange), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(port, optimizer, str(tmp_path), exchange, extra), nprocs=WORLD, join=True)
     t = ref.Tables(V, D, optimizer, dtype=np.float64, seed=3)
-    hp = ref.Hyper(learning_rate=0.05)
+    hp = ref.Hyper(learning_rate=0.05, **extra)
     for step_batches in _batches():
         joint = [np.concatenate([b[i] for b in step_batches]) for i in range(4)]
         ref.train_step(t, *joint, hp)

@@ -367,6 +367,29 @@ def test_two_rank_data_parallel_trainer_on_one_gpu(hip, tmp_path):
     assert ev[0]["global_step"] <= 10 and ev[-1]["global_step"] == 60 and 0 < ev[-1]["average_loss"] < ev[0]["average_loss"]
 
 
+@pytest.mark.parametrize("name", ["sgd", "Adamax", "rmsprop"])
+def test_two_rank_trainer_with_other_keras_optimizers_on_one_gpu(hip, tmp_path, name):
+    """`python -m trainer.estimator --optimizer <any Keras name but Nadam>` under a two-rank launcher (both ranks on the one GPU,
+    gloo transport): the per-row optimizers on the touched-rows exchange, RMSprop on the dense all-reduce; replicas stay
+    bit-identical, the eval loss over the whole file falls, rank 0's checkpoint carries the slots."""
+    import torch.multiprocessing as mp
+    csv, vocab = GOLDEN / "text8_cov90_ctx5_interaction.csv", GOLDEN / "text8_cov90_ctx5_vocab.txt"
+    job = tmp_path / "job"
+    lr = {"sgd": "0.5", "Adamax": "0.01", "rmsprop": "0.002"}[name]
+    argv = ["--train-csv", str(csv), "--vocab-txt", str(vocab), "--job-dir", str(job), "--disable-datetime-path",
+            "--embedding-size", "32", "--optimizer", name, "--learning-rate", lr, "--batch-size", "64",
+            "--train-steps", "60", "--log-every", "20", "--seed", "23", "--save-checkpoints-secs", "0"]
+    mp.spawn(_two_rank_trainer, args=(free_port(), argv, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / ("rank%d.pt" % r)) for r in range(2))
+    for n in ("R", "C", "br", "bc"):
+        assert torch.equal(a[n], b[n]), n
+    assert a["g"] == b["g"] and a["step"] == b["step"] == 60
+    ev = [json.loads(l) for l in (job / "eval" / "eval_log.jsonl").read_text().splitlines()]
+    assert ev[-1]["global_step"] == 60 and 0 < ev[-1]["average_loss"] < ev[0]["average_loss"]
+    ck = torch.load(job / "model.ckpt-60.pt")["tables"]
+    assert "slot1_R" in ck and (name != "Adamax" or "slot2_R" in ck)
+
+
 def test_two_rank_trainer_with_touched_rows_exchange_on_one_gpu(hip, tmp_path):
     """--exchange rows: the same run with the all-gather of packed touched-row lists instead of the dense all-reduce
     gives the same tables as --exchange dense, bit for bit (two ranks: g0 + g1 either way), seeded."""
@@ -788,3 +811,56 @@ def test_train_then_train_more_in_one_interpreter(hip, tmp_path):
                 done += r.run(30 - done)
     assert ta.global_step == 140 and tb.global_step == 90
     assert np.isfinite(ra.read_loss()["loss"]) and np.isfinite(rb.read_loss()["loss"])
+
+
+def test_other_optimizers_on_the_data_parallel_form_through_rccl_with_one_rank(hip):
+    """The other Keras names `tf.keras.optimizers.get` resolves (reference train_utils.py:13-16) on the multi-rank data-parallel
+    form, every collective issued through RCCL on this one GPU (`collectives=True`): the per-row optimizers (SGD with and
+    without momentum, Adamax, Adadelta, Ftrl) ride the touched-rows all-gather — glove_apply_packed_adagrad_f32 takes their
+    epilogue from glove_hyper.optimizer —, RMSprop the dense all-reduce (glove_dense_adam_f32's RMSprop sweep).  Three steps ==
+    the float64 oracle and == the single-GPU step (glove_step_sparse_f32) on the same batches."""
+    import os
+    import torch.distributed as dist
+    from helpers import make_batch, oracle_tables, to_dev
+    from test_gpu_optimizers import _check, _device_tables
+    from trainer.stepper import HipBackend, Stepper
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        B, V, d, steps = 5000, 600, 64, 3
+        backend = HipBackend("cuda:0")
+        batches = [make_batch(60 + s, B, V) for s in range(steps)]
+        for optimizer, extra in (("SGD", {}), ("SGD", dict(momentum=0.9, nesterov=True)), ("Adamax", {}), ("Adadelta", {}),
+                                 ("Ftrl", {}), ("RMSprop", {})):
+            lr = {"Adadelta": 1.0, "Ftrl": 0.05}.get(optimizer, 0.01)
+            hp = ref.Hyper(learning_rate=lr, **extra)
+            t = oracle_tables(V, d, optimizer)
+            multi_t, single_t = _device_tables(t), _device_tables(t)        # (fresh tables: the slots at their Keras initial values)
+            kw = dict(l2_reg=hp.l2_reg, reg_mult=hp.reg_mult, learning_rate=lr, optimizer=optimizer, **extra)
+            backend.row_floats = multi_t.d
+            multi = Stepper(backend, multi_t, kw, B, world=1, dist=dist, exchange="auto", collectives=True)
+            plans = [backend.build_plan(*to_dev(*bt), V, 0).compact(hip.lib, multi_t.d) for bt in batches]
+            multi.prepare(plans)
+            names = [n for n, _ in multi.phases()]
+            if optimizer == "RMSprop":
+                assert not multi.rows and "all_reduce" in names and "dense_apply" in names
+            else:
+                assert multi.rows and "all_gather" in names and "combine_apply" in names
+            single = Stepper(backend, single_t, kw, B)
+            for s in range(steps):
+                multi.step(plans[s])
+                single.step(plans[s])
+                ref.train_step(t, *batches[s], hp)
+            info = "%s %s" % (optimizer, extra)
+            _check(multi_t, t, 5e-5, 5e-6)          # (the tolerance of the single-GPU trajectories of these optimizers)
+            for n in ("R", "C", "br", "bc"):
+                torch.testing.assert_close(getattr(multi_t, n), getattr(single_t, n), rtol=5e-5, atol=5e-6, msg=lambda m: info + " " + n + ": " + m)
+                torch.testing.assert_close(multi_t.s1[n], single_t.s1[n], rtol=5e-5, atol=5e-6, msg=lambda m: info + " slot1 " + n + ": " + m)
+                if n in multi_t.s2:
+                    torch.testing.assert_close(multi_t.s2[n], single_t.s2[n], rtol=5e-5, atol=5e-6, msg=lambda m: info + " slot2 " + n + ": " + m)
+            torch.testing.assert_close(multi_t.scalars[:3], single_t.scalars[:3], rtol=5e-5, atol=5e-6)
+            assert multi_t.global_step == single_t.global_step == steps, info
+            got, want = multi.read_loss(), single.read_loss()
+            assert abs(got["loss"] - want["loss"]) <= 2e-5 * abs(want["loss"]), (info, got, want)
+    finally:
+        dist.destroy_process_group()
