@@ -158,7 +158,14 @@ __device__ inline unsigned long long digit_peers(int digit, int db, bool valid)
     return peers;
 }
 
-__device__ inline float dot4(const f4 a, const f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+// The horizontal sum of four products, association and fusing spelled out: left to the compiler one build makes it a chain of
+// fmas and another (the passes compiled for one loss head, whose body is a single basic block) packs the products two to a
+// v_pk_mul_f32 and adds them unfused — a last-bit difference in the dot product between kernels that are asked for the same bits
+// (ids one chunk holds: every step form, the packing passes, the one-launch forms).
+__device__ inline float dot4(const f4 a, const f4 b)
+{
+    return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
 
 // Per-workgroup reduction of kPartials running sums into out[blockIdx.x][kPartials].
 // Fixed order (lane butterfly, then waves 0..3) => bitwise repeatable for a fixed grid.

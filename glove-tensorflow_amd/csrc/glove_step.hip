@@ -221,7 +221,11 @@ template <int LPR, int NV, int FUSE> struct FusePass {
     static constexpr int unroll = narrow ? 4 : PassUnroll<NV>::value;
     static constexpr int waves = narrow ? 4 : (FUSE != 0 && LPR != 8 && NV <= 3) ? 3 : PassWaves<LPR>::value;
 };
-template <int LPR, int NV, bool FULL, bool REC, int FUSE>
+// HEAD: -1 = the loss head is read from the `head` argument at run time (the logistic heads); 0 = compiled for
+// GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
+// regression build 18 VGPRs at one float4 per lane — 119 against 101 — and 26 spilled scalar registers, whether they run or
+// not.  V = 2 M, d = 128, B = 1 M on the same plans, one process: 397 -> 355 us per step; V = 400 k, d = 300: 562 -> 554)
+template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1>
 __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
                 store_row<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
                 if (lg == 0) {
                     sd.gb[run_first] = se;
-                    if (sd.mark) sd.mark[cur_u] = 1.0f;
+                    if (FUSE == 0 && sd.mark) sd.mark[cur_u] = 1.0f;
                 }
             }
         }
@@ -537,9 +541,16 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
             for (int a = 0; a < U; ++a) {
                 const float valid = (q0 + a < n) ? 1.0f : 0.f;
                 float e;
-                if (head == GLOVE_HEAD_REGRESSION) {                 // uniform branch
-                    const float diff = (dp[a] + bg) - yq[a];
+                if (HEAD == GLOVE_HEAD_REGRESSION || (HEAD < 0 && head == GLOVE_HEAD_REGRESSION)) {                 // uniform branch
+                    float logit = dp[a] + bg;
+                    asm("" : "+v"(logit));                          // (the logit, the difference and e: each a rounded value of its own in
+                    float diff = logit - yq[a];                     // every build — see below)
+                    asm("" : "+v"(diff));
                     e = w2[a] * diff;                               // 0 on tail slots
+                    // (e is a rounded product for every consumer, as it is where the head is a run-time branch and e leaves it
+                    // through a select: compiled for one head the sum of e's below would otherwise contract into fma(w2, diff, .)
+                    // and the builds would differ in the last bit of the bias gradients)
+                    asm("" : "+v"(e));
                     ed += e * diff;
                 } else {
                     // pos / neg logistic heads on one logit: dL/dp = (pos (s - 1) + nf neg s) / B, s = sigmoid(p);
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
                 bsq += valid * bcv[a] * bcv[a];
                 ev[a] = e;
             }
-            if (!REC && sd.e_out) {                               // glove_rowpass_f32 only: e_i for diagnostics
+            if (FUSE == 0 && !REC && sd.e_out) {                  // glove_rowpass_f32 only (classic schedule): e_i for diagnostics
                 constexpr int ES = (U + LPR - 1) / LPR;      // pairs of this trip whose e a lane stores
 #pragma unroll
                 for (int x = 0; x < ES; ++x) {
@@ -2758,8 +2769,16 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
     if (!rec && p->B > 0 && !p->r_partner) return GLOVE_E_BADARG;     // (the diagnostic pass needs pair arrays)
-#define LAUNCH(LPR, NV, FULL, REC, FUSE) \
-    hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS)
+#define LAUNCH(LPR, NV, FULL, REC, FUSE)                                                                                       \
+    do {                                                                                                                       \
+        /* every pass compiled for the regression head (the same bits are asked of all of them on ids one chunk holds: one     \
+         * epilogue, one set of contraction decisions); the logistic heads keep the run-time branch (compiled alone their      \
+         * d = 300 build spills) */                                                                                             \
+        if (h->head == GLOVE_HEAD_REGRESSION)                                                                                   \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS);               \
+    } while (0)
 #define CALL(LPR, NV)                                                                   \
     if (LPR * NV == d4) {                                                               \
         if (rec) { if (pack) LAUNCH(LPR, NV, true, true, 2); else if (fuse) LAUNCH(LPR, NV, true, true, 1); else LAUNCH(LPR, NV, true, true, 0); } \
