@@ -215,7 +215,8 @@ struct StepConsts {
 // partner, and the fourth wave hides more of every trip than the second half of the trip did.  One process, same resident plans
 // (tools/ab_kernels.py, V = 2 M, d = 128, B = 1 M, twin form): 505 -> 407 us per step, bit-identical tables; five waves spill
 // (815 us), eight rows at four waves spill (1,088).  Three float4 per lane (d = 300) stay at four rows and three waves: two rows
-// at four waves (128 VGPRs, nothing spilled) measured 610 against 582 us at V = 400 k and 107 against 97 at V = 50 k.
+// at four waves (128 VGPRs, nothing spilled) measured 610 against 582 us at V = 400 k and 107 against 97 at V = 50 k; four rows
+// at four waves (compiled for one head: 165 VGPRs at three waves, 16 spilled at four) 697 against 574 and 122 against 95.
 template <int LPR, int NV, int FUSE> struct FusePass {
     static constexpr bool narrow = FUSE != 0 && LPR != 8 && NV == 1;
     static constexpr int unroll = narrow ? 4 : PassUnroll<NV>::value;
