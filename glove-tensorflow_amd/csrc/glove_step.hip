@@ -279,8 +279,8 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
     // pair fields, then its partner rows.  (Fetched chunk by chunk they were a third dependent trip: 599 against 584 us per C4 step.)
     constexpr bool kDesc = FUSE == 1 && !REC;
     constexpr int kDescSlots = 16;
-    __shared__ int32_t desc_raw[kDesc ? GPB * 3 * kDescSlots : 1];
-    int32_t *desc = desc_raw + (kDesc ? grp * 3 * kDescSlots : 0);
+    __shared__ int32_t desc_raw[kDesc ? GPB * 4 * kDescSlots : 1];
+    int32_t *desc = desc_raw + (kDesc ? grp * 4 * kDescSlots : 0);
     const bool use_desc = kDesc && sd.chunk_hw != nullptr && per < kDescSlots;
     const int j_first = j;
     // ... and the pair fields of all its chunks are ONE contiguous range of the side's arrays (a few dozen pairs for the short
@@ -296,8 +296,12 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
         for (int x = lg; x <= j_end - j; x += LPR) {                 // (a group of 8 lanes owns up to 12 chunks: two rounds)
             desc[x] = sd.chunk_start[j + x];
             if (x < j_end - j) {
-                desc[kDescSlots + x] = sd.chunk_id[j + x];
+                const int32_t cid = sd.chunk_id[j + x];
+                desc[kDescSlots + x] = cid;
                 desc[2 * kDescSlots + x] = (int32_t)sd.chunk_hw[j + x];
+                // twinned own table: which copy of the chunk's row is current, looked up here — behind the id, beside the pair
+                // fields' trip — instead of as a dependent trip in front of every run's own-row load
+                if (sd.own_ver) desc[3 * kDescSlots + x] = sd.own_ver[cid];
             }
         }
         stage_first = desc[0];
@@ -305,7 +309,11 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
         staged = span <= kStagePairs;
         if (staged) {
             for (int i = lg; i < span; i += LPR) {
-                stage[i] = (uint32_t)sd.partner[stage_first + i];
+                uint32_t pid = (uint32_t)sd.partner[stage_first + i];
+                // twinned partner table: the staged ids become the rows that are current, here, once for all the group's chunks
+                // (one byte gather per pair behind the id's load) instead of a dependent trip in front of every chunk's rows
+                if (sd.other_ver) pid += sd.other_ver[pid] ? (uint32_t)sd.other_twin : 0u;
+                stage[i] = pid;
                 stage[kStagePairs + i] = __float_as_uint(sd.w[stage_first + i]);
                 stage[2 * kStagePairs + i] = __float_as_uint(sd.y[stage_first + i]);
             }
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
                 }
             }
         }
-        if (FUSE && have && sd.other_ver) {
+        if (FUSE && have && sd.other_ver && !(kDesc && staged)) {      // (staged pairs were resolved when they were staged)
             // twinned partner table: the staged partner ids become the rows that are current.  One byte gather per pair,
             // issued with the own-row load below (whose latency covers it), instead of a dependent hop in every trip
             for (int t = lg; t < n; t += LPR) {
@@ -458,7 +466,8 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
             run_q = uq;
             run_pairs = 0;
             own_at = u;
-            if (FUSE && sd.own_ver) own_at = u + (sd.own_ver[u] ? sd.own_twin : 0);     // the current copy of a twinned table
+            if (FUSE && sd.own_ver)                                                     // the current copy of a twinned table
+                own_at = u + ((use_desc ? desc[3 * kDescSlots + (j - j_first)] : (int32_t)sd.own_ver[u]) ? sd.own_twin : 0);
             if (FUSE) load_row<LPR, NV>(r, sd.own, own_at, d4, lg); else load_row<LPR, NV>(r, sd.own, u, d4, lg);
             own_b = sd.own_bias[own_at];
             bg = own_b + g;
