@@ -226,7 +226,11 @@ template <int LPR, int NV, int FUSE> struct FusePass {
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
 // regression build 18 VGPRs at one float4 per lane — 119 against 101 — and 26 spilled scalar registers, whether they run or
 // not.  V = 2 M, d = 128, B = 1 M on the same plans, one process: 397 -> 355 us per step; V = 400 k, d = 300: 562 -> 554)
-template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1>
+// SIDE: -1 = the launch holds both sides (row side in the first row_blocks workgroups); 1 / 0 = it holds the row / the col side
+// alone (the three-launch fused form's launches): the col side's build then drops what only the loss needs — |c|^2 of every
+// partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
+// 153: a fourth wave per SIMD).
+template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1, int SIDE = -1>
 __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE>::waves)) void side
     f4 *park = park_raw + (kPark ? (threadIdx.x / 64) * NV * 64 : 0);       // this wave's image
     const int lg = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
-    const bool is_row = (int)blockIdx.x < row_blocks;
+    const bool is_row = SIDE < 0 ? (int)blockIdx.x < row_blocks : SIDE == 1;
     const PassSide &sd = is_row ? rowside : colside;
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
     const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
@@ -2784,7 +2788,13 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
         /* every pass compiled for the regression head (the same bits are asked of all of them on ids one chunk holds: one     \
          * epilogue, one set of contraction decisions); the logistic heads keep the run-time branch (compiled alone their      \
          * d = 300 build spills) */                                                                                             \
-        if (h->head == GLOVE_HEAD_REGRESSION)                                                                                   \
+        /* (the side-specialised builds below the twin form only: there the col side's fourth wave pays — V = 50 k, d = 300        \
+         * 96.8 -> 93.4 us per step; on twinned tables, bound by bandwidth, it costs: V = 400 k 577.6 -> 580.0, V = 2 M 361.5 -> 364.2) */ \
+        if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 1 && !twin)                                               \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 1 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 0 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+        else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else                                                                                                                   \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS);               \

@@ -15,8 +15,13 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def kind(r):
     n = r["Kernel_Name"].split("(")[0]
     if "sidepass" in n:
-        # last template argument: the run-merged schedule (bool in the first round-2 builds, 0 / 1 / 2 since)
-        return "pass_fused" if n.rstrip().endswith(("true>", ", 1>", ", 2>")) else "pass"
+        # the FUSE template argument: the run-merged schedule (the last argument in rounds 2 - 4: a bool in the first round-2
+        # builds, 0 / 1 / 2 since; the fifth of six since round 5 added the loss head behind it)
+        import re
+        args = re.search(r"sidepass_kernel<([^>]*)>", n)
+        a = [x.strip() for x in args.group(1).split(",")] if args else []
+        fuse = a[4] if len(a) >= 5 else (a[-1] if a else "0")
+        return "pass_fused" if fuse in ("true", "1", "2") else "pass"
     return "apply" if "apply_adagrad" in n else "triage" if "triage" in n else "other"
 
 
