@@ -165,7 +165,7 @@ TRAFFIC_PROFILES = {
     ("zipf_v2m_d128", 1048576, "dealt"): "r05_c5_v2m_d128_b1m_index_rebuilt_traffic.json",
     ("zipf_v2m_d128", 1048576, "static"): "r05_c5_v2m_d128_b1m_static_index_traffic.json",
     ("text8_v50k_d300", 131072, "dealt"): "r05_c3_v50k_d300_b131072_index_rebuilt_traffic.json",
-    ("text8_v50k_d300", 131072, "static"): "r03_c3_v50k_d300_b131072_traffic.json",
+    ("text8_v50k_d300", 131072, "static"): "r05_c3_v50k_d300_b131072_static_index_traffic.json",
     ("text8_d64", 131072, "dealt"): "r05_text8_d64_b131072_index_rebuilt_traffic.json",
     ("text8_d64", 131072, "static"): "r03_text8_d64_b131072_traffic.json",
     ("text8_d64", 1024, "dealt"): "r05_text8_d64_b1024_index_rebuilt_traffic.json",
