@@ -673,7 +673,7 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
         V_col = V_row if mode == "sharded" else V
         if world > 1:
             coo = route_by_row_owner(coo, world, rank, dist)
-    cap = chunk_cap or auto_chunk_cap(B, V, row_width(max(V_row, V_col), d))
+    cap = chunk_cap or auto_chunk_cap(B, V, row_width(V, d))
     nnz = coo["row"].numel()
     if nnz < B:
         raise SystemExit("workload has %d nonzeros < batch size %d" % (nnz, B))

@@ -249,7 +249,7 @@ class DeviceTables:
         self.V, self.d_model, self.optimizer, self.device = int(V), int(d), optimizer, torch.device(device)
         self.V_row = int(V if V_row is None else V_row)
         self.V_col = int(V if V_col is None else V_col)
-        self.d = row_width(max(self.V_row, self.V_col), d)
+        self.d = row_width(self.V, d)        # (by the whole vocabulary, not this rank's shard: every rank takes the same stride)
         if not 0 < self.V_row <= self.V or not 0 < self.V_col <= self.V:
             raise ValueError("V_row and V_col must be in (0, V]")
         gen = torch.Generator(device="cpu")

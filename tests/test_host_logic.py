@@ -359,3 +359,18 @@ def test_bench_traffic_table_points_at_committed_profiles():
         assert traffic > 0 and src == "profiles/" + name
     traffic, why = bench.measured_traffic("text8_d64", 12345, "dealt")
     assert traffic is None and "no PMC profile" in why
+
+
+def test_row_width_puts_rows_on_line_boundaries():
+    """trainer.hip_api.row_width: the stored row stride — 16-byte rows at least; 64-byte boundaries when the padding costs at
+    most d / 12 floats; 128-byte lines for tables beyond the Infinity Cache (>= 128 MB) — decided by the whole vocabulary, so that
+    every rank of a sharded run takes the same stride."""
+    from trainer.hip_api import row_width
+    assert row_width(400000, 300) == 320 and row_width(50000, 300) == 304            # C4: 1,280-byte rows; C3: 1,216
+    assert row_width(10000, 64) == 64 and row_width(2000000, 128) == 128              # already aligned
+    assert row_width(1000, 50) == 52 and row_width(10 ** 7, 50) == 52                 # padding beyond d / 12: 16-byte rows only
+    assert row_width(1000, 301) == 304 and row_width(1000, 1) == 4 and row_width(1000, 200) == 208
+    for d in (1, 7, 8, 63, 100, 129, 300, 1023):
+        for rows in (10, 10 ** 5, 10 ** 7):
+            w = row_width(rows, d)
+            assert w >= d and w % 4 == 0 and w - d <= max(3, d // 12 + 0)
