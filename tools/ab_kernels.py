@@ -45,9 +45,9 @@ def main():
     for cap in [int(c) for c in args.caps.split(",")]:
         for v in range(len(hips)):       # every build indexes the batches itself (the plan's record layout is the library's own)
             plans = [hips[v].build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V,
-                                        chunk_cap=cap, compact=True, d=(d + 3) // 4 * 4) for b in range(nb)]
+                                        chunk_cap=cap, compact=True, d=tables.d) for b in range(nb)]
             configs.append((cap, v, plans))
-    ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, d), dtype=torch.uint8, device=dev)
+    ws = torch.empty(hip.lib.glove_step_workspace_bytes(B, B, tables.d), dtype=torch.uint8, device=dev)
     res = {(c, v): {"rowpass": [], "colpass": [], "passes": [], "apply": [], "step": []} for c, v, _ in configs}
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for rnd in range(args.rounds + 1):

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402
 
 from trainer import synthetic  # noqa: E402
-from trainer.hip_api import DeviceTables, GloveHip, auto_chunk_cap, make_hyper  # noqa: E402
+from trainer.hip_api import DeviceTables, GloveHip, auto_chunk_cap, make_hyper, row_width  # noqa: E402
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
     wl = synthetic.make_workload(a.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], a.batch_size
     nb = min(a.batches, wl["row"].numel() // B)
-    dpad = (d + 3) // 4 * 4
+    dpad = row_width(V, d)          # the stored row stride (what workspace queries and thresholds take)
     cap = auto_chunk_cap(B, V, dpad)
     plans = [hip.build_plan(*(wl[k][b * B:(b + 1) * B].contiguous() for k in ("row", "col", "w", "y")), V, chunk_cap=cap).compact(hip.lib, dpad, records=True)
              for b in range(nb)]
