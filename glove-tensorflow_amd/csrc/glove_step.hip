@@ -2637,7 +2637,7 @@ static StepConsts make_consts(const glove_tables *t, const glove_hyper *h)
 
 static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_for(p->cap_chunks, kBlock / lpr); }
 
-// FUSE passes: consecutive chunks per lane group.  Up to 12: a heavy id then leaves one partial row per 12 chunks instead
+// FUSE passes: consecutive chunks per lane group.  Up to 6 (12 until round 5, see below): a heavy id then leaves one partial row per 12 chunks instead
 // of one per chunk, and an id of a few chunks is usually applied by the pass itself (an id whose chunks straddle two
 // groups goes through partial rows and the apply launch) — but the ids of the Zipf head fill consecutive FULL chunks, so
 // a head group's per x chunk_cap pairs are one serial chain of partner-row trips, the launch's critical path once per is
@@ -2653,7 +2653,10 @@ static int fuse_per(const glove_plan *p, int lpr)
     const int64_t nr = most_chunks(p, true), nc = most_chunks(p, false);
     const int64_t side = nr > nc ? nr : nc;
     int per = (int)((side + 16383) / 16384);              // <= 2,048 workgroups up to 196 k chunks a side
-    per = per < 1 ? 1 : per > 12 ? 12 : per;
+    // (round 5, the passes compiled for one head with staged version lookups — shorter per-chunk chains, more waves: the same
+    // A/B, one process, us per step: V = 400 k, d = 300: per 3 / 4 / 5 / 6 / 8 / 10 / 12 / 15 = 558 / 546 / 543 / 540 / 545* / 551* / 550 / 595*;
+    // V = 2 M, d = 128: 344.6 / 344.5 / 344.4 / 343.1 / 344* / 348* / 348.5 / 431* (* scaled from another box's run against 12): 6)
+    per = per < 1 ? 1 : per > 6 ? 6 : per;
     const int64_t groups = (int64_t)kMaxPassBlocks * (kBlock / lpr);
     // (`side` is the chunk count itself when the host knows it — also for a staging plan whose counts were read back: its
     // capacity is the worst case, V = 2 M at B = 1 M ran 16 chunks per group instead of 12 for nothing, 530 against 511 us)
