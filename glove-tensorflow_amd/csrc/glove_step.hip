@@ -3240,7 +3240,12 @@ int glove_gather_rows_f32(const float *W, const float *bias, const int32_t *ids,
 //   V = 2 M,   d = 128 (1 GB):         209 MB 128.6 / 122.9 / 120.6                    368 MB 220.3 / 199.4 / 188.8
 //   V = 10 k,  d = 64, B = 1 M (20 MB touched): 55.2 / 82.3 / 87.7
 // A tie at 146 MB, 4 - 6 % for the fused forms from 209 MB on (the twin form on tables beyond the Infinity Cache, the
-// three-launch form on the 61 MB table): the switch sits between.
+// three-launch form on the 61 MB table): the switch sat between (192 MB).
+// Round 5 (the passes compiled for one head, staged version lookups, six chunks per lane group; same tool, forms 1 / 3 / 4):
+//   V = 50 k,  d = 300:  56 MB 32.5 / 39.1 / 40.8     75 MB 41.1 / 41.6 / 42.8     92 MB 46.2 / 44.3 / 46.5    122 MB 57.6 / 54.4 / 58.5   148 MB 69.2 / 62.5 / 67.5
+//   V = 400 k, d = 300:  77 MB 42.2 / 44.2 / 46.5    137 MB 60.3 / 58.0 / 60.9    241 MB 98.3 / 93.5 / 89.6
+//   V = 2 M,   d = 128:  35 MB 26.0 / 31.8 / 35.9     64 MB 42.2 / 40.2 / 41.8    117 MB 67.5 / 63.9 / 63.1    209 MB 114.3 / 114.4 / 104.5
+// The fused forms now pay from 90 MB on: the switch is GLOVE_FUSED_STEP_BYTES = 96 MB.
 
 // Which form a sparse Adagrad step takes (glove_hyper.step_form; see include/glove_hip.h).
 static int pick_step_form(const glove_plan *p, const glove_tables *t, const glove_hyper *h)

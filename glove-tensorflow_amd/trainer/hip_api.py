@@ -29,7 +29,7 @@ HEAVY_CHUNKS = 8          # ids with more chunks than this are reduced by a whol
 
 
 RUN_WORDS_MIN_CHUNKS = 98304    # chunks of a side from which a resident plan of the fused regime keeps run words instead of records (6 chunks per lane group)
-FUSED_STEP_BYTES = 192 << 20    # GLOVE_FUSED_STEP_BYTES (include/glove_hip.h): touched ids x row bytes x 4 beyond which the fused step pays (tests/test_abi.py holds the two together)
+FUSED_STEP_BYTES = 96 << 20    # GLOVE_FUSED_STEP_BYTES (include/glove_hip.h): touched ids x row bytes x 4 beyond which the fused step pays (tests/test_abi.py holds the two together)
 
 
 def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
@@ -37,9 +37,9 @@ def auto_chunk_cap(B: int, V: int, d: int | None = None) -> int:
     chain of the gather passes (fewer partner-row round trips per chunk) and win while a batch holds
     few pairs per id; long chunks mean fewer partial rows and win for dense batches (bench.py --chunk-cap,
     V = 10000: B = 131072: 8 / 16 / 24 / 32 -> 22.4 / 21.2 / 22.3 / 23.3 us per step; B = 1048576: 16 -> 59.4, 32 -> 53.8).
-    Tables far beyond the caches (`d` given: V x d x 4 B >= 256 MB) take the fused step, which is bandwidth-bound
+    Tables beyond the L2s (`d` given: V x d x 4 B >= 32 MB) take the fused step at realistic batch sizes, which is bandwidth-bound
     and likes long chunks (V = 400 k, d = 300, B = 1 M: 8 / 16 / 32 -> 746 / 734 / 722 us per step)."""
-    if d is not None and V * d * 4 >= (256 << 20):
+    if d is not None and V * d * 4 >= (32 << 20):       # (round 5: V = 50 k, d = 300 — 61 MB — cap 8 / 16 / 32 -> 96.3 / 92.6 / 91.7 us per step)
         return 32
     return 16 if B <= 20 * V else 32
 

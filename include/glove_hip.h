@@ -434,7 +434,7 @@ int glove_rowside_step_adagrad_f32(const glove_plan *plan, const glove_tables *t
 /* GLOVE_STEP_AUTO takes a fused form when (distinct row ids + distinct col ids of the plan) x d x 16 B — the rows a
  * step reads and writes — reaches this many bytes (and the plan carries chunk records or run words); callers that keep a twinned
  * table use the same number to know whether a step may have left versions flipped. */
-#define GLOVE_FUSED_STEP_BYTES ((size_t)192 << 20)
+#define GLOVE_FUSED_STEP_BYTES ((size_t)96 << 20)
 /* Twinned row table (glove_tables.R_ver) back to the plain form: current rows copied into rows 0 .. V_row-1, versions
  * cleared.  A no-op without a twin.  Call before anything but glove_step(s)_adagrad_f32 reads or writes R / br. */
 int glove_canonicalize_f32(const glove_tables *t, void *stream);
