@@ -89,6 +89,8 @@ def parse(argv=None):
     ap.add_argument("--learning-rate", type=float, default=0.05)
     ap.add_argument("--collectives", action="store_true",
                     help="with --row-sharded / --force-dense on one GPU: issue every collective through RCCL although there is one rank")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="with --row-sharded on one GPU: the whole serve / fetch / push / owner-apply sequence although every row is local")
     ap.add_argument("--step-form", type=int, default=0, help="glove_hyper.step_form: 0 auto, 1 two launches, 2 fused one pass, 3 fused three launches, 4 fused on a twinned row table, 5 tagged step (latency-bound regime)")
     ap.add_argument("--static-index", action="store_true",
                     help="one GPU: the trainer's --epoch-shuffle static (the index of every resident batch built at load, "
@@ -422,7 +424,8 @@ def run_dealt_multi(ctx, workload, B, mode, steps=200, warmup=20, lr=0.05, chunk
     nnz = stream.nnz
     hyper_kw = dict(learning_rate=lr, step_form=step_form)
     if mode == "sharded":
-        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives)
+        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives,
+                                 exercise_exchange=ctx.args.exercise_exchange)
     elif mode == "rowsharded":
         stepper = RowShardedStepper(backend, tables, hyper_kw, B, world, dist, exchange=exchange, collectives=ctx.args.collectives)
         stepper.prepare(batch_size=B)
@@ -702,7 +705,8 @@ def run_config(ctx, workload, B, optimizer="Adagrad", mode="auto", steps=200, wa
     t0 = time.perf_counter()
     stepper = None
     if mode == "sharded":
-        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives)
+        stepper = ShardedStepper(backend, tables, hyper_kw, B, world, rank, dist, collectives=ctx.args.collectives,
+                                 exercise_exchange=ctx.args.exercise_exchange)
         handles = [stepper.add_batch(*bt, cap) for bt in batches]
         plans = [stepper.batches[h]["plan"] for h in handles]
     else:

@@ -610,12 +610,27 @@ class ShardedStepper(GraphedSteps):
         self.batches, self.bufs, self.view, self.owner_state, self._caps, self._dirty = [], None, None, {}, (0, 0), True
         self.tail = torch.zeros(4, dtype=getattr(backend, "tail_dtype", torch.float32), device=tables.device)   # loss partials, summed over ranks
         self._push = SideCollective(tables.device)          # the col gradients' all-to-all while it is in flight
+        self._prep_pg = None                                # the communicator of the prepare's collectives (prepare_group)
+        self._spare = {}                                    # staging plans of dropped batches, by (B, id bound, chunk cap)
         if hasattr(backend, "shard_rows"):
             backend.shard_rows = tables.V_row       # local row ids: anything outside the shard counts as id 0, like a bad col id
+
+    def prepare_group(self):
+        """The communicator the fetch lists' sizes and indices travel on — one of their own.  A transport runs the collectives of
+        ONE communicator in the order they were issued: on the steps' communicator a batch prepared beside the steps (a dealt
+        epoch: ReshufflingRunner._prepare_ahead) had its two small all-to-alls queued behind the fetch / push of every step
+        already launched, and the host read of its sizes waited for all of them — steps and prepares took turns (V = 400 k,
+        d = 300, B = 1 M, one rank with the exchange exercised: 1.89 ms per step against 1.34 on a static stream)."""
+        if not self._multi:
+            return None
+        if self._prep_pg is None:
+            self._prep_pg = self.dist.new_group()           # (collective: every rank prepares its first batch at the same point)
+        return self._prep_pg
 
     def add_batch(self, row, col, w, y, chunk_cap=0) -> int:
         """row: this rank's LOCAL row indices; col: global col ids.  Collective; returns the batch's handle."""
         W, dist = self.world, self.dist
+        pg = self.prepare_group()
         if self.local_only:                                             # local index = id: the plain step's plan
             plan = self.backend.build_plan(row, col, w, y, self.tables.V, chunk_cap)
             self.batches.append(dict(plan=plan, want=[0], serve=[0], serve_idx=None, n=0, ns=0))
@@ -631,13 +646,13 @@ class ShardedStepper(GraphedSteps):
         req = ((uc[order] % per) if per else (uc[order] // W)).to(torch.int32).contiguous()        # the owners' local indices
         serve = torch.empty_like(want)
         if self._multi:
-            dist.all_to_all_single(serve, want)
+            dist.all_to_all_single(serve, want, group=pg)
         else:
             serve.copy_(want)
         want_l, serve_l = [int(x) for x in want.tolist()], [int(x) for x in serve.tolist()]
         serve_idx = torch.empty(sum(serve_l), dtype=torch.int32, device=req.device)
         if self._multi:
-            dist.all_to_all_single(serve_idx, req, serve_l, want_l)
+            dist.all_to_all_single(serve_idx, req, serve_l, want_l, group=pg)
         else:
             serve_idx.copy_(req)
         n_uc = int(uc.numel())
@@ -652,46 +667,97 @@ class ShardedStepper(GraphedSteps):
         on the col side, so nothing is sorted here: the distinct col ids are the runs of the col side, a pair's compact col id is
         the number of its run, and the index is numbered by glove_plan_build_sorted.  Collective; returns the batch's handle.
         Same fetch lists and the same plan as add_batch gives for the batch in row-major arrival order."""
-        from trainer.hip_api import Pairs, PlanBlock
+        return self.add_batch_dealt_finish(self.add_batch_dealt_begin(row_side, col_side, first, B, chunk_cap))
+
+    def add_batch_dealt_begin(self, row_side, col_side, first: int, B: int, chunk_cap: int) -> dict:
+        """First half of add_batch_dealt: everything the device can do without the host knowing a size — the runs of the col
+        side, the fetch counts per owner and their all-to-all, the index — issued on the current stream with NO host read; the
+        sizes (distinct col ids, ids wanted from / served to every rank, the index's counts) start their way to one pinned
+        block behind it.  add_batch_dealt_finish reads them.  A runner keeps a batch or two between the halves
+        (ReshufflingRunner._prepare_one): by the time it reads, the copy has long landed, and the host never waits for a
+        prepare launch queued behind the running step's kernels (six such waits per batch made a prepare 1.7 ms beside
+        1.3 ms steps: the host fell behind and the steps waited for their fetch lists at every epoch's end).  Collective."""
+        from trainer.hip_api import Pairs, PlanBlock, auto_chunk_cap
         hip, W, dist, per = self.backend.hip, self.world, self.dist, self.col_per
+        pg = self.prepare_group()
         sl = slice(first, first + B)
-        uc, run = torch.unique_consecutive(col_side.id[sl], return_inverse=True)       # (one host read: the number of runs)
-        n_uc = int(uc.numel())
+        ids = col_side.id[sl]
+        dev = ids.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        new = torch.ones(B, **i32)                                       # 1 where a run of equal col ids starts
+        new[1:] = (ids[1:] != ids[:-1]).to(torch.int32)
+        upto = torch.cumsum(new, 0, dtype=torch.int32)                  # runs that have started up to and including a position
+        run = upto - 1                                                   # the pair's compact col id = the number of its run
         if getattr(self, "_lut", None) is None:
-            self._lut = torch.zeros(W * per, dtype=torch.int32, device=uc.device)
-        self._lut[uc.long()] = torch.arange(n_uc, dtype=torch.int32, device=uc.device)
-        want = torch.bincount(uc.long() // per, minlength=W)
-        req = (uc % per).to(torch.int32).contiguous()
+            self._lut = torch.zeros(W * per, **i32)
+            self._edges = torch.arange(0, (W + 1) * per, per, **i32)     # the owners' first col ids
+        self._lut[ids] = run                                             # (the pairs of a run all write its number)
+        req = torch.zeros(B, **i32)                                      # the owners' local indices, in fetch order; [:n_uc] is used
+        req[run] = ids % per
+        # ids wanted from every owner = runs that start inside its range of the (sorted) ids: W + 1 binary searches and the
+        # running count at their positions (an index_add_ of the million flags onto W counters was 213 us of atomics on one
+        # address at world 1)
+        pos = torch.searchsorted(ids, self._edges)
+        before = torch.where(pos > 0, upto[(pos - 1).clamp(min=0)], torch.zeros_like(upto[:1]))
+        want = (before[1:] - before[:-1]).long()
         serve = torch.empty_like(want)
         if self._multi:
-            dist.all_to_all_single(serve, want)
+            dist.all_to_all_single(serve, want, group=pg)
         else:
             serve.copy_(want)
-        # the index over compact col ids, while the counts travel
-        def side(src, ids, partner):
+        # the index over compact col ids, while the counts travel.  Its capacities come from a bound of the distinct col ids
+        # (the host does not know their number yet): no more than pairs, no more than columns
+        def side(src, sid, partner):
             p = Pairs.__new__(Pairs)
-            p.n, p.id, p.partner, p.w, p.y, p._struct = B, ids.contiguous(), partner.contiguous(), src.w[sl], src.y[sl], None
+            p.n, p.id, p.partner, p.w, p.y, p._struct = B, sid.contiguous(), partner.contiguous(), src.w[sl], src.y[sl], None
             return p
-        rs = side(row_side, row_side.id[sl], self._lut[row_side.partner[sl].long()])
-        cs = side(col_side, run.to(torch.int32), col_side.partner[sl])
-        V_plan = max(n_uc, self.tables.V_row)
-        from trainer.hip_api import auto_chunk_cap
+        rs = side(row_side, row_side.id[sl], self._lut[row_side.partner[sl]])
+        cs = side(col_side, run, col_side.partner[sl])
+        V_plan = max(min(B, W * per), self.tables.V_row)
         cap = chunk_cap or auto_chunk_cap(B, V_plan, self.tables.d)
-        plan = hip.staging_plan(B, V_plan, cap, uc.device, V_row=self.tables.V_row, records=True)
-        block = PlanBlock([plan])
+        # the staging plan, its struct block and the pinned block of its sizes come back from the batches of epochs past
+        # (drop_batches): allocating them anew — two dozen tensors, two pinned blocks, a pageable copy of the structs, each
+        # of the last three a wait for the stream — was most of a prepare's host time
+        key = (B, V_plan, cap)
+        pool = self._spare.setdefault(key, [])
+        if pool:
+            plan, block, sizes_host = pool.pop()
+        else:
+            plan = hip.staging_plan(B, V_plan, cap, dev, V_row=self.tables.V_row, records=True)
+            block = PlanBlock([plan])
+            sizes_host = torch.empty(2 * W + 1, dtype=torch.int64)
+            if dev.type == "cuda":
+                sizes_host = sizes_host.pin_memory()
         if getattr(self, "_sorted_ws", None) is None or self._sorted_ws_B != B:
-            self._sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, 1), 256), dtype=torch.uint8, device=uc.device)
+            self._sorted_ws = torch.empty(max(hip.lib.glove_plan_sorted_workspace_bytes(B, 1), 256), dtype=torch.uint8, device=dev)
             self._sorted_ws_B = B
         hip.build_plans_sorted(rs, cs, 0, block, 1, V_plan, self._sorted_ws)
         block.fetch_counts()
-        want_l, serve_l = [int(x) for x in want.tolist()], [int(x) for x in serve.tolist()]        # (host reads: everything above has run)
-        block.adopt_counts(1)
+        sizes = torch.cat([want, serve, run[-1:].long() + 1])
+        sizes_host.copy_(sizes, non_blocking=True)
+        landed = None
+        if dev.type == "cuda":
+            landed = torch.cuda.Event()
+            landed.record()
+        return dict(plan=plan, block=block, req=req, sizes=sizes_host, landed=landed, keep=(sizes, rs, cs), spare_key=key)
+
+    def add_batch_dealt_finish(self, half: dict) -> int:
+        """Second half: the sizes on the host (the only wait of a prepare, for a copy issued a batch or two ago), the ids this
+        rank serves by all-to-all.  Collective; returns the batch's handle."""
+        W, dist = self.world, self.dist
+        if half["landed"] is not None:
+            half["landed"].synchronize()
+        got = [int(x) for x in half["sizes"].tolist()]
+        want_l, serve_l, n_uc = got[:W], got[W:2 * W], got[2 * W]
+        half["block"].adopt_counts(1)
+        req = half["req"][:n_uc]
         serve_idx = torch.empty(sum(serve_l), dtype=torch.int32, device=req.device)
         if self._multi:
-            dist.all_to_all_single(serve_idx, req, serve_l, want_l)
+            dist.all_to_all_single(serve_idx, req, serve_l, want_l, group=self.prepare_group())
         else:
             serve_idx.copy_(req)
-        self.batches.append(dict(plan=plan, want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l), block=block))
+        self.batches.append(dict(plan=half["plan"], want=want_l, serve=serve_l, serve_idx=serve_idx, n=n_uc, ns=sum(serve_l),
+                                 block=half["block"], spare=(half["spare_key"], half["sizes"])))
         self._dirty = True
         return len(self.batches) - 1
 
@@ -705,6 +771,10 @@ class ShardedStepper(GraphedSteps):
         """Forgets these prepared batches only (the handles of the others stay valid): an epoch that has been stepped through,
         while the next one's batches — prepared beside its steps — stay."""
         for h in handles:
+            bt = self.batches[h]
+            if bt is not None and "spare" in bt:
+                # (the caller orders the next refill behind the steps that still read the plan: ReshufflingRunner._prepare_epoch)
+                self._spare.setdefault(bt["spare"][0], []).append((bt["plan"], bt["block"], bt["spare"][1]))
             self.batches[h] = None
             if getattr(self, "_graphs", None):
                 self._graphs.pop(h, None)
@@ -832,7 +902,10 @@ class ReshufflingRunner:
         self.position = 0                      # next batch of the current epoch
         self.handles = None                    # both tables sharded: the epoch's prepared batches
         self._ahead = []                       # ... and those of the next epoch prepared so far (dealt streams)
-        self._prep = torch.cuda.Stream(device=tables.device) if tables.device.type == "cuda" else None
+        self._begun = []                       # ... and those begun, not finished (_prepare_one)
+        # (high priority: short launches that should not queue behind a step's workgroups — and HIP keeps the hardware queues
+        # of each priority apart, so this stream shares none with the steps' streams)
+        self._prep = torch.cuda.Stream(device=tables.device, priority=-1) if tables.device.type == "cuda" else None
         # batches per epoch: the ranks' shards differ in length (by one pair data parallel, by the ownership of the rows
         # when routed), epochs end together: everybody steps through as many batches as the shortest shard has — the
         # pairs behind them wait for the next permutation, like the `nnz mod B` behind a rank's last full batch
@@ -975,8 +1048,9 @@ class ReshufflingRunner:
             return
         old = self.handles or []
         self.handles, self._ahead = self._ahead, []
-        while len(self.handles) < self.nb:              # (the first epoch; an epoch shorter than the steps that were run in it)
+        while len(self.handles) + len(self._begun) < self.nb:      # (the first epoch; an epoch shorter than the steps that were run in it)
             self._prepare_one(self.stream.epoch, self.handles)
+        self._finish_begun(self.handles)
         main = torch.cuda.current_stream()
         main.wait_stream(self._prep)                    # the plans and fetch lists are complete before a step reads them
         self.stepper.drop_batches(old)
@@ -984,24 +1058,40 @@ class ReshufflingRunner:
         # waits for the steps of the old epoch that are still running)
         self._prep.wait_stream(main)
 
+    PREPARES_IN_FLIGHT = 2
+
     def _prepare_one(self, epoch: int, into: list):
-        """Batch len(into) of `epoch`: its col ids' fetch lists agreed between the ranks and its index, issued on the prepare
-        stream (its host reads wait for that stream only: the steps on the compute stream keep running)."""
-        b = len(into)
+        """The next batch of `epoch` (batch len(into) + those begun and not finished): its col ids' fetch lists agreed between
+        the ranks and its index, issued on the prepare stream — the steps on the compute stream keep running.  On a dealt
+        stream a prepare is begun here and finished PREPARES_IN_FLIGHT calls later (ShardedStepper.add_batch_dealt_begin /
+        _finish): its one host read finds the sizes already there."""
+        b = len(into) + len(self._begun)
         rs, cs = self.stream.epoch_sides(epoch)
         with torch.cuda.stream(self._prep):
             if b == 0:
                 self._prep.wait_event(self.stream.dealt_event(epoch))
             B = self.stream.B
             if self.stepper.col_per and not self.stepper.local_only:        # (col ids numbered owner-major: the batch arrives sorted for this form too)
-                into.append(self.stepper.add_batch_dealt(rs, cs, b * B, B, self.cap))
+                self._begun.append(self.stepper.add_batch_dealt_begin(rs, cs, b * B, B, self.cap))
+                if len(self._begun) > self.PREPARES_IN_FLIGHT:
+                    into.append(self.stepper.add_batch_dealt_finish(self._begun.pop(0)))
             else:
                 into.append(self.stepper.add_batch(*(t.contiguous() for t in rs.arrays(b * B, (b + 1) * B)), self.cap))
 
+    def _finish_begun(self, into: list):
+        with torch.cuda.stream(self._prep):
+            while self._begun:
+                into.append(self.stepper.add_batch_dealt_finish(self._begun.pop(0)))
+
     def _prepare_ahead(self):
         """One batch of the NEXT epoch per step of this one (every rank the same sequence: the collectives inside line up)."""
-        if getattr(self.stream, "masters", None) is not None and len(self._ahead) < self.nb:
+        if getattr(self.stream, "masters", None) is None:
+            return
+        if len(self._ahead) + len(self._begun) < self.nb:
             self._prepare_one(self.stream.epoch + 1, self._ahead)
+        elif self._begun:
+            with torch.cuda.stream(self._prep):
+                self._ahead.append(self.stepper.add_batch_dealt_finish(self._begun.pop(0)))
 
     def _launch(self, slot: int, off: int, count: int):
         """Steps off .. off + count - 1 of a slot: replayed from the hipGraph of that run (captured the first time it is
@@ -1054,11 +1144,13 @@ class ReshufflingRunner:
         first = self.position
         if self.sharded:
             count = min(n_steps, nb - first, self.burst)
-            # the run's steps first, then as many batches of the next epoch: the prepare's host reads (its fetch lists' sizes)
-            # block this thread, and the compute stream should have the whole run queued by then
+            # a step, then a batch of the next epoch, in turn: a prepare reads its sizes PREPARES_IN_FLIGHT batches late, so the
+            # host stays that far ahead of the prepare stream and never waits for the steps.  (All steps of the run first, then
+            # the prepares, left the prepares waiting for the whole run where their stream shared a hardware queue with the
+            # stream of the steps' push: a HIP process has four queues by default, a queue runs in order, and every push in it
+            # waits for its step — 1.7 - 1.9 ms per step against 1.25 on a static stream, rocprofv3 queue ids.)
             for b in range(first, first + count):
                 self.stepper.step(self.handles[b])
-            for _ in range(count):
                 self._prepare_ahead()
         elif self.hip is None:                     # a test backend: one synchronous build per step
             count = min(n_steps, nb - first, self.burst)
