@@ -219,10 +219,12 @@ struct StepConsts {
 // at four waves (compiled for one head: 165 VGPRs at three waves, 16 spilled at four) 697 against 574 and 122 against 95.
 // (the run-merged passes of 8-lane groups without records — d <= 64 on vocabularies far beyond text8's: off the benchmarked
 // path — do not fit four waves any more: three asked for, nothing spilled)
-template <int LPR, int NV, int FUSE, bool REC = true> struct FusePass {
+// (... and with the loss head read at run time — HEAD below: the logistic heads' exp / log expansions — the run-merged passes of
+// 8-lane groups do not fit four waves with records either: 29 - 34 VGPRs spilled at 128; three asked for)
+template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0> struct FusePass {
     static constexpr bool narrow = FUSE != 0 && LPR != 8 && NV == 1;
     static constexpr int unroll = narrow ? 4 : PassUnroll<NV>::value;
-    static constexpr int waves = narrow ? 4 : (FUSE != 0 && NV <= 3 && (LPR != 8 || !REC)) ? 3 : PassWaves<LPR>::value;
+    static constexpr int waves = narrow ? 4 : (FUSE != 0 && NV <= 3 && (LPR != 8 || !REC || HEAD < 0)) ? 3 : PassWaves<LPR>::value;
 };
 // HEAD: -1 = the loss head is read from the `head` argument at run time (the logistic heads); 0 = compiled for
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
@@ -233,7 +235,7 @@ template <int LPR, int NV, int FUSE, bool REC = true> struct FusePass {
 // partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
 // 153: a fourth wave per SIMD).
 template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1, int SIDE = -1>
-__global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC>::waves)) void sidepass_kernel(
+__global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
