@@ -313,8 +313,10 @@ def _two_rank_trainer_sorting_prepare(rank, port, argv, out_dir):
     for p in (here.parent, here):
         sys.path.insert(0, str(p))
     from trainer.stepper import ShardedStepper
-    ShardedStepper.add_batch_dealt = lambda self, rs, cs, first, B, cap: self.add_batch(
-        *(t.contiguous() for t in rs.arrays(first, first + B)), cap)
+    # (the runner prepares in two halves: the first only remembers the batch, the second does everything the general way)
+    ShardedStepper.add_batch_dealt_begin = lambda self, rs, cs, first, B, cap: dict(rs=rs, first=first, B=B, cap=cap)
+    ShardedStepper.add_batch_dealt_finish = lambda self, half: self.add_batch(
+        *(t.contiguous() for t in half["rs"].arrays(half["first"], half["first"] + half["B"])), half["cap"])
     _two_rank_trainer(rank, port, argv, out_dir)
 
 
