@@ -1016,6 +1016,8 @@ def main(argv=None):
                 raise SystemExit("--gpus %d but %d visible" % (args.gpus, torch.cuda.device_count()))
             raise SystemExit(launch_ranks(args.gpus, argv))
         args.gpus = world
+    if world > 1 or args.row_sharded or args.force_dense:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (trainer.estimator.multi_rank_queues: before the first GPU call)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # a rank that hangs (a collective nobody else entered) ends with a traceback instead of holding the node

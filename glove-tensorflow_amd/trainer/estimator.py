@@ -413,11 +413,21 @@ def estimator_predict(params):
     return Estimator(params).predict()
 
 
+def multi_rank_queues():
+    """A HIP process has four hardware queues by default and runs a queue's packets in order; a multi-rank process has more
+    streams than that (compute, the epoch deals, the prepares, the push all-to-all, RCCL's and torch's own), and two that
+    share a queue take turns whatever their events say (rocprofv3 queue ids: profiles/r05_exp_sharded_prepare_hw_queues.txt).
+    Eight queues, unless the caller has chosen; read by the HIP runtime when it starts, so call before the first GPU call."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def main(argv=None, adapt_params=None):
     """`adapt_params(params)`: hook for the sibling entry points that share this loop
     (trainer.logistic_matrix_factorisation)."""
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(name)s: %(message)s")
     world, rank, _ = _dist_env()
+    if world > 1:
+        multi_rank_queues()
     params = parse_args(argv) if rank == 0 or world == 1 else None
     if params is not None and adapt_params is not None:
         adapt_params(params)

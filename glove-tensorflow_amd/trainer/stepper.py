@@ -205,7 +205,9 @@ class SideCollective:
     stream itself capture and replay correctly.  On a CPU transport (the gloo tests) it is the transport's asynchronous form."""
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # (high priority: HIP keeps the hardware queues of each priority apart — at normal priority this stream has been seen
+        # sharing a queue with the compute stream, and a queue runs in order: no overlap at all)
+        self.stream = torch.cuda.Stream(device=device, priority=-1) if torch.device(device).type == "cuda" else None
         self.done, self.work = None, None
 
     def start(self, issue):
