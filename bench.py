@@ -1080,10 +1080,12 @@ def main(argv=None):
                   ("c4_zipf_v400k_d300_static_index", 12, dict(workload="zipf_v400k_d300", B=1048576, steps=24, warmup=4, max_batches=16)),
                   # BASELINE configs[0]'s shape (Keras-legacy Adam, the reference's default batch) as the trainer runs it, and static
                   ("c1_shape_adam_bs1024", 5, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001, dynamic=True)),
-                  ("c1_shape_adam_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001)),
+                  ("c1_shape_adam_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, optimizer="Adam", steps=2000, warmup=200, lr=0.001, max_batches=1024)),
                   # BASELINE configs[1] at the reference's batch size, at 131,072 pairs and at (nearly) the whole stream per step
                   ("text8_d64_bs1024", 5, dict(workload="text8_d64", B=1024, steps=2000, warmup=200, dynamic=True)),
-                  ("text8_d64_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200)),
+                  # (1,024 resident batches, most of an epoch, as the trainer's static mode keeps ALL of them: cycling through 8 leaves their
+                  # records and rows cache-hot — 8.4 against 8.9 us per step, profiles/r05_exp_resident_batches_bs1024.txt)
+                  ("text8_d64_bs1024_static_index", 4, dict(workload="text8_d64", B=1024, steps=2000, warmup=200, max_batches=1024)),
                   ("c2_text8_d64", 5, dict(workload="text8_d64", B=131072, steps=200, warmup=20, dynamic=True)),
                   ("c2_text8_d64_static_index", 4, dict(workload="text8_d64", B=131072, steps=200, warmup=20, max_batches=64)),
                   ("text8_d64_bs1048576_static_index", 4, dict(workload="text8_d64", B=1048576, steps=100, warmup=10)),

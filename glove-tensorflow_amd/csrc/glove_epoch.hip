@@ -318,8 +318,8 @@ struct DealJob {
     {
         int32_t batch;
         if (FIRST) {
-            const uint64_t p = s[side].link ? (uint64_t)(uint32_t)s[side].link[i] : (uint64_t)i;
-            const uint32_t seat = (uint32_t)feistel_walk(p, n, bits, key);
+            const uint32_t p = s[side].link ? (uint32_t)s[side].link[i] : (uint32_t)i;
+            const uint32_t seat = feistel_walk(p, (uint32_t)n, bits, key);
             batch = (int32_t)(bshift >= 0 ? seat >> bshift : seat / B);      // (uniform: a batch size that is a power of two)
             s[side].cache[i] = batch;
         } else {
