@@ -68,6 +68,43 @@ __device__ inline void store_row(float *table, size_t row_index, int d4, int lg,
     }
 }
 
+// ---- cache policy of the run-merged (fused) passes ----------------------------------------------------------------------
+// A fused pass is bound by the bytes its partner gathers miss the XCD's 4 MB L2 with: the L2 is worth what it
+// holds of the Zipf head of the partner table, and everything else that streams through it — the own rows and accumulator rows,
+// read once, and the finished rows and accumulators, written once and read by nobody in this launch — pushes those rows out.
+// So the streams are marked: own rows and accumulators are loaded non-temporal (`nt`: served by the L2, first in line to be
+// replaced), finished rows are stored write-through (`sc1`: the line does not stay in the L2; MI355X_MICROARCH.md, stores of
+// each flavour).  Same bits; one process, same resident plans, twin form, us per step (tools/ab_kernels.py,
+// profiles/r05_exp_cache_policy_fused_passes.txt):
+//                                   plain    sc1 stores   nt loads   both
+//   V = 400 k, d = 300, B = 1 M     585.1      582.1       575.8     571.2
+//   V = 2 M,   d = 128, B = 1 M     377.0      372.6       372.2     368.0
+// (nt on the pair fields and chunk descriptors as well: 571.6 / 369.9 — nothing, not taken; nt on the partner gathers of cold
+// ids lost in round 3: DESIGN_APPENDIX.md)
+template <int LPR, int NV>
+__device__ inline void load_row_nt(f4 (&dst)[NV], const float *table, int32_t id, int d4, int lg)
+{
+    const f4 *p = reinterpret_cast<const f4 *>(table) + (size_t)id * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        const f4 v = __builtin_nontemporal_load(p + (i4 < d4 ? i4 : d4 - 1));
+        dst[k] = (i4 < d4) ? v : f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int LPR, int NV>
+__device__ inline void store_row_wt(float *table, size_t row_index, int d4, int lg, const f4 (&src)[NV])
+{
+    f4 *p = reinterpret_cast<f4 *>(table) + row_index * d4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i4 = lg + k * LPR;
+        // (a store the compiler does not count in vmcnt: its own waits can only become longer by it, never shorter)
+        if (i4 < d4) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p + i4), "v"(src[k]) : "memory");
+    }
+}
+
 // ---- optimizer arithmetic (Keras-legacy forms) -------------------------
 // x / (sqrt(a) + eps) uses the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE
 // expansions: ~3 ulp on the update term, far inside the 1e-5 parity tolerance, and a third of the
@@ -230,7 +267,8 @@ template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0> struct FuseP
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
 // regression build 18 VGPRs at one float4 per lane — 119 against 101 — and 26 spilled scalar registers, whether they run or
 // not.  V = 2 M, d = 128, B = 1 M on the same plans, one process: 397 -> 355 us per step; V = 400 k, d = 300: 562 -> 554)
-// SIDE: -1 = the launch holds both sides (row side in the first row_blocks workgroups); 1 / 0 = it holds the row / the col side
+// SIDE: -1 / -2 = the launch holds both sides (row side in the first row_blocks workgroups; -2: with the streaming cache policy
+// below, the twin form's launches); 1 / 0 = it holds the row / the col side
 // alone (the three-launch fused form's launches): the col side's build then drops what only the loss needs — |c|^2 of every
 // partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
 // 153: a fourth wave per SIMD).
@@ -263,6 +301,11 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
     GLOVE_STAMP(0);
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
+    // SIDE == -2: the twin form's launches — tables beyond the caches: the streams of a fused pass leave the L2 to the partner
+    // rows (see "cache policy of the run-merged passes" above).  A build of its own: on cache-resident tables (V = 50 k, d = 300:
+    // the three-launch form) the policy costs 8 % (94.0 -> 101.8 us per step: the next launch finds the finished rows in the caches
+    // there), and as a run-time switch it cost every shape 1.2 %.
+    constexpr bool streams = FUSE == 1 && SIDE == -2;
     if (is_row && blockIdx.x == 0 && threadIdx.x == 0) {
         *step += 1;                         // global_step (see glove_hip.h)
         if (FUSE && work) work[0] = 0;      // the apply side's work list starts empty (triage_kernel)
@@ -449,11 +492,12 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
                 for (int k = 0; k < NV; ++k) A[k] = park[k * 64 + (threadIdx.x & 63)];
 #pragma unroll
                 for (int k = 0; k < NV; ++k) adagrad_vec(r[k], A[k], acc[k], kc.lr, kc.eps);
-                store_row<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
+                if (streams) store_row_wt<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A); else store_row<LPR, NV>(sd.S1, (size_t)cur_u, d4, lg, A);
                 const bool to_slot = sd.fuse == kFuseSlot;
                 // in place: the row itself; twin: the copy that is NOT current (own_at is the current one)
                 const size_t out_at = sd.fuse == kFuseTwin ? (size_t)(own_at == cur_u ? cur_u + sd.own_twin : cur_u) : (size_t)cur_u;
-                store_row<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
+                if (streams) store_row_wt<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
+                else store_row<LPR, NV>(to_slot ? sd.gp : sd.own_out, to_slot ? (size_t)run_first : out_at, d4, lg, r);
                 if (lg == 0) {
                     adagrad_elem(bval, Ab, Gb, kc.lr, kc.eps);
                     sd.S1b[cur_u] = Ab;
@@ -476,7 +520,9 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
             own_at = u;
             if (FUSE && sd.own_ver)                                                     // the current copy of a twinned table
                 own_at = u + ((use_desc ? desc[3 * kDescSlots + (j - j_first)] : (int32_t)sd.own_ver[u]) ? sd.own_twin : 0);
-            if (FUSE) load_row<LPR, NV>(r, sd.own, own_at, d4, lg); else load_row<LPR, NV>(r, sd.own, u, d4, lg);
+            if (FUSE && streams) load_row_nt<LPR, NV>(r, sd.own, own_at, d4, lg);
+            else if (FUSE) load_row<LPR, NV>(r, sd.own, own_at, d4, lg);
+            else load_row<LPR, NV>(r, sd.own, u, d4, lg);
             own_b = sd.own_bias[own_at];
             bg = own_b + g;
             // whole: the run starts at the id's first chunk and the id's last chunk is still inside this group's range
@@ -487,8 +533,9 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
                 for (int k = 0; k < NV; ++k) {
                     const int i4 = lg + k * LPR;
                     // destination: the wave-uniform base + lane * 16 B (the hardware adds the lane part)
-                    if (FULL || i4 < d4)
-                        __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 0);
+                    if (!(FULL || i4 < d4)) continue;
+                    if (streams) __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 2);      // aux 2 = nt
+                    else __builtin_amdgcn_global_load_lds(src + i4, (__attribute__((address_space(3))) void *)(park + k * 64), 16, 0, 0);
                 }
                 Ab = sd.S1b[u];
             }
@@ -2801,8 +2848,12 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 1 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 0 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)         /* (tables beyond the caches: the streaming build) */ \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? -2 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+        else if (FUSE == 1 && twin)                                                                                            \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, -1, FUSE == 1 ? -2 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else                                                                                                                   \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS);               \
     } while (0)
