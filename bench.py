@@ -975,7 +975,7 @@ def headline(out: dict) -> dict:
                                         for name, leg in cb.get("legs", {}).items() if isinstance(leg, dict)}
         if "error" in cb.get("legs", {}):
             line["cpu_baseline"]["error"] = str(cb["legs"]["error"])[:200]
-    for k in ("configs_skipped", "configs_file", "final_loss", "wall_seconds"):
+    for k in ("configs_skipped", "configs_failed", "configs_file", "final_loss", "wall_seconds"):
         if k in out:
             line[k] = out[k]
     if "configs" in out:
@@ -1001,6 +1001,17 @@ def write_configs_file(out: dict) -> str:
         except OSError:
             continue
     return ""
+
+
+def emit_headline(out: dict, rank: int) -> None:
+    """Rank 0: the headline as a `[bench-config]` stderr line, the side file, and THE stdout line (the only JSON line there)."""
+    if rank != 0:
+        return
+    out["name"] = "headline"
+    print("[bench-config] " + json.dumps(config_line(out)), file=sys.stderr, flush=True)
+    out["configs_file"] = write_configs_file(out)
+    sys.stderr.flush()
+    print(json.dumps(headline(out)), flush=True)
 
 
 def main(argv=None):
@@ -1099,10 +1110,18 @@ def main(argv=None):
                   ("c4_zipf_v400k_d300_data_parallel_static_index", 60, dict(workload="zipf_v400k_d300", B=1048576, steps=12, warmup=3, mode="dp")),
                   ("c5_zipf_v2m_d128_both_tables_sharded", 70, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded", dynamic=True)),
                   ("c5_zipf_v2m_d128_both_tables_sharded_static_index", 60, dict(workload="zipf_v2m_d128", B=1048576, steps=12, warmup=3, mode="sharded"))])
-        configs, skipped = [], []
+        if world > 1 and not args.with_configs:
+            # more than one GPU: the static companion of the headline only; the other forms on request (--with-configs)
+            specs = specs[:1]
+        if world > 1:
+            # no run of this path on more than one GPU exists: the headline is on stdout before any side
+            # configuration starts, so nothing that happens in one of them can take it away
+            out["wall_seconds"] = time.perf_counter() - T_START
+            emit_headline(out, rank)
+        configs, skipped, failed = [], [], []
         for name, est, spec in specs:
             # the decision is rank 0's (the ranks' clocks differ) and collective
-            go = torch.tensor([1 if time.perf_counter() - T_START + est <= args.budget_seconds else 0], device=dev)
+            go = torch.tensor([1 if time.perf_counter() - T_START + est <= args.budget_seconds and not (failed and world > 1) else 0], device=dev)
             if world > 1:
                 dist.broadcast(go, src=0)
             if not int(go.item()):
@@ -1110,26 +1129,35 @@ def main(argv=None):
                 continue
             kw = dict(extra)
             kw.update({k: v for k, v in spec.items() if k not in ("workload", "B")})
-            r = run_config(ctx, spec["workload"], spec["B"], **kw)
+            try:
+                r = run_config(ctx, spec["workload"], spec["B"], **kw)
+            except Exception as exc:            # a side configuration never costs the run its headline
+                import traceback
+                traceback.print_exc()
+                failed.append({"name": name, "error": ("%s: %s" % (type(exc).__name__, exc))[:200]})
+                if world > 1:
+                    break                       # (the ranks are no longer in step: no further collective decision)
+                continue
             r["name"] = name
             r = brief(r)
             configs.append(r)
             if rank == 0:
                 print("[bench-config] " + json.dumps(config_line(r)), file=sys.stderr, flush=True)
         out["configs_skipped"] = skipped
+        if failed:
+            out["configs_failed"] = failed
         out["configs"] = configs
         # the headline workload in the trainer's static mode, beside the headline
         for r in configs:
             if r["name"] == "c4_zipf_v400k_d300_static_index":
                 out["config"]["same_workload_static_index"] = {
                     "nonzeros_per_s": r["value"], "ms_per_step": r["ms_per_step"], "index": r["config"]["index"]}
-    out["wall_seconds"] = time.perf_counter() - T_START
-    if rank == 0:
-        out["name"] = "headline"
-        print("[bench-config] " + json.dumps(config_line(out)), file=sys.stderr, flush=True)
-        out["configs_file"] = write_configs_file(out)
-        sys.stderr.flush()
-        print(json.dumps(headline(out)), flush=True)          # the last thing on stdout, and the only JSON line
+    out.setdefault("wall_seconds", time.perf_counter() - T_START)
+    if world > 1 and plain:
+        if rank == 0:
+            write_configs_file(out)             # (the stdout line went out before the side configurations)
+    else:
+        emit_headline(out, rank)
     faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         import gc

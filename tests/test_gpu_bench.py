@@ -49,3 +49,14 @@ def test_two_ranks_rehearsed_on_one_gpu_print_one_short_headline_line():
     assert j["process_group"]["world_size"] == 2 and j["process_group"]["backend"] == "gloo" and len(j["process_group"]["devices_by_rank"]) == 2
     assert j["collectives"]["all_to_all_ms"] > 0 and 0.0 < j["roofline"]["frac"] < 1.0
     assert abs(j["value"] - 2 * 1048576 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+def test_more_than_one_rank_prints_the_headline_before_any_side_configuration():
+    """At N > 1 the stdout line goes out before the side configurations start (here: all of them cut by the budget), so a
+    failure in one of them cannot cost the run its headline; the side file is rewritten afterwards."""
+    j, err = _run(["--gpus", "2", "--rehearse-on-one-gpu", "--with-configs", "--steps", "4", "--warmup", "1", "--budget-seconds", "1"])
+    assert j["n_gpus"] == 2 and j["config"]["index"] == "dealt" and "configs_skipped" not in j
+    marks = [json.loads(ln[len("[bench-config] "):]) for ln in err.splitlines() if ln.startswith("[bench-config] ")]
+    assert [m["name"] for m in marks] == ["headline"]
+    side = json.loads((REPO / j["configs_file"]).read_text())
+    assert len(side["configs_skipped"]) == 4 and side["configs"] == []
