@@ -118,18 +118,22 @@ __host__ __device__ inline uint32_t feistel_mix(uint32_t x, uint32_t k)
 
 // (32-bit arithmetic: glove_epoch_deal takes n < 2^31, so bits <= 31 and both halves fit 16 bits — the 64-bit form cost the
 // deal's histogram pass twice the integer instructions per round)
-__host__ __device__ inline uint32_t feistel_walk(uint32_t x, uint32_t n, int bits, uint4 key)
+// one trip through the network (a bijection of [0, 2^bits))
+__host__ __device__ inline uint32_t feistel_once(uint32_t x, int bits, uint4 key)
 {
     const int hb = bits / 2, lb = bits - hb;
     const uint32_t hmask = (1u << hb) - 1u, lmask = (1u << lb) - 1u;
-    do {
-        uint32_t H = x >> lb, L = x & lmask;
-        H ^= feistel_mix(L, key.x) & hmask;
-        L ^= feistel_mix(H, key.y) & lmask;
-        H ^= feistel_mix(L, key.z) & hmask;
-        L ^= feistel_mix(H, key.w) & lmask;
-        x = (H << lb) | L;
-    } while (x >= n);
+    uint32_t H = x >> lb, L = x & lmask;
+    H ^= feistel_mix(L, key.x) & hmask;
+    L ^= feistel_mix(H, key.y) & lmask;
+    H ^= feistel_mix(L, key.z) & hmask;
+    L ^= feistel_mix(H, key.w) & lmask;
+    return (H << lb) | L;
+}
+
+__host__ __device__ inline uint32_t feistel_walk(uint32_t x, uint32_t n, int bits, uint4 key)
+{
+    do x = feistel_once(x, bits, key); while (x >= n);
     return x;
 }
 
