@@ -132,17 +132,20 @@ def free_port() -> int:
 def launch_ranks(n: int, argv: list) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this process has not
     touched the GPU and never will), relay rank 0's JSON line, return the child's exit code."""
-    proc = subprocess.run(launcher_argv(n, argv, free_port()), stdout=subprocess.PIPE, text=True, cwd=str(REPO))
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
-    for ln in proc.stdout.splitlines():
-        if not ln.startswith('{"metric"'):
-            print(ln, file=sys.stderr)
-    if proc.returncode == 0 and len(lines) != 1:
-        print("expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+    proc = subprocess.Popen(launcher_argv(n, argv, free_port()), stdout=subprocess.PIPE, text=True, cwd=str(REPO))
+    lines = 0
+    for ln in proc.stdout:              # relayed as it comes: rank 0's line is out before the side configurations start
+        ln = ln.rstrip("\n")
+        if ln.startswith('{"metric"'):
+            lines += 1
+            print(ln, flush=True)
+        else:
+            print(ln, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print("expected one JSON line from rank 0, got %d" % lines, file=sys.stderr)
         return 1
-    for ln in lines:
-        print(ln, flush=True)
-    return proc.returncode
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------ figures

@@ -272,12 +272,41 @@ template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0> struct FuseP
 // alone (the three-launch fused form's launches): the col side's build then drops what only the loss needs — |c|^2 of every
 // partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
 // 153: a fourth wave per SIMD).
+// The twin form's col-side launch carries, behind its pass workgroups, the workgroups that list the light ids the apply launch
+// still has to visit (a thread per distinct id: an id one run did not hold completely goes onto work[4 ...], work[0] counts
+// them — zeroed by the row-side launch before).  The list depends on the plan alone, so it is drawn in the shadow of the pass's
+// last workgroups instead of in a launch of its own between pass and apply (triage_kernel: 5 us + a launch boundary per step;
+// the version flips of the finished row ids, which do have to wait for the col side's gathers, moved into the apply launch).
+struct ListTail {
+    const int32_t *counts;          // device counts[8]
+    const int32_t *rec_r, *rec_c;   // {id, first chunk, chunks, pairs} per distinct id
+    int nu_r_host, nu_c_host;       // -1 = read the device counts
+    int heavy_chunks, per;
+    int first_block;                // workgroups from here on list; < 0: no tail in this launch
+};
+
+__device__ inline void list_unfinished_ids(const ListTail &tl, int32_t *__restrict__ work, int q)
+{
+    const int nu_r = tl.nu_r_host >= 0 ? tl.nu_r_host : tl.counts[1];
+    const int nu_c = tl.nu_c_host >= 0 ? tl.nu_c_host : tl.counts[3];
+    if (q >= nu_r + nu_c) return;
+    const int4 rec = q < nu_r ? reinterpret_cast<const int4 *>(tl.rec_r)[q] : reinterpret_cast<const int4 *>(tl.rec_c)[q - nu_r];
+    if (rec.z > tl.heavy_chunks) return;                                            // heavy ids keep their own workgroups
+    const int runs = 1 + (rec.y + rec.z - 1) / tl.per - rec.y / tl.per;             // (Slots::count)
+    if (runs == 1) return;                                                          // one run held it: the pass applied it
+    work[4 + atomicAdd(work, 1)] = q;
+}
+
 template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1, int SIDE = -1>
 __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
-    float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work)
+    float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work, ListTail tail)
 {
+    if (FUSE == 1 && SIDE == -2 && tail.first_block >= 0 && (int)blockIdx.x >= tail.first_block) {      // (block-uniform)
+        list_unfinished_ids(tail, work, ((int)blockIdx.x - tail.first_block) * kBlock + (int)threadIdx.x);
+        return;
+    }
     constexpr int GPB = kBlock / LPR;
     constexpr int U = FusePass<LPR, NV, FUSE>::unroll;
     constexpr int SL = kChunkMax / LPR > 0 ? kChunkMax / LPR : 1;     // pairs a lane stages
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
     const bool is_row = SIDE < 0 ? (int)blockIdx.x < row_blocks : SIDE == 1;
     const PassSide &sd = is_row ? rowside : colside;
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
-    const int nblk = is_row ? row_blocks : gridDim.x - row_blocks;
+    const int nblk = is_row ? row_blocks : (FUSE == 1 && SIDE == -2 && tail.first_block >= 0 ? tail.first_block : (int)gridDim.x) - row_blocks;
     GLOVE_STAMP(0);
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
@@ -708,6 +737,8 @@ struct IdWork {
     int per;                    // consecutive chunks per group of that FUSE pass
     const int32_t *work;        // not null: triage_kernel listed the light ids that still need this launch: work[0] = their
                                 // number, work[4 ...] = their positions q (row ids first, col ids behind nu_r)
+    int flips;                  // 1: the list came from the col-side launch (ListTail): the version flips of the row ids a run of the
+                                // twin form's row pass finished are still to do — here, a thread per row id
 };
 
 // The partial rows of one id.  Classic passes: one per chunk, slots f .. f+n-1 (per == 1).  FUSE passes: one per run, a
@@ -833,6 +864,15 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
     // the last workgroup of the grid only does the once-per-step scalar work, beside everyone else
     if ((int)blockIdx.x == nblocks - 1) return (wk.sides & 2) != 0;
     const int lb = blockIdx.x - wk.heavy_blocks, nlb = nblocks - wk.heavy_blocks - 1;
+    if (wk.flips) {
+        // twin form, list drawn by the col-side launch: the row ids one run of the row pass held completely have their new
+        // row in the other copy — flip their version now that no gather reads the old one (ids are distinct: a thread per byte;
+        // the ids on the list are not among them)
+        for (int q = lb * kBlock + (int)threadIdx.x; q < nu_r; q += nlb * kBlock) {
+            const int4 rec = reinterpret_cast<const int4 *>(rs.uniq_rec)[q];
+            if (rec.z <= wk.heavy_chunks && Slots(rec.y, rec.z, wk.per).count == 1) rs.ver[rec.x] ^= 1;
+        }
+    }
     // behind a FUSE pass triage_kernel has listed the few ids that still need work: walk that list instead of all ids
     const int n_items = wk.work ? wk.work[0] : total - q_begin;
     for (int it = lb * GPB + grp; it < n_items; it += nlb * GPB) {
@@ -2666,6 +2706,7 @@ static IdWork id_work(const glove_plan *p)
     w.pre_r = w.pre_c = kFuseNone;
     w.per = 1;
     w.work = nullptr;
+    w.flips = 0;
     return w;
 }
 
@@ -2803,7 +2844,7 @@ static PassSide pass_side(const glove_plan *p, const glove_tables *t, const Step
 static int launch_passes(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws, size_t ws_bytes,
                          void *stream, int which, float *mark_rows = nullptr, float *mark_cols = nullptr,
                          bool want_e = false, int fuse_r = kFuseNone, int fuse_c = kFuseNone, bool twin = false,
-                         float *packed = nullptr)
+                         float *packed = nullptr, bool list_tail = false)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     const bool fuse = fuse_r != kFuseNone || fuse_c != kFuseNone || twin;
@@ -2833,7 +2874,16 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     }
     const StepConsts kc = make_consts(t, h);
     hipStream_t st = (hipStream_t)stream;
-#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work
+    // the twin form's col-side launch: behind the pass, the workgroups that list the ids the apply launch has to visit
+    ListTail tail{p->counts, p->r_uniq_rec, p->c_uniq_rec, p->host_counts[1], p->host_counts[3], p->heavy_chunks, per, -1};
+    int nb_launch = nb;
+    if (list_tail) {
+        if (!twin || which != 2 || fuse_c != kFuseInPlace || !w.work || sides_of(h) != 3) return GLOVE_E_BADARG;
+        const int64_t ids = tail.nu_r_host >= 0 && tail.nu_c_host >= 0 ? (int64_t)tail.nu_r_host + tail.nu_c_host : 2 * (int64_t)p->cap_uniq;
+        tail.first_block = nb;
+        nb_launch = nb + (int)((ids + kBlock - 1) / kBlock);
+    }
+#define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work, tail
     // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
     if (!rec && p->B > 0 && !p->r_partner) return GLOVE_E_BADARG;     // (the diagnostic pass needs pair arrays)
@@ -2849,11 +2899,11 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 0 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)         /* (tables beyond the caches: the streaming build) */ \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? -2 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? -2 : -1>), dim3(nb_launch), dim3(kBlock), 0, st, ARGS); \
         else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
         else if (FUSE == 1 && twin)                                                                                            \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, -1, FUSE == 1 ? -2 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, -1, FUSE == 1 ? -2 : -1>), dim3(nb_launch), dim3(kBlock), 0, st, ARGS); \
         else                                                                                                                   \
             hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS);               \
     } while (0)
@@ -2894,7 +2944,7 @@ int glove_colpass_f32(const glove_plan *p, const glove_tables *t, const glove_hy
 }
 
 static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, const glove_hyper *h, void *ws,
-                                size_t ws_bytes, float *loss_out, void *stream, int pre_r, int pre_c)
+                                size_t ws_bytes, float *loss_out, void *stream, int pre_r, int pre_c, bool listed = false)
 {
     if (int rc = check_common(p, t, h, ws)) return rc;
     if (!t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
@@ -2922,7 +2972,12 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
     hipStream_t st = (hipStream_t)stream;
     const bool short_list = (pre_r == kFuseTwin && pre_c == kFuseInPlace && wk.sides == 3) ||
                             (pre_r == kFuseInPlace && wk.sides == 1);        // glove_rowside_step_adagrad_f32
-    if (short_list && w.work) {
+    if (listed) {
+        // the col-side launch drew the list (ListTail); the finished row ids' version flips are this launch's (for_each_id)
+        if (!(pre_r == kFuseTwin && pre_c == kFuseInPlace && wk.sides == 3) || !w.work) return GLOVE_E_BADARG;
+        wk.work = w.work;
+        wk.flips = 1;
+    } else if (short_list && w.work) {
         // sort the ids out first (triage_kernel, a thread per id): the launch below then walks the list of those that
         // still need it.  Only where that list is short — the twin form, whose finished ids need a version flip at most
         // (V = 400 k, d = 300: apply 62 -> 12 us + 5 us of triage), and the in-place row side of the sharded forms,
@@ -3413,8 +3468,13 @@ int glove_step_adagrad_f32(const glove_plan *p, const glove_tables *t, const glo
         // the col side keeps gathering the old rows from the current copy, and the apply launch only flips versions
         if (!t->R_ver) return GLOVE_E_BADARG;
         if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 1, nullptr, nullptr, false, kFuseTwin, kFuseNone, true)) return rc;
-        if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 2, nullptr, nullptr, false, kFuseNone, kFuseInPlace, true)) return rc;
-        return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseTwin, kFuseInPlace);
+        {
+            // (the list of ids for the apply launch rides in the col-side launch when both sides step and the workspace has the list)
+            const StepWs w = carve_step_ws(ws, p->B, p->cap_chunks, t->d);
+            const bool tail = w.work != nullptr && sides_of(h) == 3;
+            if (int rc = launch_passes(p, t, h, ws, ws_bytes, stream, 2, nullptr, nullptr, false, kFuseNone, kFuseInPlace, true, nullptr, tail)) return rc;
+            return launch_apply_adagrad(p, t, h, ws, ws_bytes, loss_out, stream, kFuseTwin, kFuseInPlace, tail);
+        }
     case GLOVE_STEP_TWO_LAUNCH:
         break;
     default:
