@@ -234,10 +234,13 @@ def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
         monkeypatch.delenv(k, raising=False)
     seen = {}
 
-    def fake_run(cmd, **kw):
-        seen["cmd"], seen["kw"] = cmd, kw
-        return types.SimpleNamespace(returncode=0, stdout='rank 1 says hello\n{"metric": "co-occurrence nonzeros/sec", "n_gpus": 4}\n')
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    def fake_child(code, text):
+        def popen(cmd, **kw):
+            seen["cmd"], seen["kw"] = cmd, kw
+            return types.SimpleNamespace(stdout=iter(text.splitlines(keepends=True)), wait=lambda: code)
+        return popen
+    # (rank 0's line is relayed as it comes — at N > 1 it is printed before the side configurations start)
+    monkeypatch.setattr(subprocess, "Popen", fake_child(0, 'rank 1 says hello\n{"metric": "co-occurrence nonzeros/sec", "n_gpus": 4}\n'))
     monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
     monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
     with pytest.raises(SystemExit) as exc:
@@ -252,7 +255,7 @@ def test_bench_gpus_n_starts_the_ranks_itself(monkeypatch, capsys):
     out = capsys.readouterr()
     assert out.out.strip() == '{"metric": "co-occurrence nonzeros/sec", "n_gpus": 4}' and "rank 1 says hello" in out.err
     # a failing child fails the bench; more GPUs asked for than visible is refused before any launch
-    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: types.SimpleNamespace(returncode=3, stdout=""))
+    monkeypatch.setattr(subprocess, "Popen", fake_child(3, ""))
     with pytest.raises(SystemExit) as exc:
         bench.main(["--gpus", "2"])
     assert exc.value.code == 3
