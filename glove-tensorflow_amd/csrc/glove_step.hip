@@ -834,7 +834,9 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
             fn.prefetch(is_row, id, st);
         }
         // a heavy id is the longest dependent chain of the launch (the head of a Zipf batch: ~50 rows per group):
-        // four rows in flight per trip at every row width (16 cost the d = 64 shape its occupancy: 8.4 -> 9.3 us)
+        // four rows in flight per trip at every row width (16 cost the d = 64 shape its occupancy: 8.4 -> 9.3 us; round 5, the
+        // twin form's short-list apply, whole step, same plans: V = 400 k, d = 300 548.8 us with 4, 556.5 with 8, 555.4 with 16;
+        // V = 2 M, d = 128 359.1 / 358.0 / 360.1 — profiles/r05_exp_heavy_rows_in_flight.txt)
         sum_partials<LPR, NV, 4>(sb, sl, grp, GPB, d4, lg, G, Gb);
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) red[grp][lg + kk * LPR] = G[kk];
