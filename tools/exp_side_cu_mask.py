@@ -51,8 +51,10 @@ def main():
         tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
         backend.row_floats = tables.d
         stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False)
-        if share:
+        if share > 0:
             stream.side = masked_stream(hiplib, dev, share)
+        elif share < 0:                 # no second stream at all: deals and index builds in line with the steps
+            stream.side = torch.cuda.current_stream(dev)
         hyper = make_hyper(batch_size=B, learning_rate=0.05)
         runner = ReshufflingRunner(hip, stream, tables, hyper, burst=64)
         out = []
@@ -65,7 +67,7 @@ def main():
             torch.cuda.synchronize()
             if rnd:
                 out.append((time.perf_counter() - t0) * 1e6 / args.steps)
-        print("  side stream on %-22s %s" % ("all CUs (torch stream)" if not share else "1/%d of the CUs" % share,
+        print("  side stream on %-22s %s" % ("all CUs (torch stream)" if not share else "the steps' own stream" if share < 0 else "1/%d of the CUs" % share,
                                             "  ".join("%.1f" % x for x in out)), flush=True)
         del runner, stream, tables
         torch.cuda.synchronize()
