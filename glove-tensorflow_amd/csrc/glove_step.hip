@@ -258,10 +258,11 @@ struct StepConsts {
 // path — do not fit four waves any more: three asked for, nothing spilled)
 // (... and with the loss head read at run time — HEAD below: the logistic heads' exp / log expansions — the run-merged passes of
 // 8-lane groups do not fit four waves with records either: 29 - 34 VGPRs spilled at 128; three asked for)
-template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0> struct FusePass {
+// (... and neither do their builds with solid workgroups — SOLID below: 2 VGPRs spilled at four waves)
+template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0, bool SOLID = false> struct FusePass {
     static constexpr bool narrow = FUSE != 0 && LPR != 8 && NV == 1;
     static constexpr int unroll = narrow ? 4 : PassUnroll<NV>::value;
-    static constexpr int waves = narrow ? 4 : (FUSE != 0 && NV <= 3 && (LPR != 8 || !REC || HEAD < 0)) ? 3 : PassWaves<LPR>::value;
+    static constexpr int waves = narrow ? 4 : (FUSE != 0 && NV <= 3 && (LPR != 8 || !REC || HEAD < 0 || SOLID)) ? 3 : PassWaves<LPR>::value;
 };
 // HEAD: -1 = the loss head is read from the `head` argument at run time (the logistic heads); 0 = compiled for
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
@@ -297,8 +298,11 @@ __device__ inline void list_unfinished_ids(const ListTail &tl, int32_t *__restri
     work[4 + atomicAdd(work, 1)] = q;
 }
 
-template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1, int SIDE = -1>
-__global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)) void sidepass_kernel(
+// SOLID: the build that adds up, per workgroup, the sums of lane groups that all hold one id (batches of 131,072 chunks a side and
+// more: solid_groups) — a build of its own, so that the others keep their registers (compiled into all of them the epilogue cost
+// five shapes a wave per SIMD and the 8-lane shapes 45 spilled VGPRs)
+template <int LPR, int NV, bool FULL, bool REC, int FUSE, int HEAD = -1, int SIDE = -1, bool SOLID = false>
+__global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD, SOLID>::waves)) void sidepass_kernel(
     const int32_t *__restrict__ counts, PassSide rowside, PassSide colside, int row_blocks,
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work, ListTail tail)
@@ -396,6 +400,22 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
                 stage[i] = pid;
                 stage[kStagePairs + i] = __float_as_uint(sd.w[stage_first + i]);
                 stage[2 * kStagePairs + i] = __float_as_uint(sd.y[stage_first + i]);
+            }
+        }
+    }
+    // FUSE == 1: a workgroup all of whose chunks belong to ONE id (the head of a Zipf batch: its full chunks fill dozens of
+    // workgroups) adds its groups' sums up before it leaves — one partial row per workgroup instead of one per group for the one
+    // workgroup that has to sum them in the apply launch (its longest chain: V = 400 k, B = 1 M, the id of rank 1: 400 rows)
+    bool solid = false;
+    if (FUSE == 1 && SOLID) {
+        const int f0 = bid * GPB * per, l0 = f0 + GPB * per - 1;
+        if (l0 < n_chunks) {
+            if (REC) {
+                const uint4 *rq = reinterpret_cast<const uint4 *>(sd.crec);
+                const size_t stride = rec_stride_q(sd.capP);
+                solid = rq[(size_t)f0 * stride].x == rq[(size_t)l0 * stride].x;
+            } else {
+                solid = sd.chunk_id[f0] == sd.chunk_id[l0];
             }
         }
     }
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
                     sd.S1b[cur_u] = Ab;
                     if (to_slot) sd.gb[run_first] = bval; else sd.own_bias_out[out_at] = bval;
                 }
-            } else {
+            } else if (!(FUSE == 1 && SOLID && solid)) {     // (a solid workgroup's sums leave together, below)
                 store_row<LPR, NV>(sd.gp, (size_t)run_first, d4, lg, acc);
                 if (lg == 0) {
                     sd.gb[run_first] = se;
@@ -699,6 +719,28 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD>::waves)
             }
         }
     }
+    if (FUSE == 1 && SOLID && solid) {      // block-uniform
+        // every group holds the sums of its one run (same id everywhere): groups 0 .. GPB - 1 added in that order by group 0, one
+        // partial row in the slot of the workgroup's first chunk.  (A wave writes into its own part of the parking image, which
+        // no run of a solid workgroup has used: no run of it was whole.)
+        __shared__ float solid_bias[SOLID ? GPB : 1];
+        f4 *sums = park_raw;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sums[(grp * NV + k) * LPR + lg] = acc[k];
+        if (lg == 0) solid_bias[grp] = se;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll 1
+            for (int g2 = 1; g2 < GPB; ++g2) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) acc[k] += sums[(g2 * NV + k) * LPR + lg];
+                se += solid_bias[g2];
+            }
+            const size_t slot = (size_t)bid * GPB * per;
+            store_row<LPR, NV>(sd.gp, slot, d4, lg, acc);
+            if (lg == 0) sd.gb[slot] = se;
+        }
+    }
     GLOVE_DRAIN(); GLOVE_STAMP(4);          // stores retired
     if (is_row) {                           // block-uniform
         part[0] *= 0.5f / inv_batch;        // sum e diff = 2 inv_batch sum w diff^2
@@ -735,6 +777,7 @@ struct IdWork {
     int sides;                  // 1 = rows only, 2 = cols only, 3 = both
     int pre_r, pre_c;           // what a FUSE pass already did for the ids one run held completely (kFuse*), per side
     int per;                    // consecutive chunks per group of that FUSE pass
+    int gpb;                    // ... and its lane groups per workgroup (solid workgroups leave one partial row: Slots); 0 = none
     const int32_t *work;        // not null: triage_kernel listed the light ids that still need this launch: work[0] = their
                                 // number, work[4 ...] = their positions q (row ids first, col ids behind nu_r)
     int flips;                  // 1: the list came from the col-side launch (ListTail): the version flips of the row ids a run of the
@@ -744,13 +787,41 @@ struct IdWork {
 // The partial rows of one id.  Classic passes: one per chunk, slots f .. f+n-1 (per == 1).  FUSE passes: one per run, a
 // run being the id's chunks inside one group's range of `per` consecutive chunks: the k-th run starts at the id's
 // first chunk (k == 0) or at the k-th multiple of `per` behind it.
+// Behind a run-merged applying pass (gpb > 0: its lane groups per workgroup) a workgroup whose gpb * per chunks ALL belong to the
+// id — a "solid" workgroup: the head of a Zipf batch owns dozens of them — has added its groups' sums up in LDS and left ONE
+// partial row, in the slot of its first chunk (sidepass_kernel): the runs of the id are then the group ranges in front of its first
+// solid workgroup, one per solid workgroup, and the group ranges behind the last (the id of rank 1 of the headline batch: 55 partial
+// rows instead of 400 for the one workgroup that sums them in the apply launch).
 struct Slots {
     int f, per, count;
-    __device__ Slots(int first_chunk, int chunks, int per_) : f(first_chunk), per(per_)
+    int gpb, g0, head, sb0, nsb;
+    bool one_group;
+    __device__ Slots(int first_chunk, int chunks, int per_, int gpb_ = 0) : f(first_chunk), per(per_), gpb(gpb_)
     {
-        count = 1 + (first_chunk + chunks - 1) / per_ - first_chunk / per_;
+        g0 = first_chunk / per_;
+        const int g1 = (first_chunk + chunks - 1) / per_;
+        one_group = g1 == g0;                                       // one group's range held all its chunks: the pass applied it
+        count = head = 1 + g1 - g0;
+        sb0 = nsb = 0;
+        if (gpb_ > 0) {
+            const int bc = gpb_ * per_;                             // chunks of a workgroup
+            const int bs = (first_chunk + bc - 1) / bc;             // workgroups [bs, be) lie inside the id's chunks
+            const int be = (first_chunk + chunks) / bc;
+            if (be > bs) {
+                sb0 = bs;
+                nsb = be - bs;
+                head = bs * gpb_ - g0;
+                count = head + nsb + (g1 + 1 - be * gpb_);
+            }
+        }
     }
-    __device__ int at(int k) const { return k == 0 ? f : (f / per + k) * per; }
+    __device__ int at(int k) const
+    {
+        if (k == 0) return f;
+        if (k < head) return (g0 + k) * per;
+        if (k < head + nsb) return (sb0 + (k - head)) * gpb * per;
+        return ((sb0 + nsb) * gpb + (k - head - nsb)) * per;
+    }
 };
 
 // G += partial rows k0, k0+stride, ... (< sl.count), PB loads in flight at a time, added in order
@@ -810,8 +881,8 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         const int4 rec = reinterpret_cast<const int4 *>(sb.uniq_rec)[code & 0x3fffffff];
         const int32_t id = rec.x;
         const int pre = is_row ? wk.pre_r : wk.pre_c;
-        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1);
-        if (pre != kFuseNone && sl.count == 1) {       // one run held the whole id: the pass kernel applied it
+        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1, pre != kFuseNone ? wk.gpb : 0);
+        if (pre != kFuseNone && sl.one_group) {       // one run held the whole id: the pass kernel applied it
             if (pre == kFuseSlot && grp == 0) {
                 f4 Wn[NV];
                 load_row<LPR, NV>(Wn, sb.gp, sl.f, d4, lg);
@@ -887,9 +958,9 @@ __device__ inline bool for_each_id(const IdWork &wk, const SideBufs &rs, const S
         GLOVE_DRAIN(); GLOVE_STAMP(1);      // record arrived
         const int32_t id = rec.x;
         const int pre = is_row ? wk.pre_r : wk.pre_c;
-        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1);
+        const Slots sl(rec.y, rec.z, pre != kFuseNone ? wk.per : 1, pre != kFuseNone ? wk.gpb : 0);
         const int sl0 = sl.f;
-        if (pre != kFuseNone && sl.count == 1) {
+        if (pre != kFuseNone && sl.one_group) {
             // one run held the whole id and the pass kernel already applied it (sidepass_kernel FUSE): in place ->
             // nothing left to do; into its slot -> move the finished row and bias into the table now that no pass
             // reads the old ones; twin -> the other copy holds the new row: flip the version
@@ -2707,6 +2778,7 @@ static IdWork id_work(const glove_plan *p)
     w.sides = 3;
     w.pre_r = w.pre_c = kFuseNone;
     w.per = 1;
+    w.gpb = 0;
     w.work = nullptr;
     w.flips = 0;
     return w;
@@ -2740,6 +2812,15 @@ static inline int rowpass_blocks(const glove_plan *p, int lpr) { return blocks_f
 // chunks to fill the chip with such groups (V = 400 k at B = 131,072: per 1 or 2 156 us, per 4 165 us; V = 50 k: 103 /
 // 103 / 106), more only when the plan has more chunks than kMaxPassBlocks workgroups of such groups cover (the loss
 // partials are kept per workgroup).
+// Solid workgroups (sidepass_kernel, Slots) pay where the head of the batch leaves hundreds of partial rows: from 131,072 chunks a
+// side (V = 400 k, d = 300, one process, same plans: B = 1 M 565.3 -> 557.7 us per step; at B = 131,072 — 50 k chunks, the id of
+// rank 1 in 50 runs — the head workgroups' epilogue is on the passes' critical path: 139.3 -> 142.4).  Pass and apply launch ask here.
+static bool solid_groups(const glove_plan *p)
+{
+    const int64_t r = most_chunks(p, true), c = most_chunks(p, false);
+    return (r > c ? r : c) >= 131072;
+}
+
 static int fuse_per(const glove_plan *p, int lpr)
 {
     const int64_t nr = most_chunks(p, true), nc = most_chunks(p, false);
@@ -2886,9 +2967,18 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
         nb_launch = nb + (int)((ids + kBlock - 1) / kBlock);
     }
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work, tail
+    const bool solid = fuse && !pack && solid_groups(p);        // (the applying run-merged passes: FUSE == 1)
     // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
     if (!rec && p->B > 0 && !p->r_partner) return GLOVE_E_BADARG;     // (the diagnostic pass needs pair arrays)
+// (K: one launch of the build <..., HEAD, SIDE>, in its solid form where the batch calls for it — FUSE == 1 only)
+#define K(LPR, NV, FULL, REC, FUSE, HEAD, SIDE, GRID)                                                                          \
+    do {                                                                                                                       \
+        if (FUSE == 1 && solid)                                                                                                \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, HEAD, SIDE, FUSE == 1>), dim3(GRID), dim3(kBlock), 0, st, ARGS); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, HEAD, SIDE, false>), dim3(GRID), dim3(kBlock), 0, st, ARGS); \
+    } while (0)
 #define LAUNCH(LPR, NV, FULL, REC, FUSE)                                                                                       \
     do {                                                                                                                       \
         /* every pass compiled for the regression head (the same bits are asked of all of them on ids one chunk holds: one     \
@@ -2897,17 +2987,17 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
         /* (the side-specialised builds below the twin form only: there the col side's fourth wave pays — V = 50 k, d = 300        \
          * 96.8 -> 93.4 us per step; on twinned tables, bound by bandwidth, it costs: V = 400 k 577.6 -> 580.0, V = 2 M 361.5 -> 364.2) */ \
         if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 1 && !twin)                                               \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 1 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 1 : -1), nb);                                        \
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? 0 : -1>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 0 : -1), nb);                                        \
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)         /* (tables beyond the caches: the streaming build) */ \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, FUSE == 1 ? -2 : -1>), dim3(nb_launch), dim3(kBlock), 0, st, ARGS); \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? -2 : -1), nb_launch);                                \
         else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION>), dim3(nb), dim3(kBlock), 0, st, ARGS); \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, -1, nb);                                                          \
         else if (FUSE == 1 && twin)                                                                                            \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE, -1, FUSE == 1 ? -2 : -1>), dim3(nb_launch), dim3(kBlock), 0, st, ARGS); \
+            K(LPR, NV, FULL, REC, FUSE, -1, (FUSE == 1 ? -2 : -1), nb_launch);                                                   \
         else                                                                                                                   \
-            hipLaunchKernelGGL((sidepass_kernel<LPR, NV, FULL, REC, FUSE>), dim3(nb), dim3(kBlock), 0, st, ARGS);               \
+            K(LPR, NV, FULL, REC, FUSE, -1, -1, nb);                                                                             \
     } while (0)
 #define CALL(LPR, NV)                                                                   \
     if (LPR * NV == d4) {                                                               \
@@ -2920,6 +3010,7 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     GLOVE_DISPATCH_PASS_SHAPE(shape, CALL);
 #undef CALL
 #undef LAUNCH
+#undef K
 #undef ARGS
     return (int)hipGetLastError();
 }
@@ -2960,6 +3051,7 @@ static int launch_apply_adagrad(const glove_plan *p, const glove_tables *t, cons
     wk.pre_c = pre_c;
     const bool fused = pre_r != kFuseNone || pre_c != kFuseNone;
     wk.per = fused ? fuse_per(p, pass_shape(d4).lpr) : 1;
+    wk.gpb = fused && solid_groups(p) ? kBlock / pass_shape(d4).lpr : 0;
     const int nb = wk.heavy_blocks + blocks_for(2 * (int64_t)p->cap_uniq, kBlock / shape.lpr) + 1;
     // workgroups of the row-side pass, whose loss partials the scalar duty sums (the first launch of the step)
     const int nb_row = fused ? fusepass_blocks(p, pass_shape(d4).lpr, wk.per, true) : rowpass_blocks(p, pass_shape(d4).lpr);

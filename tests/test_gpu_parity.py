@@ -1530,3 +1530,44 @@ def test_full_size_spot_check_against_oracle(hip, workload, B):
             gb = e.sum() + kappa_b * n * ownb0[u].double()
             want_b = ownb0[u].double() - lr * gb / ((0.1 + gb ** 2).sqrt() + 1e-7)
             np.testing.assert_allclose(gotb[u].item(), want_b.item(), rtol=2e-5, atol=1e-6, err_msg="%s bias %d" % (side, u))
+
+
+@pytest.mark.parametrize("V,d", [(300, 64), (200, 300), (400, 128)])
+def test_solid_workgroups_of_heavy_ids(hip, V, d):
+    """From 131,072 chunks a side the run-merged passes add up, per workgroup, the sums of lane groups that all hold the same id
+    ("solid" workgroups: the head of a Zipf batch), and the apply launch enumerates one partial row per solid workgroup (Slots).
+    Forced here with one pair per chunk (chunk_cap = 1: 140,000 chunks a side, the head ids fill dozens of workgroups): every fused
+    form, with chunk records and with run words, against the float64 oracle; the forms agree bit for bit among themselves."""
+    from trainer.hip_api import DeviceTables
+    B = 140000
+    row, col, w, y = make_batch(77, B, V)
+    hp = ref.Hyper(learning_rate=0.05)
+    t = oracle_tables(V, d, "Adagrad")
+    t0 = tables_from_oracle(t, DeviceTables)
+    start = {n: getattr(t0, n).clone() for n in ("R", "C", "br", "bc")}
+    loss, _, _ = ref.train_step(t, row, col, w, y, hp)
+    dev = to_dev(row, col, w, y)
+    plans = {"records": hip.build_plan(*dev, V, chunk_cap=1).compact(hip.lib, d=1 << 20),
+             "run words": hip.build_plan(*dev, V, chunk_cap=1, compact=True, d=t0.d, run_words=True)}
+    assert plans["records"].r_crec is not None and plans["records"].host_counts[0] == B
+    prev = None
+    for kind, plan in plans.items():
+        if kind == "run words" and plan.r_chunk_hw is None:
+            continue
+        for form in (2, 3, 4):
+            if kind == "run words" and form == 2:
+                continue
+            dt = DeviceTables(V, d, "Adagrad", seed=0)
+            for n, x in start.items():
+                getattr(dt, n).copy_(x)
+            if form == 4:
+                dt.enable_twin()
+            loss_out = torch.zeros(4, device="cuda:0")
+            hip.step_adagrad(plan, dt, _hyper(hp, B, step_form=form), loss_out)
+            np.testing.assert_allclose(loss_out[0].item(), loss, rtol=5e-5, err_msg="%s form %d" % (kind, form))
+            assert_tables_close(dt, t, rtol=2e-5, atol=2e-6)
+            now = {n: getattr(dt, n).clone() for n in ("R", "C", "br", "bc")}
+            if prev is not None:
+                for n in now:
+                    assert torch.equal(now[n], prev[n]), (kind, form, n)
+            prev = now
