@@ -268,8 +268,9 @@ template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0, bool SOLID =
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
 // regression build 18 VGPRs at one float4 per lane — 119 against 101 — and 26 spilled scalar registers, whether they run or
 // not.  V = 2 M, d = 128, B = 1 M on the same plans, one process: 397 -> 355 us per step; V = 400 k, d = 300: 562 -> 554)
-// SIDE: -1 / -2 = the launch holds both sides (row side in the first row_blocks workgroups; -2: with the streaming cache policy
-// below, the twin form's launches); 1 / 0 = it holds the row / the col side
+// SIDE: -1 / -2 / -3 = the launch holds both sides (row side in the first row_blocks workgroups; -2 and -3: the twin form's launches,
+// whose col-side launch may carry the list tail — -2 with the streaming cache policy below: row tables of 128 MB and more, -3
+// without: twinned tables the caches hold); 1 / 0 = it holds the row / the col side
 // alone (the three-launch fused form's launches): the col side's build then drops what only the loss needs — |c|^2 of every
 // partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
 // 153: a fourth wave per SIMD).
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD, SOLID>:
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work, ListTail tail)
 {
-    if (FUSE == 1 && SIDE == -2 && tail.first_block >= 0 && (int)blockIdx.x >= tail.first_block) {      // (block-uniform)
+    if (FUSE == 1 && SIDE <= -2 && tail.first_block >= 0 && (int)blockIdx.x >= tail.first_block) {      // (block-uniform)
         list_unfinished_ids(tail, work, ((int)blockIdx.x - tail.first_block) * kBlock + (int)threadIdx.x);
         return;
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD, SOLID>:
     const bool is_row = SIDE < 0 ? (int)blockIdx.x < row_blocks : SIDE == 1;
     const PassSide &sd = is_row ? rowside : colside;
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
-    const int nblk = is_row ? row_blocks : (FUSE == 1 && SIDE == -2 && tail.first_block >= 0 ? tail.first_block : (int)gridDim.x) - row_blocks;
+    const int nblk = is_row ? row_blocks : (FUSE == 1 && SIDE <= -2 && tail.first_block >= 0 ? tail.first_block : (int)gridDim.x) - row_blocks;
     GLOVE_STAMP(0);
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
@@ -2968,6 +2969,9 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
     }
 #define ARGS p->counts, rs, cs, row_blocks, t->scalars, t->step, d4, h->inv_batch, w.blockpart, (int)h->head, h->neg_factor, kc, per, w.work, tail
     const bool solid = fuse && !pack && solid_groups(p);        // (the applying run-merged passes: FUSE == 1)
+    // the twin form's streaming cache policy: row tables beyond the Infinity Cache's reach (on the 61 MB table of V = 50 k, d = 300
+    // it costs 3 - 8 %: the next launch finds the finished rows in the caches there)
+    const bool streaming = (size_t)v_row(t) * (size_t)t->d * 4 >= ((size_t)128 << 20);
     // (the diagnostic row pass stores e by pair position, which the records do not carry: it reads the plain arrays)
     const bool rec = p->r_crec != nullptr && p->c_crec != nullptr && !want_e;
     if (!rec && p->B > 0 && !p->r_partner) return GLOVE_E_BADARG;     // (the diagnostic pass needs pair arrays)
@@ -2990,11 +2994,13 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 1 : -1), nb);                                        \
         else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 0 : -1), nb);                                        \
-        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)         /* (tables beyond the caches: the streaming build) */ \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin && streaming)  /* (tables beyond the caches: the streaming build) */ \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? -2 : -1), nb_launch);                                \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)                                                         \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? -3 : -1), nb_launch);                                \
         else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, -1, nb);                                                          \
-        else if (FUSE == 1 && twin)                                                                                            \
+        else if (FUSE == 1 && twin)                  /* (the logistic heads: one twin build, streaming) */                      \
             K(LPR, NV, FULL, REC, FUSE, -1, (FUSE == 1 ? -2 : -1), nb_launch);                                                   \
         else                                                                                                                   \
             K(LPR, NV, FULL, REC, FUSE, -1, -1, nb);                                                                             \

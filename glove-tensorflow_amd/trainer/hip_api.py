@@ -373,13 +373,17 @@ class DeviceTables:
         self._struct = None
 
     def maybe_enable_twin(self):
-        """The policy: row tables of 128 MB and more — beyond the Infinity Cache, where batches reach the fused step's regime — get the twin.
+        """The policy: row tables of 32 MB and more — where batches reach the fused step's regime — get the twin (128 MB until round 5).
         Measured per step, three-launch form -> twin form with its id triage: V = 400 k, d = 300: 678 -> 627 us;
         V = 2 M, d = 128: 578 -> 539 us (the passes pay ~20 us each for looking up which copy of a row is current, the
         apply launch shrinks from 95 to 15 us); V = 50 k, d = 300 (Infinity-Cache resident): no gain, not enabled."""
         # (round 4, tools/ab_step_forms.py: on the 61 MB table of V = 50 k, d = 300 — Infinity-Cache resident — the three-launch
         # form beats the twin form 101.0 to 103.2 us; on tables beyond the cache the twin form wins by 4 - 11 %)
-        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (128 << 20):
+        # (round 5: without a triage launch — the list of unfinished ids rides in the col-side launch — and without the streaming
+        # cache policy on tables the caches hold, the twin form also wins on the 61 MB table: V = 50 k, d = 300, B = 131,072
+        # 96.2 -> 92.9 us per step, B = 65,536 64.9 -> 64.4, B = 1 M 295.0 -> 292.6: tools/ab_step_forms.py,
+        # profiles/r05_exp_twin_form_on_cache_resident_tables.txt; below 32 MB nothing was measured: not enabled)
+        if self.optimizer == "Adagrad" and self.V_row * self.d * 4 >= (32 << 20):
             self.enable_twin()
 
     def canonicalize(self):

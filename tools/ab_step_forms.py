@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--forms", default="1,3,4")
+    ap.add_argument("--lib", default="", help="another build of libglove_hip.so (default: the one in the tree)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    hip = GloveHip(dev)
+    hip = GloveHip(dev, lib_path=a.lib, any_abi=True) if a.lib else GloveHip(dev)
     wl = synthetic.make_workload(a.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], a.batch_size
     nb = min(a.batches, wl["row"].numel() // B)
