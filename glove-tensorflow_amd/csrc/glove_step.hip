@@ -268,10 +268,10 @@ template <int LPR, int NV, int FUSE, bool REC = true, int HEAD = 0, bool SOLID =
 // GLOVE_HEAD_REGRESSION (every pass of the GloVe estimator: the logistic epilogue's exp / log expansions cost the
 // regression build 18 VGPRs at one float4 per lane — 119 against 101 — and 26 spilled scalar registers, whether they run or
 // not.  V = 2 M, d = 128, B = 1 M on the same plans, one process: 397 -> 355 us per step; V = 400 k, d = 300: 562 -> 554)
-// SIDE: -1 / -2 / -3 = the launch holds both sides (row side in the first row_blocks workgroups; -2 and -3: the twin form's launches,
-// whose col-side launch may carry the list tail — -2 with the streaming cache policy below: row tables of 128 MB and more, -3
-// without: twinned tables the caches hold); 1 / 0 = it holds the row / the col side
-// alone (the three-launch fused form's launches): the col side's build then drops what only the loss needs — |c|^2 of every
+// SIDE: -1 / -2 = the launch holds both sides (row side in the first row_blocks workgroups; -2: the twin form's launches on row
+// tables of 128 MB and more, with the streaming cache policy below); 1 / 0 = it holds the row / the col side
+// alone (the three-launch fused form's launches, and the twin form's on tables the caches hold; the col-side launch of the twin
+// form — SIDE 0 or -2 — may carry the list tail): the col side's build then drops what only the loss needs — |c|^2 of every
 // partner row (a fifth of a trip's arithmetic), the bias squares, e . diff — and with them 17 - 27 VGPRs (d = 300: 126 against
 // 153: a fourth wave per SIMD).
 // The twin form's col-side launch carries, behind its pass workgroups, the workgroups that list the light ids the apply launch
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD, SOLID>:
     const float *__restrict__ scalars, int64_t *__restrict__ step, int d4, float inv_batch,
     float *__restrict__ blockpart, int head, float neg_factor, StepConsts kc, int per, int32_t *__restrict__ work, ListTail tail)
 {
-    if (FUSE == 1 && SIDE <= -2 && tail.first_block >= 0 && (int)blockIdx.x >= tail.first_block) {      // (block-uniform)
+    if (FUSE == 1 && (SIDE == -2 || SIDE == 0) && tail.first_block >= 0 && (int)blockIdx.x >= tail.first_block) {      // (block-uniform)
         list_unfinished_ids(tail, work, ((int)blockIdx.x - tail.first_block) * kBlock + (int)threadIdx.x);
         return;
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock, (FusePass<LPR, NV, FUSE, REC, HEAD, SOLID>:
     const bool is_row = SIDE < 0 ? (int)blockIdx.x < row_blocks : SIDE == 1;
     const PassSide &sd = is_row ? rowside : colside;
     const int bid = is_row ? blockIdx.x : blockIdx.x - row_blocks;
-    const int nblk = is_row ? row_blocks : (FUSE == 1 && SIDE <= -2 && tail.first_block >= 0 ? tail.first_block : (int)gridDim.x) - row_blocks;
+    const int nblk = is_row ? row_blocks : (FUSE == 1 && (SIDE == -2 || SIDE == 0) && tail.first_block >= 0 ? tail.first_block : (int)gridDim.x) - row_blocks;
     GLOVE_STAMP(0);
     const int n_chunks = sd.n_host >= 0 ? sd.n_host : counts[sd.count_index];
     const float g = scalars[0];
@@ -2988,16 +2988,15 @@ static int launch_passes(const glove_plan *p, const glove_tables *t, const glove
         /* every pass compiled for the regression head (the same bits are asked of all of them on ids one chunk holds: one     \
          * epilogue, one set of contraction decisions); the logistic heads keep the run-time branch (compiled alone their      \
          * d = 300 build spills) */                                                                                             \
-        /* (the side-specialised builds below the twin form only: there the col side's fourth wave pays — V = 50 k, d = 300        \
-         * 96.8 -> 93.4 us per step; on twinned tables, bound by bandwidth, it costs: V = 400 k 577.6 -> 580.0, V = 2 M 361.5 -> 364.2) */ \
-        if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 1 && !twin)                                               \
+        /* (the side-specialised builds on tables the caches hold — three-launch form and twin form alike: there the col side's     \
+         * fourth wave pays, V = 50 k, d = 300 96.8 -> 93.4 us per step; on tables beyond them, bound by bandwidth, it costs:        \
+         * V = 400 k 577.6 -> 580.0, V = 2 M 361.5 -> 364.2) */ \
+        if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 1 && !(twin && streaming))                                \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 1 : -1), nb);                                        \
-        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !twin)                                          \
-            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 0 : -1), nb);                                        \
-        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin && streaming)  /* (tables beyond the caches: the streaming build) */ \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && which == 2 && !(twin && streaming))                           \
+            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? 0 : -1), nb_launch);                                 \
+        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)         /* (tables beyond the caches: the streaming build) */ \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? -2 : -1), nb_launch);                                \
-        else if (h->head == GLOVE_HEAD_REGRESSION && FUSE == 1 && twin)                                                         \
-            K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, (FUSE == 1 ? -3 : -1), nb_launch);                                \
         else if (h->head == GLOVE_HEAD_REGRESSION)                                                                              \
             K(LPR, NV, FULL, REC, FUSE, GLOVE_HEAD_REGRESSION, -1, nb);                                                          \
         else if (FUSE == 1 && twin)                  /* (the logistic heads: one twin build, streaming) */                      \
