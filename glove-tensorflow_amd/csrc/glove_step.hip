@@ -1341,11 +1341,42 @@ __global__ void sum_headers_kernel(PackedLists pls, float *__restrict__ acc4, in
     acc4[0] = t[0]; acc4[1] = t[1]; acc4[2] = t[2]; acc4[3] = t[3];
 }
 
+// Keras-legacy Nadam on the same two-part kernel (the legacy optimizer's sparse path decays m and v over the whole variable like
+// its Adam, but only the touched rows move: optimizer_v2/nadam.py `_resource_apply_sparse`; restated in oracle/glove_ref.py _nadam).
+// The momentum cache — the running product of the schedule u_i = beta1 (1 - 0.5 0.96^(0.004 i)) — lives in scalars[4 + parity]:
+// step t reads slot (t - 1) & 1 and its scalar epilogue writes slot t & 1, so no workgroup of step t sees the new value.
+struct NadamConsts { float lr, eps, b1, b2, one_minus_u_t, u_t1, om_new, om_next, v_den, sched_new; };
+__device__ inline NadamConsts nadam_consts(float lr, float eps, float b1, float b2, double ln_beta2, int64_t t, const float *scalars)
+{
+#pragma clang fp contract(off)
+    const double ln096 = -0.040821994520255166;                 // ln 0.96
+    const float u_t = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)t * ln096)));
+    const float u_t1 = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)(t + 1) * ln096)));
+    const float cache = scalars[4 + (int)((t - 1) & 1)];
+    NadamConsts k;
+    k.lr = lr; k.eps = eps; k.b1 = b1; k.b2 = b2;
+    k.sched_new = cache * u_t;
+    k.one_minus_u_t = 1.0f - u_t;
+    k.u_t1 = u_t1;
+    k.om_new = 1.0f - k.sched_new;
+    k.om_next = 1.0f - k.sched_new * u_t1;
+    k.v_den = -expm1f((float)((double)t * ln_beta2));
+    return k;
+}
+__device__ inline void nadam_elem(float &w, float &m, float &v, float g, const NadamConsts &k)
+{
+#pragma clang fp contract(off)
+    m = m * k.b1 + (1.0f - k.b1) * g;
+    v = v * k.b2 + (1.0f - k.b2) * g * g;
+    const float m_bar = k.one_minus_u_t * (g / k.om_new) + k.u_t1 * (m / k.om_next);
+    w -= k.lr * m_bar / (sqrtf(v / k.v_den) + k.eps);
+}
+
 // ---- the element updates of the per-row Keras optimizers (SGD, Adamax, Adadelta, Ftrl): include/glove_hip.h glove_hyper.optimizer;
 // used by the apply epilogues of the single-GPU step (SparseOptApply) and of the touched-rows exchange (apply_packed_kernel)
 struct OptConsts { float lr, eps, momentum, lr_t, b1, b2; int nesterov; float rho; };
 template <int OPT> struct OptSlots {
-    static constexpr bool two = OPT == GLOVE_OPT_ADAMAX || OPT == GLOVE_OPT_ADADELTA || OPT == GLOVE_OPT_FTRL;
+    static constexpr bool two = OPT == GLOVE_OPT_ADAMAX || OPT == GLOVE_OPT_ADADELTA || OPT == GLOVE_OPT_FTRL || OPT == GLOVE_OPT_NADAM;
 };
 template <int OPT>
 struct OptElem {
@@ -1381,13 +1412,16 @@ struct OptElem {
         v = fmaxf(o.b2 * v, fabsf(g));
         w -= o.lr_t * m / (v + o.eps);
     }
-    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o)
+    // (nk: Nadam's constants of this step — the touched-rows exchange only: apply_packed_kernel; a = m, b = v)
+    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o, const NadamConsts &nk)
     {
         if (OPT == GLOVE_OPT_SGD) sgd(w, a, g, o);
         else if (OPT == GLOVE_OPT_ADAMAX) adamax(w, a, b, g, o);
         else if (OPT == GLOVE_OPT_ADADELTA) adadelta(w, a, b, g, o);
+        else if (OPT == GLOVE_OPT_NADAM) nadam_elem(w, a, b, g, nk);
         else ftrl(w, a, b, g, o);
     }
+    __device__ static void one(float &w, float &a, float &b, float g, const OptConsts &o) { one(w, a, b, g, o, NadamConsts{}); }
 };
 
 // A lane group walks entries gg, gg + TG, gg + 2 TG, ... (TG lane groups in the launch).  Looked up one entry at a time
@@ -1399,6 +1433,33 @@ struct OptElem {
 // under all of them, so the exchange is the same and the epilogue differs.  s2: the second slot of every variable where the
 // optimizer has one (scalars[2] for the global bias).
 struct SlotTwo { float *R, *C, *br, *bc; };
+
+// Nadam on the touched-rows exchange: m and v of every row NO rank touched decay (Keras' legacy sparse Nadam decays them over
+// the whole variable); the rows some rank touched — marked by count_packed_kernel — are apply_packed_kernel's, the next launch.
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void nadam_decay_unmarked_kernel(DenseViews dv, SideBufs rs, SideBufs cs, SlotTwo s2, int d4,
+                                                                      float b1, float b2, int V)
+{
+    constexpr int GPB = kBlock / LPR;
+    const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int total = dv.V_row + V;
+    for (int v = blockIdx.x * GPB + grp; v < total; v += gridDim.x * GPB) {
+        if (dv.mark[v] & kMarkCountMask) continue;
+        const bool is_row = v < dv.V_row;
+        const int id = is_row ? v : v - dv.V_row;
+        const SideBufs &sb = is_row ? rs : cs;
+        float *S2 = is_row ? s2.R : s2.C, *S2b = is_row ? s2.br : s2.bc;
+        f4 M[NV], Vv[NV];
+        load_row<LPR, NV>(M, sb.S1, id, d4, lg);
+        load_row<LPR, NV>(Vv, S2, id, d4, lg);
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) { M[kk] = b1 * M[kk]; Vv[kk] = b2 * Vv[kk]; }
+        store_row<LPR, NV>(sb.S1, (size_t)id, d4, lg, M);
+        store_row<LPR, NV>(S2, (size_t)id, d4, lg, Vv);
+        if (lg == 0) { sb.S1b[id] = b1 * sb.S1b[id]; S2b[id] = b2 * S2b[id]; }
+    }
+}
+
 template <int LPR, int NV, int OPT>
 __global__ __launch_bounds__(kBlock) void apply_packed_kernel(
     PackedLists pls, DenseViews dv, SideBufs rs, SideBufs cs, SlotTwo s2, int d4, StepConsts k, OptConsts o, double ln_beta1,
@@ -1411,6 +1472,10 @@ __global__ __launch_bounds__(kBlock) void apply_packed_kernel(
     const bool slots = kAdagrad || !(OPT == GLOVE_OPT_SGD && o.momentum == 0.f);     // (plain SGD keeps no slot)
     // t = global_step as the passes of this step left it (Adamax: lr_t = lr / (1 - beta1^t), as apply_sparse_opt_kernel)
     if (OPT == GLOVE_OPT_ADAMAX) o.lr_t = o.lr / -expm1f((float)((double)(*step) * ln_beta1));
+    // Nadam (the ranks' touched rows move; every other row's m and v have decayed in nadam_decay_unmarked_kernel, the launch before):
+    // the constants of step t = global_step as the passes left it; ln_beta1 carries ln beta2 here
+    NadamConsts nk = {};
+    if (OPT == GLOVE_OPT_NADAM) nk = nadam_consts(o.lr, o.eps, o.b1, o.b2, ln_beta1, *step, scalars);
     const int lg = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const size_t stride4 = (size_t)d4 + 1;
     const PackedList &pl = pls.l[blockIdx.y];
@@ -1489,7 +1554,7 @@ __global__ __launch_bounds__(kBlock) void apply_packed_kernel(
                         if constexpr (kTwo) { bb[0] = Bv[e][kk].x; bb[1] = Bv[e][kk].y; bb[2] = Bv[e][kk].z; bb[3] = Bv[e][kk].w; }
                         const float g[4] = {G[e][kk].x, G[e][kk].y, G[e][kk].z, G[e][kk].w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) OptElem<OPT>::one(w[i], a[i], bb[i], g[i], o);
+                        for (int i = 0; i < 4; ++i) OptElem<OPT>::one(w[i], a[i], bb[i], g[i], o, nk);
                         Wv[e][kk] = f4{w[0], w[1], w[2], w[3]};
                         A[e][kk] = f4{a[0], a[1], a[2], a[3]};
                         if constexpr (kTwo) Bv[e][kk] = f4{bb[0], bb[1], bb[2], bb[3]};
@@ -1500,7 +1565,7 @@ __global__ __launch_bounds__(kBlock) void apply_packed_kernel(
                 store_row<LPR, NV>(W, (size_t)id[e], d4, lg, Wv[e]);
                 if (lg == 0) {
                     if constexpr (kAdagrad) adagrad_elem(bval[e], Ab[e], Gb[e], k.lr, k.eps);
-                    else OptElem<OPT>::one(bval[e], Ab[e], Bb[e], Gb[e], o);
+                    else OptElem<OPT>::one(bval[e], Ab[e], Bb[e], Gb[e], o, nk);
                     if (slots) (is_row[e] ? rs.S1b : cs.S1b)[id[e]] = Ab[e];
                     if constexpr (kTwo) (is_row[e] ? s2.br : s2.bc)[id[e]] = Bb[e];
                     (is_row[e] ? rs.bias : cs.bias)[id[e]] = bval[e];
@@ -1529,8 +1594,9 @@ __global__ __launch_bounds__(kBlock) void apply_packed_kernel(
             adagrad_elem(scalars[0], scalars[1], dg, k.lr, k.eps);
         } else {
             float gn = g, a = scalars[1], b = scalars[2];
-            OptElem<OPT>::one(gn, a, b, dg, o);
+            OptElem<OPT>::one(gn, a, b, dg, o, nk);
             scalars[0] = gn; scalars[1] = a; scalars[2] = b;
+            if (OPT == GLOVE_OPT_NADAM) scalars[4 + (int)(*step & 1)] = nk.sched_new;      // the momentum cache (see nadam_consts)
         }
         if (loss_out) { loss_out[0] = loss; loss_out[1] = L; loss_out[2] = reg; loss_out[3] = t[0]; }
     }
@@ -2497,37 +2563,6 @@ struct AdamApply {
     }
 };
 
-// Keras-legacy Nadam on the same two-part kernel (the legacy optimizer's sparse path decays m and v over the whole variable like
-// its Adam, but only the touched rows move: optimizer_v2/nadam.py `_resource_apply_sparse`; restated in oracle/glove_ref.py _nadam).
-// The momentum cache — the running product of the schedule u_i = beta1 (1 - 0.5 0.96^(0.004 i)) — lives in scalars[4 + parity]:
-// step t reads slot (t - 1) & 1 and its scalar epilogue writes slot t & 1, so no workgroup of step t sees the new value.
-struct NadamConsts { float lr, eps, b1, b2, one_minus_u_t, u_t1, om_new, om_next, v_den, sched_new; };
-__device__ inline NadamConsts nadam_consts(float lr, float eps, float b1, float b2, double ln_beta2, int64_t t, const float *scalars)
-{
-#pragma clang fp contract(off)
-    const double ln096 = -0.040821994520255166;                 // ln 0.96
-    const float u_t = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)t * ln096)));
-    const float u_t1 = b1 * (1.0f - 0.5f * expf((float)(0.004 * (double)(t + 1) * ln096)));
-    const float cache = scalars[4 + (int)((t - 1) & 1)];
-    NadamConsts k;
-    k.lr = lr; k.eps = eps; k.b1 = b1; k.b2 = b2;
-    k.sched_new = cache * u_t;
-    k.one_minus_u_t = 1.0f - u_t;
-    k.u_t1 = u_t1;
-    k.om_new = 1.0f - k.sched_new;
-    k.om_next = 1.0f - k.sched_new * u_t1;
-    k.v_den = -expm1f((float)((double)t * ln_beta2));
-    return k;
-}
-__device__ inline void nadam_elem(float &w, float &m, float &v, float g, const NadamConsts &k)
-{
-#pragma clang fp contract(off)
-    m = m * k.b1 + (1.0f - k.b1) * g;
-    v = v * k.b2 + (1.0f - k.b2) * g * g;
-    const float m_bar = k.one_minus_u_t * (g / k.om_new) + k.u_t1 * (m / k.om_next);
-    w -= k.lr * m_bar / (sqrtf(v / k.v_den) + k.eps);
-}
-
 template <int LPR, int NV>
 struct NadamApply {
     SideBufs rs, cs;
@@ -3360,15 +3395,17 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
     if (!t->R || !t->C || !t->br || !t->bc || !t->scalars || !t->s1_R || !t->s1_C || !t->s1_br || !t->s1_bc) return GLOVE_E_BADARG;
     // glove_hyper.optimizer: Adagrad, or one of the per-row Keras optimizers (only touched rows move: the exchange is the same)
     const int opt = h->optimizer;
-    const bool two_slots = opt == GLOVE_OPT_ADAMAX || opt == GLOVE_OPT_ADADELTA || opt == GLOVE_OPT_FTRL;
+    const bool two_slots = opt == GLOVE_OPT_ADAMAX || opt == GLOVE_OPT_ADADELTA || opt == GLOVE_OPT_FTRL || opt == GLOVE_OPT_NADAM;
     if (opt != GLOVE_OPT_ADAGRAD && opt != GLOVE_OPT_SGD && !two_slots) return GLOVE_E_BADARG;
     if (two_slots && (!t->s2_R || !t->s2_C || !t->s2_br || !t->s2_bc)) return GLOVE_E_BADARG;
-    if (opt == GLOVE_OPT_ADAMAX && (!(h->beta1 > 0.0 && h->beta1 < 1.0) || !(h->beta2 > 0.0 && h->beta2 < 1.0) || !t->step)) return GLOVE_E_BADARG;
+    if ((opt == GLOVE_OPT_ADAMAX || opt == GLOVE_OPT_NADAM) &&
+        (!(h->beta1 > 0.0 && h->beta1 < 1.0) || !(h->beta2 > 0.0 && h->beta2 < 1.0) || !t->step)) return GLOVE_E_BADARG;
+    if (opt == GLOVE_OPT_NADAM && sides_of(h) != 3) return GLOVE_E_BADARG;                 // (m and v of BOTH tables decay every step)
     if (opt == GLOVE_OPT_ADADELTA && !(h->rho > 0.f && h->rho < 1.f)) return GLOVE_E_BADARG;
     if (opt == GLOVE_OPT_FTRL && !(h->learning_rate > 0.f)) return GLOVE_E_BADARG;
     if (opt == GLOVE_OPT_SGD && !(h->momentum >= 0.f && h->momentum < 1.f)) return GLOVE_E_BADARG;
     const OptConsts o = {h->learning_rate, h->epsilon, h->momentum, 0.f, (float)h->beta1, (float)h->beta2, h->nesterov ? 1 : 0, h->rho};
-    const double ln_b1 = opt == GLOVE_OPT_ADAMAX ? log((double)(float)h->beta1) : 0.0;
+    const double ln_b1 = opt == GLOVE_OPT_ADAMAX ? log((double)(float)h->beta1) : opt == GLOVE_OPT_NADAM ? log((double)(float)h->beta2) : 0.0;
     const SlotTwo s2 = {t->s2_R, t->s2_C, t->s2_br, t->s2_bc};
     if (int rc = plain_table(t, stream)) return rc;
     const int d4 = t->d / 4;
@@ -3393,6 +3430,15 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
         }
         tail = scratch;
     }
+    if (opt == GLOVE_OPT_NADAM) {
+        // the rows nobody touched: m and v decay (the marks are still whole: the apply launches below clear them as they go)
+        const int nbd = blocks_for((int64_t)v_row(t) + t->V, kBlock / shape.lpr);
+#define CALL(LPR, NV)                                                                                               \
+        hipLaunchKernelGGL((nadam_decay_unmarked_kernel<LPR, NV>), dim3(nbd), dim3(kBlock), 0, st, dv, rs, cs, s2, d4,   \
+                           (float)h->beta1, (float)h->beta2, (int)t->V)
+        GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
+#undef CALL
+    }
     for (int32_t first = 0; first < n_lists; first += 8) {
         PackedLists pls;
         pls.n = n_lists - first < 8 ? n_lists - first : 8;
@@ -3412,6 +3458,7 @@ int glove_apply_packed_adagrad_f32(const glove_packed_list *lists, int32_t n_lis
         else if (opt == GLOVE_OPT_SGD) LAUNCH_OPT(LPR, NV, GLOVE_OPT_SGD);                                          \
         else if (opt == GLOVE_OPT_ADAMAX) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADAMAX);                                    \
         else if (opt == GLOVE_OPT_ADADELTA) LAUNCH_OPT(LPR, NV, GLOVE_OPT_ADADELTA);                                \
+        else if (opt == GLOVE_OPT_NADAM) LAUNCH_OPT(LPR, NV, GLOVE_OPT_NADAM);                                      \
         else LAUNCH_OPT(LPR, NV, GLOVE_OPT_FTRL)
         GLOVE_DISPATCH_ROW_SHAPE(shape, CALL);
 #undef LAUNCH_OPT

@@ -144,8 +144,6 @@ class Estimator:
         stream = self.stream()
         hyper_kwargs = dict(l2_reg=p["l2_reg"], reg_mult=p.get("reg_multiplicity", 2.0),
                             learning_rate=p["learning_rate"], optimizer=self.optimizer_name)
-        if self.world > 1 and self.optimizer_name == "Nadam":
-            raise ValueError("Nadam runs on one GPU (the data-parallel form takes the seven other Keras optimizers; the sharded forms Adagrad)")
         if p.get("step_form"):
             hyper_kwargs["step_form"] = int(p["step_form"])
             if int(p["step_form"]) == 4 and self.world == 1:

@@ -331,10 +331,10 @@ class Stepper(GraphedSteps):
     Which optimizers (`tf.keras.optimizers.get`, reference train_utils.py:13-16) run on several ranks, and how:
     Adagrad either way; the per-row ones (SGD, Adamax, Adadelta, Ftrl: only touched rows move) on the touched-rows
     exchange, whose apply takes their epilogue; the dense-decay ones (Adam, RMSprop: every row's slots move every step) on
-    the dense all-reduce.  Nadam (m, v decay everywhere, touched rows move: it needs the union of the ranks' id marks) runs on
-    one GPU only."""
+    the dense all-reduce.  Nadam (m, v decay everywhere, touched rows move) rides the touched-rows exchange too: the lists
+    ARE the union of the ranks' ids — the rows no list names decay (a sweep in front of the apply), the named ones move."""
 
-    ROWS_ONLY = ("SGD", "Adamax", "Adadelta", "Ftrl")       # per-row optimizers: touched-rows exchange
+    ROWS_ONLY = ("SGD", "Adamax", "Adadelta", "Ftrl", "Nadam")       # touched-rows exchange (the lists carry the union of the ids)
     DENSE_ONLY = ("Adam", "RMSprop")                        # dense-decay optimizers: dense all-reduce
 
     def __init__(self, backend, tables, hyper_kwargs: dict, batch_size: int, world=1, dist=None, exchange="auto",
@@ -354,7 +354,7 @@ class Stepper(GraphedSteps):
         if exchange == "dense" and self._multi and tables.optimizer in self.ROWS_ONLY:
             raise ValueError("%s runs on the touched-rows exchange (its dense form would need the ranks' id marks)" % tables.optimizer)
         if self._multi and tables.optimizer not in ("Adagrad",) + self.ROWS_ONLY + self.DENSE_ONLY:
-            raise ValueError("the data-parallel form takes Adagrad, SGD, Adamax, Adadelta, Ftrl, Adam and RMSprop, got %s" % tables.optimizer)
+            raise ValueError("the data-parallel form takes the eight Keras names (Adagrad, SGD, Adamax, Adadelta, Ftrl, Nadam, Adam, RMSprop), got %s" % tables.optimizer)
         if self._multi and tables.optimizer in self.ROWS_ONLY:
             exchange = "rows"
         self.hyper = backend.make_hyper(batch_size=batch_size * self.world, **hyper_kwargs)
@@ -380,7 +380,7 @@ class Stepper(GraphedSteps):
         Stream whose batches are indexed as they are used (`plans` None, `batch_size` given: reshuffled epochs): from the
         most ids a batch of that size can touch — the lists' capacity has to hold any batch."""
         world = self.world if force_world is None else force_world
-        if self.tables.optimizer in self.DENSE_ONLY + ("Nadam",) or self.exchange == "dense" or (
+        if self.tables.optimizer in self.DENSE_ONLY or self.exchange == "dense" or (
                 world == 1 and not self._multi and self.exchange != "rows"):
             return
         if self.G is None:

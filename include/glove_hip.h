@@ -407,7 +407,8 @@ int glove_count_packed_f32(const glove_packed_list *lists, int32_t n_lists, cons
 int glove_combine_packed_f32(const glove_packed_list *list, int32_t tag, const glove_tables *t, float *G_flat,
                              int32_t *mark, int64_t capacity_entries, void *stream);
 /* The optimizer glove_hyper.optimizer names — Adagrad, or one of the per-row Keras optimizers (GLOVE_OPT_SGD, _ADAMAX, _ADADELTA,
- * _FTRL: only touched rows move under them, so they ride the same exchange; their second slots are glove_tables.s2_*) — on
+ * _FTRL: only touched rows move under them, so they ride the same exchange; their second slots are glove_tables.s2_*; and
+ * GLOVE_OPT_NADAM, both sides in one call: the rows NO list names have their m and v decayed first, the named ones move) — on
  * every id the lists touched (lists[i] was combined with tag i): each id is applied from the list that
  * touched it first, its mark is cleared.  tail: device float[4] {sum_e, sum w diff^2, sum |r|^2+|c|^2, sum b^2}
  * already summed over the ranks, or NULL = summed here over the lists' headers in list order.  With the col side

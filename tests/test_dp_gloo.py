@@ -60,7 +60,9 @@ def _worker(rank, port, optimizer, out_dir, exchange="dense", extra=None):
     # the other names tf.keras.optimizers.get resolves (train_utils.py:13-16): per-row ones on the touched-rows exchange
     # (whatever was asked for), the dense-decay RMSprop on the all-reduce
     ("SGD", "auto", {}), ("SGD", "rows", dict(momentum=0.9, nesterov=True)), ("Adamax", "auto", {}), ("Adadelta", "auto", {}),
-    ("Ftrl", "auto", {}), ("RMSprop", "auto", {})])
+    ("Ftrl", "auto", {}), ("RMSprop", "auto", {}),
+    # Nadam: m and v decay everywhere, the union of the ranks' touched rows moves — the lists are that union
+    ("Nadam", "auto", {})])
 def test_two_ranks_equal_one_rank_on_the_joint_batch(tmp_path, optimizer, exchange, extra):
     """Dense all-reduce and touched-rows all-gather: either way two ranks == one rank on the joint batch."""
     sys.path.insert(0, str(HERE.parent / "oracle"))

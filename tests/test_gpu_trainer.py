@@ -818,8 +818,8 @@ def test_train_then_train_more_in_one_interpreter(hip, tmp_path):
 def test_other_optimizers_on_the_data_parallel_form_through_rccl_with_one_rank(hip):
     """The other Keras names `tf.keras.optimizers.get` resolves (reference train_utils.py:13-16) on the multi-rank data-parallel
     form, every collective issued through RCCL on this one GPU (`collectives=True`): the per-row optimizers (SGD with and
-    without momentum, Adamax, Adadelta, Ftrl) ride the touched-rows all-gather — glove_apply_packed_adagrad_f32 takes their
-    epilogue from glove_hyper.optimizer —, RMSprop the dense all-reduce (glove_dense_adam_f32's RMSprop sweep).  Three steps ==
+    without momentum, Adamax, Adadelta, Ftrl, and Nadam, whose untouched rows' m and v decay in a sweep in front of the apply) ride the
+    touched-rows all-gather — glove_apply_packed_adagrad_f32 takes their epilogue from glove_hyper.optimizer —, RMSprop the dense all-reduce (glove_dense_adam_f32's RMSprop sweep).  Three steps ==
     the float64 oracle and == the single-GPU step (glove_step_sparse_f32) on the same batches."""
     import os
     import torch.distributed as dist
@@ -833,8 +833,8 @@ def test_other_optimizers_on_the_data_parallel_form_through_rccl_with_one_rank(h
         backend = HipBackend("cuda:0")
         batches = [make_batch(60 + s, B, V) for s in range(steps)]
         for optimizer, extra in (("SGD", {}), ("SGD", dict(momentum=0.9, nesterov=True)), ("Adamax", {}), ("Adadelta", {}),
-                                 ("Ftrl", {}), ("RMSprop", {})):
-            lr = {"Adadelta": 1.0, "Ftrl": 0.05}.get(optimizer, 0.01)
+                                 ("Ftrl", {}), ("RMSprop", {}), ("Nadam", {})):
+            lr = {"Adadelta": 1.0, "Ftrl": 0.05, "Nadam": 0.002}.get(optimizer, 0.01)
             hp = ref.Hyper(learning_rate=lr, **extra)
             t = oracle_tables(V, d, optimizer)
             multi_t, single_t = _device_tables(t), _device_tables(t)        # (fresh tables: the slots at their Keras initial values)
