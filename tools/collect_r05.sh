@@ -1,8 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box: every committed profile of round 5 (profiles/r05_*), regenerated from the bench commands with the
 # library in the tree.  Output: gpurun_out/profiles_r05/ (copy into profiles/).  One log per configuration.
+# Usage: bash tools/collect_r05.sh [names...]   e.g. "c4d c4s c5d c5s" (default: all)
 t=r05
-c() { name=$1; shift; bash tools/collect_profiles.sh $t "$@" > gpurun_out/prof_$name.log 2>&1 || { echo "$name FAILED"; tail -5 gpurun_out/prof_$name.log; }; echo "$name done"; date; }
+want=" ${*:-c4d c4s c5d c5s c3d c3s t8 t1k c1} "
+c() { name=$1; shift; case "$want" in *" $name "*) ;; *) return;; esac
+      bash tools/collect_profiles.sh $t "$@" > gpurun_out/prof_$name.log 2>&1 || { echo "$name FAILED"; tail -5 gpurun_out/prof_$name.log; }; echo "$name done"; date; }
 c c4d c4_v400k_d300_b1m_index_rebuilt zipf_v400k_d300 1048576 40
 c c4s c4_v400k_d300_b1m_static_index zipf_v400k_d300 1048576 40 --static-index
 c c5d c5_v2m_d128_b1m_index_rebuilt zipf_v2m_d128 1048576 40
