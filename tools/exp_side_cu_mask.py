@@ -37,11 +37,13 @@ def main():
     ap.add_argument("--batch-size", type=int, default=1048576)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--shares", default="0,1,2,4,8")
+    ap.add_argument("--lib", default="", help="another build of libglove_hip.so")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.zeros(1, device=dev)
     hiplib = ctypes.CDLL("libamdhip64.so")
-    hip = GloveHip(dev)
+    hip = GloveHip(dev, lib_path=args.lib, any_abi=True) if args.lib else GloveHip(dev)
+    print('lib:', args.lib or 'in-tree', flush=True)
     wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], args.batch_size
     print("%s B=%d: us per step of the runner over %d steps (two timed runs each)" % (args.workload, B, args.steps), flush=True)
