@@ -361,6 +361,16 @@ __device__ inline int64_t run_start_of(const int32_t *__restrict__ keys, int64_t
     const int lane = threadIdx.x & 63;
     const int32_t key = keys[pos];
     int64_t lo = 0, hi = pos;                              // answer in [lo, hi]; keys[hi] >= key throughout
+    if (pos > 0) {
+        // most runs of a batch are a few pairs long: the 64 positions in front of pos first, in the same round trip as the key —
+        // one round for every run that starts among them instead of the three or four of the search over [0, pos]
+        const int64_t q = pos - 1 - lane;
+        const bool other = q >= 0 && keys[q] != key;       // (sorted: a different key in front of pos is a smaller one)
+        const unsigned long long m = __ballot(other);
+        if (m != 0) return pos - (__ffsll((long long)m) - 1);      // first lane whose position differs: the run starts right behind it
+        if (pos < 64) return 0;                            // everything in front of pos holds the key
+        hi = pos - 64;                                     // keys[pos - 64 .. pos] all hold the key
+    }
     while (lo < hi) {
         // 64 probes spread over the undecided positions lo .. hi-1
         const int64_t n = hi - lo, step = (n + 63) / 64;
@@ -388,6 +398,15 @@ __device__ inline int64_t run_end_of(const int32_t *__restrict__ keys, int64_t B
     const int lane = threadIdx.x & 63;
     const int32_t key = keys[pos];
     int64_t lo = pos + 1, hi = B;                          // answer in [lo, hi]; everything below lo holds the key
+    {
+        // the 64 positions behind pos first (see run_start_of)
+        const int64_t q = pos + 1 + lane;
+        const bool other = q < B && keys[q] != key;
+        const unsigned long long m = __ballot(other);
+        if (m != 0) return pos + 1 + (__ffsll((long long)m) - 1);
+        if (pos + 65 >= B) return B;                       // everything behind pos holds the key
+        lo = pos + 65;
+    }
     while (lo < hi) {
         const int64_t n = hi - lo, step = (n + 63) / 64;
         int64_t q = lo + step * lane;
