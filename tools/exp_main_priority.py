@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The default mode with the steps on a HIGH-priority stream (the side stream of deals and index builds stays at normal priority)
-against the steps on the default stream: two runners in one process, timed runs alternating (process-to-process spread is 2 - 3 %).
+"""The default mode with the steps on a HIGH-priority stream (the side stream of deals and index builds stays at normal priority),
+and with the side stream at the LOWEST priority HIP offers (hipStreamCreateWithPriority), against the trainer's streams: runners in
+one process, timed runs alternating (process-to-process spread is 2 - 3 %).
 Usage: python tools/exp_main_priority.py [--workload zipf_v400k_d300] [--batch-size 1048576] [--steps 230]"""
 import argparse
 import sys
@@ -28,14 +29,24 @@ def main():
     hip = GloveHip(dev)
     wl = synthetic.make_workload(args.workload, device=dev, work_device=dev)
     V, d, B = wl["V"], wl["d"], args.batch_size
+    import ctypes
+    hiplib = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(), ctypes.c_int()
+    hiplib.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest))
+    print("stream priorities: least %d, greatest %d" % (least.value, greatest.value), flush=True)
     runs = {}
-    for name, main_stream in (("default stream", torch.cuda.current_stream(dev)), ("high-priority stream", torch.cuda.Stream(device=dev, priority=-1))):
+    for name, main_stream in (("default stream", torch.cuda.current_stream(dev)), ("high-priority stream", torch.cuda.Stream(device=dev, priority=-1)),
+                              ("default, side lowest", torch.cuda.current_stream(dev))):
         with torch.cuda.stream(main_stream):
             backend = HipBackend(dev)
             backend.hip = hip
             tables = DeviceTables(V, d, "Adagrad", device=dev, seed=1)
             backend.row_floats = tables.d
             stream = NonzeroStream({k: wl[k] for k in ("row", "col", "w", "y")}, B, V, backend, dev, seed=0, static_plans=False)
+            if name.endswith("side lowest"):
+                h = ctypes.c_void_p()
+                assert hiplib.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) == 0        # 1 = hipStreamNonBlocking
+                stream.side = torch.cuda.ExternalStream(h.value, device=dev)
             runner = ReshufflingRunner(hip, stream, tables, make_hyper(batch_size=B, learning_rate=0.05), burst=64)
             torch.cuda.synchronize()
         runs[name] = (main_stream, runner, [])
